@@ -1,0 +1,450 @@
+"""CPU oracle for the xarray-spatial dense-raster hot path (TEST INFRASTRUCTURE ONLY).
+
+This module is the *checker*, never the product: only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+it.  Nothing under `xrspatial_amd/` imports it, and the product raises when
+the HIP library is missing rather than falling back to this code.
+
+What it is: a dtype-explicit NumPy restatement of the reference's *CPU* path
+(Numba `@ngjit` loops and plain NumPy), written from the reference's behaviour,
+each function citing the reference file:line it follows.  The reference cannot
+be imported in this environment (numba / xarray / datashader absent, SURVEY.md
+§8c), so parity is pinned instead against every golden vector the reference's
+own tests hold for this path (tests/golden/reference_vectors.npz, extracted by
+tests/golden/make_golden.py) -- see tests/test_oracle_golden.py.
+
+Why "dtype-explicit": Numba types `int64_literal * float32` as float64, so the
+reference's "float32" CPU kernels do their arithmetic in float64 and only the
+final store rounds to float32.  NumPy 2 would keep such an expression in
+float32, so every promotion below is spelled out by hand.
+
+Third-party arithmetic the path relies on (not vendored in the reference):
+  * numba (unpinned in setup.cfg:20-24; semantics read from numba 0.54.1
+    np/arraymath.py:963-1108): nanmean = float64 accumulator / count;
+    nanvar = two-pass float64; nanstd = nanvar ** 0.5; nansum = accumulator of
+    the array dtype (float32 here), row-major; nanmin/nanmax seeded with
+    element 0, NaN-skipping.
+  * numpy (installed: the reference's hillshade and zonal.stats are pure NumPy,
+    so for those two the restatement calls the same NumPy primitives).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+def _nan_like(shape, dtype=F32):
+    out = np.empty(shape, dtype=dtype)
+    out[...] = np.nan
+    return out
+
+
+# --------------------------------------------------------------------------
+# 3x3 terrain stencils
+# --------------------------------------------------------------------------
+
+def slope(data, cellsize_x, cellsize_y):
+    """Planar Horn slope in degrees.  Reference: xrspatial/slope.py:56-76 (`_cpu`).
+
+    a,b,c = row y+1; g,h,i = row y-1 (slope.py:64-71).  Sums, division, sqrt and
+    arctan are float64 (int literal * float32 -> float64 under Numba); the store
+    into the float32 output rounds once.  One-cell NaN border.
+    """
+    z = np.asarray(data).astype(F32).astype(F64)
+    out = _nan_like(z.shape)
+    if z.shape[0] < 3 or z.shape[1] < 3:
+        return out
+    up, mid, dn = z[2:], z[1:-1], z[:-2]      # rows y+1, y, y-1
+    a, b, c = up[:, :-2], up[:, 1:-1], up[:, 2:]
+    d, f = mid[:, :-2], mid[:, 2:]
+    g, h, i = dn[:, :-2], dn[:, 1:-1], dn[:, 2:]
+    with np.errstate(all="ignore"):
+        dz_dx = ((c + 2 * f + i) - (a + 2 * d + g)) / (8 * float(cellsize_x))
+        dz_dy = ((g + 2 * h + i) - (a + 2 * b + c)) / (8 * float(cellsize_y))
+        p = (dz_dx * dz_dx + dz_dy * dz_dy) ** .5
+        out[1:-1, 1:-1] = (np.arctan(p) * 57.29578).astype(F32)
+    return out
+
+
+def aspect(data):
+    """Planar aspect, compass degrees, -1 on flat cells.
+
+    Reference: xrspatial/aspect.py:56-90 (`_run_numpy`): a,b,c = row y-1,
+    g,h,i = row y+1, divisor 8 (cell size ignored), float64 throughout, no
+    359.999 clamp on the CPU path.
+    """
+    z = np.asarray(data).astype(F32).astype(F64)
+    out = _nan_like(z.shape)
+    if z.shape[0] < 3 or z.shape[1] < 3:
+        return out
+    up, mid, dn = z[:-2], z[1:-1], z[2:]      # rows y-1, y, y+1
+    a, b, c = up[:, :-2], up[:, 1:-1], up[:, 2:]
+    d, f = mid[:, :-2], mid[:, 2:]
+    g, h, i = dn[:, :-2], dn[:, 1:-1], dn[:, 2:]
+    with np.errstate(all="ignore"):
+        dz_dx = ((c + 2 * f + i) - (a + 2 * d + g)) / 8
+        dz_dy = ((g + 2 * h + i) - (a + 2 * b + c)) / 8
+        ang = np.arctan2(dz_dy, -dz_dx) * (180 / np.pi)
+        compass = np.where(ang < 0, 90.0 - ang,
+                           np.where(ang > 90.0, 360.0 - ang + 90.0, 90.0 - ang))
+        flat = (dz_dx == 0) & (dz_dy == 0)
+        res = np.where(flat, -1.0, compass)
+        # a NaN gradient is neither flat nor comparable: arctan2 gives NaN
+        out[1:-1, 1:-1] = res.astype(F32)
+    return out
+
+
+def curvature(data, cellsize):
+    """Reference: xrspatial/curvature.py:31-49 (`_cpu`, cast at :47).
+
+    Neighbour-pair sums are float32 (f32 + f32), the rest float64
+    (`/ 2` with an int literal promotes), result stored as float32.
+    """
+    z = np.asarray(data).astype(F32)
+    out = _nan_like(z.shape)
+    if z.shape[0] < 3 or z.shape[1] < 3:
+        return out
+    c = z[1:-1, 1:-1].astype(F64)
+    with np.errstate(all="ignore"):
+        vert = (z[2:, 1:-1] + z[:-2, 1:-1]).astype(F64) / 2 - c
+        horz = (z[1:-1, 2:] + z[1:-1, :-2]).astype(F64) / 2 - c
+        cs = float(cellsize)
+        out[1:-1, 1:-1] = (-2 * (vert + horz) * 100 / (cs * cs)).astype(F32)
+    return out
+
+
+def hillshade(data, azimuth=225, angle_altitude=25):
+    """Reference: xrspatial/hillshade.py:20-35 (`_run_numpy`) -- pure NumPy.
+
+    float32 gradients / slope / aspect; the final combine is float64 under
+    NumPy >= 2 because `np.sin(altituderad)` is a strongly typed np.float64
+    scalar.  Cell size is ignored.  4 edges NaN.
+    Returns float64 (what the reference returns with the installed NumPy 2).
+    """
+    z = np.asarray(data).astype(F32)
+    az = 360.0 - azimuth
+    with np.errstate(all="ignore"):
+        gy, gx = np.gradient(z)                      # axis-0 first, as the reference unpacks (x, y)
+        slope_ = np.pi / 2. - np.arctan(np.sqrt(gy * gy + gx * gx))
+        aspect_ = np.arctan2(-gy, gx)
+        azr = az * np.pi / 180.
+        alr = angle_altitude * np.pi / 180.
+        shaded = np.sin(alr) * np.sin(slope_) + \
+            np.cos(alr) * np.cos(slope_) * np.cos((azr - np.pi / 2.) - aspect_)
+        res = (shaded + 1) / 2
+    res[(0, -1), :] = np.nan
+    res[:, (0, -1)] = np.nan
+    return res
+
+
+# --------------------------------------------------------------------------
+# per-cell multispectral indices
+# --------------------------------------------------------------------------
+
+def normalized_ratio(arr1, arr2):
+    """(a-b)/(a+b), NaN where a+b == 0, pure float32.
+
+    Reference: xrspatial/multispectral.py:825-841 (`_normalized_ratio_cpu`),
+    inputs `.astype('f4')` at :727.
+    """
+    a = np.asarray(arr1).astype(F32)
+    b = np.asarray(arr2).astype(F32)
+    out = _nan_like(a.shape)
+    with np.errstate(all="ignore"):
+        num = a - b
+        den = a + b
+        ok = ~(den == 0.0)
+        np.divide(num, den, out=out, where=ok)
+    return out
+
+
+def evi(nir, red, blue, c1=6.0, c2=7.5, soil_factor=1.0, gain=2.5):
+    """Reference: xrspatial/multispectral.py:175-188 (`_evi_cpu`).
+
+    numerator float32; denominator float64 (c1, c2, soil_factor are Python
+    floats); gain * (f32 / f64) float64; stored float32.
+    """
+    n = np.asarray(nir).astype(F32)
+    r = np.asarray(red).astype(F32)
+    b = np.asarray(blue).astype(F32)
+    out = _nan_like(n.shape)
+    with np.errstate(all="ignore"):
+        num = (n - r).astype(F64)
+        den = n.astype(F64) + float(c1) * r.astype(F64) - float(c2) * b.astype(F64) + float(soil_factor)
+        ok = den != 0.0
+        val = float(gain) * (num / den)
+        out[ok] = val[ok].astype(F32)
+    return out
+
+
+def savi(nir, red, soil_factor=1.0):
+    """Reference: xrspatial/multispectral.py:876-890 (`_savi_cpu`).
+
+    numerator float32, `nir + red` float32, then `+ soil_factor` float64.
+    """
+    n = np.asarray(nir).astype(F32)
+    r = np.asarray(red).astype(F32)
+    out = _nan_like(n.shape)
+    with np.errstate(all="ignore"):
+        num = (n - r).astype(F64)
+        soma = (n + r).astype(F64) + float(soil_factor)
+        den = soma * (1.0 + float(soil_factor))
+        ok = den != 0.0
+        val = num / den
+        out[ok] = val[ok].astype(F32)
+    return out
+
+
+# --------------------------------------------------------------------------
+# k x k kernels
+# --------------------------------------------------------------------------
+
+def convolve_2d(data, kernel):
+    """Correlation (no flip), NaN border of k//2, NaN propagating.
+
+    Reference: xrspatial/convolution.py:285-313 (`_convolve_2d_numpy`):
+    float64 accumulator `num = 0.0`, taps visited row-major, product
+    `kernel[..] * data[..]` promoted to float64, stored float32.
+    """
+    z = np.asarray(data).astype(F32).astype(F64)
+    k = np.asarray(kernel)
+    kf = k.astype(F64)
+    nx, ny = z.shape
+    nkx, nky = k.shape
+    wkx, wky = nkx // 2, nky // 2
+    out = _nan_like(z.shape)
+    ox, oy = nx - 2 * wkx, ny - 2 * wky
+    if ox <= 0 or oy <= 0:
+        return out
+    acc = np.zeros((ox, oy), dtype=F64)
+    with np.errstate(all="ignore"):
+        for ii in range(nkx):
+            for jj in range(nky):
+                acc += kf[ii, jj] * z[ii:ii + ox, jj:jj + oy]
+    out[wkx:nx - wkx, wky:ny - wky] = acc.astype(F32)
+    return out
+
+
+def focal_mean3x3(data, excludes=(np.nan,), passes=1):
+    """Reference: xrspatial/focal.py:44-67 (`_mean_numpy`), :257-259 (passes loop).
+
+    Works on float64 (`agg.data.astype(float)`).  3x3 window clamped to the
+    raster, `np.nanmean` (float64 sum in row-major order / count; 0/0 -> NaN);
+    a cell equal to any `excludes` value (NaN == NaN counted equal, :37-41) is
+    passed through unchanged.
+    """
+    cur = np.asarray(data).astype(F64)
+    rows, cols = cur.shape
+    for _ in range(int(passes)):
+        pad = np.full((rows + 2, cols + 2), np.nan, dtype=F64)
+        pad[1:-1, 1:-1] = cur
+        acc = np.zeros((rows, cols), dtype=F64)
+        cnt = np.zeros((rows, cols), dtype=np.int64)
+        for dy in range(3):
+            for dx in range(3):
+                v = pad[dy:dy + rows, dx:dx + cols]
+                ok = ~np.isnan(v)
+                acc += np.where(ok, v, 0.0)
+                cnt += ok
+        with np.errstate(all="ignore"):
+            mean = acc / cnt
+        excl = np.zeros((rows, cols), dtype=bool)
+        for ex in excludes:
+            if isinstance(ex, float) and np.isnan(ex) or (
+                    isinstance(ex, np.floating) and np.isnan(ex)):
+                excl |= np.isnan(cur)
+            else:
+                excl |= (cur == ex)
+        cur = np.where(excl, cur, mean)
+    return cur
+
+
+FOCAL_STATS = ('mean', 'max', 'min', 'range', 'std', 'var', 'sum')
+
+
+def _window_stack(z32, kernel):
+    """(ntaps, H, W) float32 stack of the taps where kernel == 1, row-major tap order.
+
+    Out-of-raster taps are NaN, which is what the reference's NaN-prefilled
+    scratch holds for them (focal.py:318-324).
+    """
+    k = np.asarray(kernel)
+    krows, kcols = k.shape
+    hr, hc = int(krows / 2), int(kcols / 2)
+    rows, cols = z32.shape
+    pad = np.full((rows + 2 * hr, cols + 2 * hc), np.nan, dtype=F32)
+    pad[hr:hr + rows, hc:hc + cols] = z32
+    taps = []
+    for ky in range(krows):
+        for kx in range(kcols):
+            if k[ky, kx] == 1:
+                taps.append(pad[ky:ky + rows, kx:kx + cols])
+    return taps
+
+
+def focal_apply(data, kernel, stat='mean'):
+    """focal.apply / focal_stats with one of the built-in `_calc_*` reducers.
+
+    Reference: xrspatial/focal.py:305-326 (`_apply_numpy`): float32 scratch
+    pre-filled NaN, taps gathered only where in-bounds and `kernel == 1`;
+    reducers focal.py:268-302 with Numba's nan-reduction semantics (module
+    docstring).  Output float32 (`np.zeros_like(data)` on the f32 cast).
+    """
+    z = np.asarray(data).astype(F32)
+    taps = _window_stack(z, kernel)
+    rows, cols = z.shape
+    with np.errstate(all="ignore"):
+        if not taps:   # kernel has no 1s: scratch stays all-NaN
+            if stat == 'sum':
+                return np.zeros((rows, cols), dtype=F32)
+            return _nan_like((rows, cols))
+        if stat in ('mean', 'var', 'std'):
+            acc = np.zeros((rows, cols), dtype=F64)
+            cnt = np.zeros((rows, cols), dtype=np.int64)
+            for v in taps:
+                ok = ~np.isnan(v)
+                acc += np.where(ok, v.astype(F64), 0.0)
+                cnt += ok
+            mean = acc / cnt
+            if stat == 'mean':
+                return mean.astype(F32)
+            ssd = np.zeros((rows, cols), dtype=F64)
+            for v in taps:
+                ok = ~np.isnan(v)
+                dlt = v.astype(F64) - mean
+                ssd += np.where(ok, dlt * dlt, 0.0)
+            var = ssd / cnt
+            if stat == 'var':
+                return var.astype(F32)
+            return (var ** 0.5).astype(F32)
+        if stat == 'sum':
+            acc32 = np.zeros((rows, cols), dtype=F32)
+            for v in taps:
+                ok = ~np.isnan(v)
+                acc32 = np.where(ok, acc32 + v, acc32).astype(F32)
+            return acc32
+        if stat in ('min', 'max', 'range'):
+            mn = taps[0].copy()
+            mx = taps[0].copy()
+            for v in taps[1:]:
+                ok = ~np.isnan(v)
+                # numba: `if not isnan(v): if not (ret < v): ret = v`  (NaN seed is replaced)
+                mn = np.where(ok & ~(mn < v), v, mn)
+                mx = np.where(ok & ~(mx > v), v, mx)
+            if stat == 'min':
+                return mn
+            if stat == 'max':
+                return mx
+            return (mx - mn).astype(F32)
+    raise ValueError(stat)
+
+
+def focal_stats(data, kernel, stats_funcs=FOCAL_STATS):
+    """Reference: xrspatial/focal.py:782-797 -- one `apply` pass per stat, stacked."""
+    return np.stack([focal_apply(data, kernel, s) for s in stats_funcs])
+
+
+# --------------------------------------------------------------------------
+# kernels (host-side helpers; reference: xrspatial/convolution.py:137-282)
+# --------------------------------------------------------------------------
+
+def circle_kernel(cellsize_x, cellsize_y, radius):
+    """0/1 float64 ellipse mask; half sizes int(r/cellsize).  convolution.py:137-196."""
+    hw = int(float(radius) / cellsize_x)
+    hh = int(float(radius) / cellsize_y)
+    x = np.linspace(-hw, hw, 2 * hw + 1)
+    y = np.linspace(-hh, hh, 2 * hh + 1)[:, None]
+    return ((x * hh) ** 2 + (y * hw) ** 2 <= (hw * hh) ** 2).astype(float)
+
+
+def annulus_kernel(cellsize_x, cellsize_y, outer_radius, inner_radius):
+    """Outer circle minus centred inner circle.  convolution.py:199-259."""
+    ko = circle_kernel(cellsize_x, cellsize_y, outer_radius)
+    ki = circle_kernel(cellsize_x, cellsize_y, inner_radius)
+    pr = (ko.shape[0] - ki.shape[0]) // 2
+    pc = (ko.shape[1] - ki.shape[1]) // 2
+    return ko - np.pad(ki, ((pr, pr), (pc, pc)), mode='constant')
+
+
+# --------------------------------------------------------------------------
+# zonal.stats (NumPy backend of the reference is plain NumPy: restated with the
+# same primitives -- argsort, unique, per-zone slices, ndarray reductions)
+# --------------------------------------------------------------------------
+
+def _majority(v):
+    vals, counts = np.unique(v, return_counts=True)
+    return vals[np.argmax(counts)]
+
+
+ZONAL_DEFAULT = dict(
+    mean=lambda z: z.mean(),
+    max=lambda z: z.max(),
+    min=lambda z: z.min(),
+    sum=lambda z: z.sum(),
+    std=lambda z: z.std(),
+    var=lambda z: z.var(),
+    count=lambda z: np.ma.count(z),
+    majority=_majority,
+)
+
+
+def zonal_stats(zones, values, zone_ids=None, stats_funcs=None, nodata_values=None,
+                return_type='table'):
+    """Reference: xrspatial/zonal.py:280-332 (`_stats_numpy`), :121-141
+    (`_sort_and_stride`), :105-118 (`_strides`), :144-163 (`_calc_stats`),
+    defaults :71-80.
+
+    Returns {'zone': ids, stat: float64 array, ...} (the DataFrame columns), or
+    the (S, H, W) float64 back-projection when return_type == 'array'.
+    Values are NOT cast: reductions run in the values dtype (float32 pairwise
+    sums for float32 input) and are widened into a float64 result (:153).
+    """
+    zones = np.asarray(zones)
+    values = np.asarray(values)
+    if stats_funcs is None:
+        stats_funcs = list(ZONAL_DEFAULT)
+    if isinstance(stats_funcs, (list, tuple)):
+        stats_funcs = {s: ZONAL_DEFAULT[s] for s in stats_funcs}
+
+    uniq = np.unique(zones[np.isfinite(zones)])
+    if zone_ids is None:
+        sel_ids = uniq
+    else:
+        sel_ids = [z for z in np.unique(zone_ids) if z in uniq]
+
+    flat_z = zones.ravel()
+    order = np.argsort(flat_z)                      # same (unstable) sort the reference calls
+    sorted_z = flat_z[order]
+    vals_by_zone = values.ravel()[order]
+    sorted_z = sorted_z[np.isfinite(sorted_z)]
+    breaks = np.searchsorted(sorted_z, uniq, side='right')   # == _strides (zonal.py:105-118)
+
+    def calc(func):
+        res = np.full(uniq.shape, np.nan)
+        start = 0
+        for i in range(len(uniq)):
+            end = breaks[i]
+            if uniq[i] in sel_ids:
+                zv = vals_by_zone[start:end]
+                zv = zv[np.isfinite(zv) & (zv != nodata_values)]
+                if len(zv) > 0:
+                    res[i] = func(zv)
+            start = end
+        return res
+
+    sel_idx = [i for i, z in enumerate(uniq) if z in sel_ids]
+    if return_type == 'table':
+        out = {'zone': np.asarray(sel_ids)}
+        for name, func in stats_funcs.items():
+            out[name] = calc(func)[sel_idx]
+        return out
+
+    result = np.full((len(stats_funcs), values.size), np.nan)
+    for sid, (name, func) in enumerate(stats_funcs.items()):
+        res = calc(func)
+        for iz in sel_idx:
+            lo = 0 if iz == 0 else breaks[iz - 1]
+            result[sid][order[lo:breaks[iz]]] = res[iz]
+    return result.reshape(len(stats_funcs), *values.shape)

@@ -1,0 +1,237 @@
+"""Pin the CPU oracle against every golden vector the reference's tests hold for
+the hot path.  No GPU, no HIP library involved."""
+import numpy as np
+import pytest
+
+from oracle import xrs_oracle as orc
+
+
+def test_slope_qgis(golden):
+    # xrspatial/tests/test_slope.py:22-52: res=(1,1), rtol 1e-5 on the interior
+    out = orc.slope(golden["dem_nan_row"], 1, 1)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out[1:-1, 1:-1], golden["qgis_slope"][1:-1, 1:-1],
+                               rtol=1e-5, equal_nan=True)
+    assert np.isnan(out[0]).all() and np.isnan(out[-1]).all()
+    assert np.isnan(out[:, 0]).all() and np.isnan(out[:, -1]).all()
+
+
+def test_aspect_qgis(golden):
+    # xrspatial/tests/test_aspect.py:20-47
+    out = orc.aspect(golden["dem_nan_row"])
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out[1:-1, 1:-1], golden["qgis_aspect"][1:-1, 1:-1],
+                               rtol=1e-5, equal_nan=True)
+
+
+@pytest.mark.parametrize("which", ["curv_convex", "curv_concave"])
+def test_curvature_spikes(golden, which):
+    # xrspatial/tests/test_curvature.py:27-83, res=(1,1) -> cellsize 1
+    out = orc.curvature(golden[which + "__0"], 1.0)
+    np.testing.assert_allclose(out, golden[which + "__1"], rtol=1e-6, equal_nan=True)
+    assert out.dtype == np.float32
+
+
+@pytest.mark.parametrize("shape", [(2, 4), (10, 15)])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.uint32, np.uint64, np.float32, np.float64])
+def test_curvature_flat(shape, dtype):
+    # xrspatial/tests/test_curvature.py:14-24, 62-69
+    out = orc.curvature(np.zeros(shape, dtype=dtype), 1)
+    exp = np.zeros(shape, np.float32)
+    exp[0] = exp[-1] = np.nan
+    exp[:, 0] = exp[:, -1] = np.nan
+    np.testing.assert_array_equal(out, exp)
+
+
+def test_hillshade_docstring():
+    # xrspatial/hillshade.py:153-170 (the only numeric known answer the reference has)
+    data = np.array([[0., 0., 0., 0., 0.],
+                     [0., 1., 0., 2., 0.],
+                     [0., 0., 3., 0., 0.],
+                     [0., 0., 0., 0., 0.],
+                     [0., 0., 0., 0., 0.]])
+    exp = np.array([[0.71130913, 0.44167341, 0.71130913],
+                    [0.95550163, 0.71130913, 0.52478473],
+                    [0.71130913, 0.88382559, 0.71130913]])
+    out = orc.hillshade(data)
+    np.testing.assert_allclose(out[1:-1, 1:-1], exp, rtol=0, atol=2e-7)
+    assert np.isnan(out[0]).all() and np.isnan(out[:, -1]).all()
+
+
+def test_hillshade_gaussian_positive():
+    # xrspatial/tests/test_hillshade.py:17-41
+    x = np.linspace(0, 50, 101)
+    X, Y = np.meshgrid(x, x, sparse=True)
+    g = np.exp((-(X - 25) ** 2 - (Y - 25) ** 2) / 50.0) / 12.5
+    out = orc.hillshade(g)
+    assert np.nanmean(out) > 0 and out[60, 60] > 0
+
+
+def test_terrain_compass_rose():
+    # xrspatial/analytics.py:22-76 docstring: +/-1 spikes on a 5x8 zero grid
+    data = np.zeros((5, 8), dtype=np.float64)
+    data[2, 2] = 1
+    data[2, 5] = -1
+    s = orc.slope(data, 1, 1)
+    a = orc.aspect(data)
+    c = orc.curvature(data, 1)
+    np.testing.assert_allclose(s[1:4, 1:4], [[10.024988, 14.036243, 10.024988],
+                                             [14.036243, 0., 14.036243],
+                                             [10.024988, 14.036243, 10.024988]], rtol=1e-6)
+    np.testing.assert_allclose(a[1:4, 1:4], [[315., 0., 45.], [270., -1., 90.], [225., 180., 135.]])
+    np.testing.assert_allclose(a[1:4, 4:7], [[135., 180., 225.], [90., -1., 270.], [45., 0., 315.]])
+    np.testing.assert_allclose(c[1:4, 1:4], [[0, -100, 0], [-100, 400, -100], [0, -100, 0]])
+    np.testing.assert_allclose(c[1:4, 4:7], [[0, 100, 0], [100, -400, 100], [0, 100, 0]])
+
+
+def test_kernels(golden):
+    # xrspatial/tests/test_focal.py:126-197
+    np.testing.assert_array_equal(orc.circle_kernel(1, 1, 1), golden["kernel_circle_1_1_1"])
+    np.testing.assert_array_equal(orc.annulus_kernel(2, 2, 2, 1), golden["kernel_annulus_2_2_2_1"])
+    assert orc.circle_kernel(1, 1, 2).shape == (5, 5) and orc.circle_kernel(1, 1, 2).sum() == 13
+    assert orc.circle_kernel(1, 1, 12).shape == (25, 25) and orc.circle_kernel(1, 1, 12).sum() == 441
+    # convolution.py:167-181 docstring
+    assert orc.circle_kernel(1, 2, 3).tolist() == [[0, 0, 0, 1, 0, 0, 0], [1] * 7, [0, 0, 0, 1, 0, 0, 0]]
+
+
+def test_convolve_2d(golden):
+    # xrspatial/tests/test_focal.py:113-225
+    d = golden["conv_data"]
+    np.testing.assert_allclose(orc.convolve_2d(d, golden["conv_custom__0"]),
+                               golden["conv_custom__1"], equal_nan=True)
+    np.testing.assert_allclose(orc.convolve_2d(d, golden["kernel_circle_1_1_1"]),
+                               golden["conv_expected_circle"], equal_nan=True)
+    np.testing.assert_allclose(orc.convolve_2d(d, golden["kernel_annulus_2_2_2_1"]),
+                               golden["conv_expected_annulus"], equal_nan=True)
+
+
+def test_convolution_2d_docstring():
+    # xrspatial/convolution.py:431-453
+    data = np.arange(24).reshape(4, 6)
+    kernel = orc.circle_kernel(1, 1, 1)
+    out = orc.convolve_2d(data, kernel)
+    np.testing.assert_array_equal(out[1:3, 1:5], [[35, 40, 45, 50], [65, 70, 75, 80]])
+    assert out.dtype == np.float32 and np.isnan(out[0]).all()
+
+
+def test_focal_stats_4x4(golden):
+    # xrspatial/tests/test_focal.py:353-394; order mean,max,min,range,std,var,sum
+    out = orc.focal_stats(golden["focal_stats__0"], golden["focal_stats__1"])
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, golden["focal_stats__2"], rtol=1e-6, equal_nan=True)
+
+
+def test_focal_apply_docstring():
+    # xrspatial/focal.py:371-392 (circle kernel mean over a 4x4 of ones-like arange)
+    data = np.arange(20, dtype=np.float64).reshape(4, 5)
+    k = orc.circle_kernel(2, 2, 3)
+    out = orc.focal_apply(data, k, 'mean')
+    exp = np.array([[2., 2.25, 3.25, 4.25, 5.33333333],
+                    [5.25, 6., 7., 8., 8.75],
+                    [10.25, 11., 12., 13., 13.75],
+                    [13.66666667, 14.75, 15.75, 16.75, 17.]])
+    np.testing.assert_allclose(out, exp, rtol=1e-6)
+
+
+def test_focal_mean_docstring():
+    # xrspatial/focal.py:195-234
+    data = np.zeros((5, 5))
+    data[2, 2] = 9
+    one = orc.focal_mean3x3(data)
+    exp1 = np.zeros((5, 5))
+    exp1[1:4, 1:4] = 1
+    np.testing.assert_allclose(one, exp1)
+    two = orc.focal_mean3x3(data, passes=2)
+    exp2 = np.array([[0.25, 1 / 3, 0.5, 1 / 3, 0.25],
+                     [1 / 3, 4 / 9, 2 / 3, 4 / 9, 1 / 3],
+                     [0.5, 2 / 3, 1.0, 2 / 3, 0.5],
+                     [1 / 3, 4 / 9, 2 / 3, 4 / 9, 1 / 3],
+                     [0.25, 1 / 3, 0.5, 1 / 3, 0.25]])
+    np.testing.assert_allclose(two, exp2, rtol=1e-12)
+    # NaN centre cells are in the default excludes -> passed through
+    d = data.copy()
+    d[0, 0] = np.nan
+    assert np.isnan(orc.focal_mean3x3(d)[0, 0])
+
+
+def test_multispectral_qgis(golden):
+    # xrspatial/tests/test_multispectral.py:114-283, 363-470
+    nir, red, blue = golden["ms_nir"], golden["ms_red"], golden["ms_blue"]
+    out = orc.normalized_ratio(nir, red)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, golden["qgis_ndvi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.savi(nir, red, 0.0), golden["qgis_ndvi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.savi(nir, red, 1.0), golden["qgis_savi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.evi(nir, red, blue), golden["qgis_evi"], rtol=1e-6, equal_nan=True)
+    # other normalized-ratio indices share the kernel (nbr, nbr2, ndmi)
+    np.testing.assert_allclose(orc.normalized_ratio(nir, golden["ms_swir2"]), golden["qgis_nbr"],
+                               rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.normalized_ratio(golden["ms_swir1"], golden["ms_swir2"]),
+                               golden["qgis_nbr2"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.normalized_ratio(nir, golden["ms_swir1"]), golden["qgis_ndmi"],
+                               rtol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16"])
+def test_multispectral_uint(golden, dtype):
+    # xrspatial/tests/test_multispectral.py:286-336
+    b1, b2, exp = (golden["uint_nratio__%d" % i] for i in range(3))
+    np.testing.assert_allclose(orc.normalized_ratio(b1.astype(dtype), b2.astype(dtype)), exp, rtol=1e-6)
+    n, r, b, exp = (golden["uint_evi__%d" % i] for i in range(4))
+    np.testing.assert_allclose(orc.evi(n.astype(dtype), r.astype(dtype), b.astype(dtype)), exp, rtol=1e-6)
+    n, r, exp = (golden["uint_savi__%d" % i] for i in range(3))
+    np.testing.assert_allclose(orc.savi(n.astype(dtype), r.astype(dtype)), exp, rtol=1e-6)
+
+
+def _check_table(res, exp, rtol=1e-5, atol=1e-7):
+    assert list(res) == list(exp) or set(res) == set(exp)
+    assert (np.asarray(res['zone']) == np.asarray(exp['zone'])).all()
+    for col in exp:
+        if col != 'zone':
+            np.testing.assert_allclose(res[col], exp[col], rtol=rtol, atol=atol, equal_nan=True)
+
+
+def test_zonal_default(golden, golden_tables):
+    # xrspatial/tests/test_zonal.py:31-90, 408-426
+    res = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"])
+    _check_table(res, golden_tables["zonal_default"])
+    arr = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"], return_type='array')
+    np.testing.assert_allclose(arr, golden["zonal_default_da"], rtol=1e-5, atol=1e-7, equal_nan=True)
+
+
+def test_zonal_zone_ids(golden, golden_tables):
+    # xrspatial/tests/test_zonal.py:131-202, 453-494
+    ids = golden_tables["zonal_zone_ids__0"]
+    res = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"], zone_ids=ids)
+    _check_table(res, golden_tables["zonal_zone_ids__1"])
+    arr = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"], zone_ids=ids, return_type='array')
+    np.testing.assert_allclose(arr, golden["zonal_zone_ids_da__1"], rtol=1e-5, atol=1e-7, equal_nan=True)
+
+
+def test_zonal_custom(golden, golden_tables):
+    # xrspatial/tests/test_zonal.py:204-237, 497-544
+    funcs = {'double_sum': lambda v: v.sum() * 2, 'range': lambda v: v.max() - v.min()}
+    nodata, ids, exp = (golden_tables["zonal_custom__%d" % i] for i in range(3))
+    res = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"], zone_ids=ids,
+                          stats_funcs=funcs, nodata_values=nodata)
+    _check_table(res, exp)
+    arr = orc.zonal_stats(golden["zonal_zones"], golden["zonal_values"], zone_ids=ids,
+                          stats_funcs=funcs, nodata_values=nodata, return_type='array')
+    np.testing.assert_allclose(arr, golden["zonal_custom_da__2"], equal_nan=True)
+
+
+def test_zonal_majority_ties():
+    # xrspatial/tests/test_zonal.py:567-590
+    z = np.array([[1, 1, 1, 1], [1, 1, 2, 2], [2, 2, 2, 2]])
+    v = np.array([[1, 1, 2, 2], [3, 3, 5, 5], [5, 5, 6, 6]])
+    res = orc.zonal_stats(z, v, stats_funcs=['majority'])
+    assert res['zone'].tolist() == [1, 2] and res['majority'].tolist() == [1, 5]
+
+
+def test_zonal_qgis(golden, golden_tables):
+    # xrspatial/tests/test_zonal.py:340-385, 593-601
+    exp = golden_tables["zonal_qgis"]
+    res = orc.zonal_stats(golden["zones_8x6"], golden["dem"],
+                          stats_funcs=[k for k in exp if k != 'zone'])
+    _check_table(res, exp, atol=1e-5)
+    assert res['count'].tolist() == exp['count']

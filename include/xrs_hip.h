@@ -1,0 +1,183 @@
+/*
+ * xrs_hip.h -- C ABI of libxrs_hip.so, the MI355X (gfx950) backend for the dense 2-D
+ * raster hot path of xarray-spatial.
+ *
+ * The reference has no FFI of its own: its only extension seam is the four-slot
+ * backend table ArrayTypeFunctionMapping(numpy_func, cupy_func, dask_func,
+ * dask_cupy_func) (xrspatial/utils.py:117-143) whose slots are per-backend
+ * "runner" functions taking raw arrays.  Each entry point below replaces one such
+ * runner (cited per function); the Python host layer (xrspatial_amd/) binds them
+ * with ctypes and keeps validation / metadata / Dataset handling above the ABI.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; the message of the
+ *    calling thread's last failure is read with xrs_last_error().
+ *  - plain pointers and sizes only.  Pointers named *_dev are device (HBM)
+ *    pointers obtained from xrs_malloc(); everything else is host memory.
+ *  - the caller owns every buffer; the library never allocates outputs, never
+ *    frees inputs, and keeps no global mutable state (re-entrant: the reference's
+ *    Numba kernels are nogil and may be called from several threads).
+ *  - rasters are C-order float32 planes: element (y, x) of a plane `p` with row
+ *    pitch `ld` (in ELEMENTS) is p[y * ld + x].  `rows` counts the rows this call
+ *    OWNS (and writes); `halo_top` / `halo_bot` say how many extra valid input
+ *    rows sit directly above `in_dev` (at negative row indices) / below row
+ *    rows-1.  0 means that side is a true raster edge.  This is the row-shard
+ *    contract of the multi-GPU path (reference semantics: dask
+ *    map_overlap(depth=k//2, boundary=nan), e.g. xrspatial/slope.py:94-97).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    kernels are asynchronous on it.
+ */
+#ifndef XRS_HIP_H
+#define XRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ runtime */
+int xrs_version(void);                                   /* ABI version, currently 1 */
+int xrs_last_error(char *buf, size_t buflen);            /* copies the thread's last error text */
+int xrs_device_count(int *count);
+int xrs_set_device(int device);
+int xrs_get_device(int *device);
+int xrs_device_name(int device, char *buf, size_t buflen);
+int xrs_mem_info(size_t *free_bytes, size_t *total_bytes);
+int xrs_malloc(void **ptr_dev, size_t bytes);
+int xrs_free(void *ptr_dev);
+int xrs_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
+int xrs_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
+int xrs_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int xrs_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
+int xrs_stream_create(void **stream);
+int xrs_stream_destroy(void *stream);
+int xrs_stream_sync(void *stream);
+int xrs_device_sync(void);
+int xrs_event_create(void **event);
+int xrs_event_destroy(void *event);
+int xrs_event_record(void *event, void *stream);
+int xrs_event_sync(void *event);
+int xrs_event_elapsed_ms(void *start_event, void *stop_event, float *ms);
+
+/* --------------------------------------------------------- 3x3 terrain family
+ * One-cell NaN border on true raster edges.  Replace the runners
+ *   slope      xrspatial/slope.py:79-83      (_run_numpy -> _cpu :56-76)
+ *   aspect     xrspatial/aspect.py:56-90     (_run_numpy)
+ *   curvature  xrspatial/curvature.py:44-49  (_run_numpy -> _cpu :31-41)
+ *   hillshade  xrspatial/hillshade.py:20-35  (_run_numpy)
+ * Arithmetic follows the reference's CPU path (float64 gradient sums), not its
+ * all-float32 CuPy kernels.  Outputs are float32; hillshade can also write
+ * float64 (out_f64 != 0), which is what the reference returns under NumPy >= 2. */
+int xrs_slope_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
+                  int64_t ld_in, int64_t ld_out, double cellsize_x, double cellsize_y,
+                  int halo_top, int halo_bot, void *stream);
+int xrs_aspect_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
+                   int64_t ld_in, int64_t ld_out, int halo_top, int halo_bot, void *stream);
+int xrs_curvature_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
+                      int64_t ld_in, int64_t ld_out, double cellsize,
+                      int halo_top, int halo_bot, void *stream);
+int xrs_hillshade_f32(const float *in_dev, void *out_dev, int out_f64, int64_t rows, int64_t cols,
+                      int64_t ld_in, int64_t ld_out, double azimuth, double angle_altitude,
+                      int halo_top, int halo_bot, void *stream);
+
+/* Fused variant: one read of the DEM, up to four outputs.  Any of the output
+ * pointers may be NULL (that product is skipped).  Same results as the four
+ * separate calls.  (The reference's summarize_terrain, xrspatial/analytics.py,
+ * makes three separate passes.) */
+int xrs_terrain_fused_f32(const float *in_dev, float *slope_dev, float *aspect_dev,
+                          float *curvature_dev, float *hillshade_dev,
+                          int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                          double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
+                          int halo_top, int halo_bot, void *stream);
+
+/* ----------------------------------------------------------- per-cell indices
+ * Flat arrays of n float32 cells, NaN where the denominator is exactly 0.
+ *   normalized_ratio  xrspatial/multispectral.py:825-841 (_normalized_ratio_cpu: ndvi/nbr/nbr2/ndmi)
+ *   evi               xrspatial/multispectral.py:175-188 (_evi_cpu)
+ *   savi              xrspatial/multispectral.py:876-890 (_savi_cpu) */
+int xrs_normalized_ratio_f32(const float *a_dev, const float *b_dev, float *out_dev, int64_t n, void *stream);
+int xrs_evi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev,
+                int64_t n, double c1, double c2, double soil_factor, double gain, void *stream);
+int xrs_savi_f32(const float *nir_dev, const float *red_dev, float *out_dev, int64_t n,
+                 double soil_factor, void *stream);
+
+/* ------------------------------------------------------------- k x k kernels
+ * convolve2d: correlation with a float64 weight matrix given on the HOST
+ * (krows x kcols, both odd, C order); NaN border of k//2 on true edges, NaNs
+ * propagate.  Replaces _convolve_2d_numpy, xrspatial/convolution.py:285-313.
+ * `work_dev` must hold xrs_kxk_workspace_bytes(krows, kcols) bytes (the weights
+ * are staged there on `stream`). */
+size_t xrs_kxk_workspace_bytes(int krows, int kcols);
+int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
+                       int64_t ld_in, int64_t ld_out, const double *kernel, int krows, int kcols,
+                       void *work_dev, int halo_top, int halo_bot, void *stream);
+
+/* focal statistics over the window cells where kernel == 1 exactly, window clipped
+ * to the raster (no NaN border), NaN cells skipped; all requested statistics in ONE
+ * pass.  Replaces _apply_numpy with the built-in reducers, xrspatial/focal.py:305-326
+ * and :268-302, i.e. focal.apply(func=_calc_*) and focal.focal_stats (:782-797).
+ * stat_mask bit i selects XRS_STAT_*; outs_dev[i] (HOST array of 7 device
+ * pointers) receives statistic i and may be NULL when its bit is clear. */
+enum { XRS_STAT_MEAN = 0, XRS_STAT_MAX = 1, XRS_STAT_MIN = 2, XRS_STAT_RANGE = 3,
+       XRS_STAT_STD = 4, XRS_STAT_VAR = 5, XRS_STAT_SUM = 6, XRS_NUM_STATS = 7 };
+int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned stat_mask,
+                        int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                        const double *kernel, int krows, int kcols, void *work_dev,
+                        int halo_top, int halo_bot, void *stream);
+
+/* focal.mean: fixed 3x3 NaN-skipping mean on a clamped window, float64 out, cells
+ * equal to one of `excludes` (NaN matches NaN) are passed through.  One pass;
+ * the host loops `passes`.  Replaces _mean_numpy, xrspatial/focal.py:44-67.
+ * in_is_f64 selects the input element type (first pass may read float32). */
+int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_t rows, int64_t cols,
+                      int64_t ld_in, int64_t ld_out, const double *excludes, int n_excludes,
+                      int halo_top, int halo_bot, void *stream);
+
+/* -------------------------------------------------------------------- zonal
+ * Per-zone partial reductions of one streaming pass over (zone index, value):
+ * count (integer-exact), sum and sum of squares (float64), min, max.  Cells with
+ * zone index < 0 or >= n_zones, non-finite values, and values == nodata (when
+ * has_nodata) are skipped.  The five output arrays (n_zones entries each) are
+ * ACCUMULATED into: initialise them with xrs_zonal_init().  These partials are
+ * the per-block statistics of the reference's dask path (_DASK_BLOCK_STATS,
+ * xrspatial/zonal.py:83-89) from which mean/std/var follow (:100-102); the
+ * NumPy path they replace is _stats_numpy (:280-332). */
+int xrs_zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
+                   float *min_dev, float *max_dev, int n_zones, void *stream);
+int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n,
+                           int n_zones, float nodata, int has_nodata,
+                           uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
+                           float *min_dev, float *max_dev, void *stream);
+/* float64 values (the reference does not cast `values`: float64 and integer rasters keep
+ * their precision; integers are widened to float64 by the host layer).  min/max are float64. */
+int xrs_zonal_init_f64(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
+                       double *min_dev, double *max_dev, int n_zones, void *stream);
+int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n,
+                           int n_zones, double nodata, int has_nodata,
+                           uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
+                           double *min_dev, double *max_dev, void *stream);
+
+/* ----------------------------------------------------- multi-GPU (RCCL, xGMI)
+ * One process per GPU.  Rank 0 creates a 128-byte id and ships it to the other
+ * ranks by any out-of-band means; every rank then calls xrs_comm_init_rank.
+ * halo exchange: the raster is sharded on the row axis; `shard_dev` points at
+ * the first OWNED row of this rank's shard, which must have `halo` spare rows
+ * above and below it.  One grouped ncclSend/ncclRecv pair per neighbour fills
+ * them (rank r-1 above, r+1 below); outer ranks' outer halos are left untouched.
+ * zonal reduce: element-wise all-reduce of the partial arrays (sum for
+ * count/sum/sumsq, min, max) so every rank holds the global partials; minmax_f64 says
+ * whether min_dev / max_dev hold float64 (the *_f64 partials) or float32. */
+int xrs_comm_unique_id(void *id128);
+int xrs_comm_init_rank(void **comm, const void *id128, int nranks, int rank);
+int xrs_comm_destroy(void *comm);
+int xrs_halo_exchange_f32(void *comm, float *shard_dev, int64_t rows, int64_t cols, int64_t ld,
+                          int halo, void *stream);
+int xrs_zonal_allreduce(void *comm, uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
+                        void *min_dev, void *max_dev, int minmax_f64, int n_zones, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRS_HIP_H */

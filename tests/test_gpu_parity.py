@@ -1,0 +1,357 @@
+"""Parity of the HIP path (through the C ABI, via the xrspatial_amd host layer) against the CPU
+oracle, on the reference's golden fixtures and on seeded synthetic rasters.  Needs an MI355X.
+
+Tolerances: float results within 1e-5 relative of the oracle (north_star), tightened where the
+arithmetic allows (bit-exact for per-cell indices, min/max/sum/range, counts)."""
+import numpy as np
+import pytest
+
+import xrspatial_amd as xs
+from oracle import c_oracle as corc
+from oracle import xrs_oracle as orc
+from tests import synth
+from xrspatial_amd.convolution import annulus_kernel, circle_kernel, convolve_2d, convolution_2d
+from xrspatial_amd.focal import apply, focal_stats, _calc_sum
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def raster(data, res=(0.5, 0.5), backend='numpy'):
+    data = np.asarray(data)
+    agg = xs.DataArray(data, dims=['y', 'x'], name='myraster', attrs={'res': res, 'crs': 'EPSG: 5070'})
+    agg['y'] = np.linspace((data.shape[0] - 1) * res[0], 0, data.shape[0])
+    agg['x'] = np.linspace(0, (data.shape[1] - 1) * res[1], data.shape[1])
+    if backend == 'hip':
+        agg.data = xs.DeviceArray.from_numpy(data)
+    return agg
+
+
+def host(a):
+    return a.get() if isinstance(a, xs.DeviceArray) else np.asarray(a)
+
+
+def check_meta(src, out):
+    assert out.shape == src.shape and out.dims == src.dims and out.attrs == src.attrs
+    for c in src.coords:
+        np.testing.assert_array_equal(host(out[c].data), host(src[c].data))
+
+
+SHAPES = [(2, 4), (3, 3), (10, 15), (37, 53), (64, 64), (128, 256), (130, 1024), (65, 516)]
+
+
+# ------------------------------------------------------------------ golden fixtures
+def test_slope_aspect_qgis(golden):
+    agg = raster(golden["dem_nan_row"], res=(1, 1))
+    s = xs.slope(agg, name='slope_numpy')
+    assert s.name == 'slope_numpy' and s.data.dtype == np.float32
+    check_meta(agg, s)
+    np.testing.assert_allclose(s.data[1:-1, 1:-1], golden["qgis_slope"][1:-1, 1:-1], rtol=1e-5, equal_nan=True)
+    a = xs.aspect(raster(golden["dem_nan_row"]))
+    np.testing.assert_allclose(a.data[1:-1, 1:-1], golden["qgis_aspect"][1:-1, 1:-1], rtol=1e-5, equal_nan=True)
+    for r in (s, a):
+        assert np.isnan(r.data[0]).all() and np.isnan(r.data[-1]).all()
+        assert np.isnan(r.data[:, 0]).all() and np.isnan(r.data[:, -1]).all()
+
+
+def test_curvature_goldens(golden):
+    for which in ("curv_convex", "curv_concave"):
+        out = xs.curvature(raster(golden[which + "__0"], res=(1, 1)))
+        np.testing.assert_allclose(out.data, golden[which + "__1"], rtol=1e-6, equal_nan=True)
+        assert out.data.dtype == np.float32
+
+
+def test_hillshade_docstring():
+    data = np.zeros((5, 5))
+    data[1, 1], data[1, 3], data[2, 2] = 1, 2, 3
+    exp = np.array([[0.71130913, 0.44167341, 0.71130913],
+                    [0.95550163, 0.71130913, 0.52478473],
+                    [0.71130913, 0.88382559, 0.71130913]])
+    out = xs.hillshade(raster(data))
+    assert out.data.dtype == orc.hillshade(data).dtype
+    np.testing.assert_allclose(out.data[1:-1, 1:-1], exp, rtol=1e-5)
+    assert np.isnan(out.data[0]).all() and np.isnan(out.data[:, -1]).all()
+
+
+def test_compass_rose():
+    data = np.zeros((5, 8))
+    data[2, 2], data[2, 5] = 1, -1
+    agg = raster(data, res=(1, 1))
+    np.testing.assert_allclose(xs.aspect(agg).data[1:4, 1:7],
+                               [[315, 0, 45, 135, 180, 225], [270, -1, 90, 90, -1, 270], [225, 180, 135, 45, 0, 315]])
+    np.testing.assert_allclose(xs.slope(agg).data[1:4, 1:4], orc.slope(data, 1, 1)[1:4, 1:4], rtol=1e-6)
+    np.testing.assert_allclose(xs.curvature(agg).data[1:4, 1:7], orc.curvature(data, 1)[1:4, 1:7])
+
+
+def test_convolve_goldens(golden):
+    d = golden["conv_data"]
+    for k, exp in ((golden["conv_custom__0"], golden["conv_custom__1"]),
+                   (golden["kernel_circle_1_1_1"], golden["conv_expected_circle"]),
+                   (golden["kernel_annulus_2_2_2_1"], golden["conv_expected_annulus"])):
+        out = convolve_2d(d, k)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float32
+        np.testing.assert_allclose(out, exp, equal_nan=True)
+    np.testing.assert_array_equal(circle_kernel(1, 1, 1), golden["kernel_circle_1_1_1"])
+    np.testing.assert_array_equal(annulus_kernel(2, 2, 2, 1), golden["kernel_annulus_2_2_2_1"])
+
+
+def test_focal_stats_golden(golden):
+    agg = raster(golden["focal_stats__0"])
+    out = focal_stats(agg, golden["focal_stats__1"])
+    assert out.ndim == 3 and out.dims[0] == 'stats'
+    np.testing.assert_allclose(out.data, golden["focal_stats__2"], rtol=1e-6, equal_nan=True)
+
+
+def test_focal_mean_docstring():
+    data = np.zeros((5, 5))
+    data[2, 2] = 9
+    np.testing.assert_allclose(xs.focal.mean(raster(data), passes=2).data, orc.focal_mean3x3(data, passes=2),
+                               rtol=1e-12)
+    assert xs.focal.mean(raster(data)).data.dtype == np.float64
+
+
+def test_multispectral_goldens(golden):
+    nir, red, blue = (raster(golden[k]) for k in ("ms_nir", "ms_red", "ms_blue"))
+    out = xs.ndvi(nir, red)
+    assert out.data.dtype == np.float32 and out.name == 'ndvi'
+    check_meta(nir, out)
+    np.testing.assert_allclose(out.data, golden["qgis_ndvi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(xs.savi(nir, red, soil_factor=0.0).data, golden["qgis_ndvi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(xs.savi(nir, red).data, golden["qgis_savi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(xs.evi(nir, red, blue).data, golden["qgis_evi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(xs.nbr(nir, raster(golden["ms_swir2"])).data, golden["qgis_nbr"], rtol=1e-6, equal_nan=True)
+    for dtype in ("uint8", "uint16"):
+        b1, b2, exp = (golden["uint_nratio__%d" % i] for i in range(3))
+        np.testing.assert_allclose(xs.ndvi(xs.DataArray(b1.astype(dtype)), xs.DataArray(b2.astype(dtype))).data, exp, rtol=1e-6)
+        n, r, b, exp = (golden["uint_evi__%d" % i] for i in range(4))
+        np.testing.assert_allclose(xs.evi(*(xs.DataArray(v.astype(dtype)) for v in (n, r, b))).data, exp, rtol=1e-6)
+    with pytest.raises(ValueError):
+        xs.savi(nir, red, soil_factor=2.0)
+    with pytest.raises(ValueError):
+        xs.evi(nir, red, blue, gain=-1)
+
+
+def test_zonal_goldens(golden, golden_tables):
+    zones, values = raster(golden["zonal_zones"]), raster(golden["zonal_values"])
+    z0, v0 = zones.data.copy(), values.data.copy()
+    df = xs.zonal_stats(zones, values)
+    exp = golden_tables["zonal_default"]
+    assert list(df.columns) == ['zone', 'mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    assert (df['zone'] == exp['zone']).all()
+    for col in df.columns[1:]:
+        np.testing.assert_allclose(df[col], exp[col], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(zones.data, z0)
+    np.testing.assert_array_equal(values.data, v0)
+    ids = golden_tables["zonal_zone_ids__0"]
+    df = xs.zonal_stats(zones, values, zone_ids=ids, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
+    exp = golden_tables["zonal_zone_ids__1"]
+    assert (df['zone'] == exp['zone']).all()
+    for col in df.columns[1:]:
+        np.testing.assert_allclose(df[col], exp[col], rtol=1e-5, atol=1e-7)
+    # QGIS zonal statistics on the 8x6 DEM (test_zonal.py:340-385)
+    exp = golden_tables["zonal_qgis"]
+    df = xs.zonal_stats(raster(golden["zones_8x6"]), raster(golden["dem"]), stats_funcs=['mean', 'max', 'min', 'sum', 'count'])
+    assert df['count'].tolist() == exp['count']
+    for col in ('mean', 'max', 'min', 'sum'):
+        np.testing.assert_allclose(df[col], exp[col], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ seeded synthetic rasters
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("backend", ["numpy", "hip"])
+def test_terrain_vs_oracle(shape, backend):
+    z = synth.smooth_dem(shape, nan_frac=0.01 if shape[0] > 8 else 0.0)
+    agg = raster(z, res=(30.0, 30.0), backend=backend)
+    for got, want in ((xs.slope(agg), orc.slope(z, 30.0, 30.0)),
+                      (xs.aspect(agg), orc.aspect(z)),
+                      (xs.curvature(agg), orc.curvature(z, 30.0)),
+                      (xs.hillshade(agg), orc.hillshade(z)),
+                      (xs.hillshade(agg, azimuth=100, angle_altitude=60), orc.hillshade(z, 100, 60))):
+        assert isinstance(got.data, xs.DeviceArray if backend == 'hip' else np.ndarray)
+        np.testing.assert_allclose(host(got.data), want, rtol=RTOL, atol=1e-6, equal_nan=True)
+        check_meta(agg, got)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.uint32, np.float32, np.float64])
+def test_terrain_random_ints(dtype):
+    # the reference's `random_data` fixture (tests/conftest.py:6-10)
+    data = np.random.default_rng(2841).integers(-100, 100, size=(10, 15)).astype(dtype)
+    agg = raster(data)
+    np.testing.assert_allclose(xs.slope(agg).data, orc.slope(data, 0.5, 0.5), rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(xs.aspect(agg).data, orc.aspect(data), rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(xs.curvature(agg).data, orc.curvature(data, 0.5), rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(xs.hillshade(agg).data, orc.hillshade(data), rtol=RTOL, equal_nan=True)
+
+
+def test_flat_and_tiny():
+    for shape in [(2, 4), (1, 1), (1, 7), (3, 3)]:
+        out = xs.curvature(raster(np.zeros(shape), res=(1, 1))).data
+        np.testing.assert_array_equal(out, orc.curvature(np.zeros(shape), 1))
+        assert np.isnan(xs.slope(raster(np.zeros(shape))).data[0]).all()
+    flat = xs.aspect(raster(np.ones((5, 6)))).data
+    assert (flat[1:-1, 1:-1] == -1).all()
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (64, 256), (100, 1028)])
+def test_percell_bit_exact(shape):
+    a, b, c = (synth.bands(shape, s) for s in (400, 100, 300))
+    a[0, 0] = b[0, 0] = 0.0
+    a[1, 1] = np.nan
+    A, B, C = (raster(v) for v in (a, b, c))
+    np.testing.assert_array_equal(xs.ndvi(A, B).data, orc.normalized_ratio(a, b))
+    np.testing.assert_array_equal(xs.evi(A, B, C).data, orc.evi(a, b, c))
+    np.testing.assert_array_equal(xs.evi(A, B, C, c1=5.0, c2=7.0, soil_factor=0.5, gain=2.0).data,
+                                  orc.evi(a, b, c, 5.0, 7.0, 0.5, 2.0))
+    np.testing.assert_array_equal(xs.savi(A, B, soil_factor=0.5).data, orc.savi(a, b, 0.5))
+    dev = xs.ndvi(raster(a, backend='hip'), raster(b, backend='hip'))
+    np.testing.assert_array_equal(dev.data.get(), orc.normalized_ratio(a, b))
+
+
+KERNELS = {
+    'circle5': circle_kernel(1, 1, 2),
+    'annulus7': annulus_kernel(1, 1, 3, 1),
+    'custom3': np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=float),
+    'row3': np.array([[1, 1, 1]], dtype=float),
+    'circle9': circle_kernel(1, 1, 4),
+    'circle25': circle_kernel(1, 1, 12),
+    'weights5x3': np.arange(15, dtype=float).reshape(5, 3) / 7.0,
+}
+
+
+@pytest.mark.parametrize("kname", list(KERNELS))
+@pytest.mark.parametrize("shape", [(41, 35), (64, 512), (70, 260)])
+def test_kxk_vs_oracle(kname, shape):
+    k = KERNELS[kname]
+    z = synth.smooth_dem(shape, nan_frac=0.02)
+    agg = raster(z)
+    np.testing.assert_allclose(convolution_2d(agg, k).data, corc.convolve_2d(z, k), rtol=1e-6, equal_nan=True)
+    got = focal_stats(agg, k)
+    assert list(host(got['stats'].data)) == list(orc.FOCAL_STATS)
+    for i, stat in enumerate(orc.FOCAL_STATS):
+        want = corc.focal_apply(z, k, stat)
+        if stat in ('max', 'min', 'range', 'sum'):
+            np.testing.assert_array_equal(got.data[i], want, err_msg=stat)
+        else:
+            np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=stat)
+    np.testing.assert_allclose(apply(agg, k).data, corc.focal_apply(z, k, 'mean'), rtol=1e-6, equal_nan=True)
+    np.testing.assert_array_equal(apply(agg, k, _calc_sum).data, corc.focal_apply(z, k, 'sum'))
+
+
+def test_focal_all_nan_window_and_device_backend():
+    z = synth.smooth_dem((40, 256))
+    z[10:20, 30:60] = np.nan
+    k = circle_kernel(1, 1, 2)
+    dev = focal_stats(raster(z, backend='hip'), k)
+    assert isinstance(dev.data, xs.DeviceArray) and dev.shape == (7, 40, 256)
+    np.testing.assert_allclose(dev.data.get(), orc.focal_stats(z, k), rtol=1e-6, atol=1e-9, equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        apply(raster(z), k, func=lambda w: 0)
+    with pytest.raises(ValueError):
+        apply(raster(z), np.ones((4, 6)))
+    with pytest.raises(TypeError):
+        apply(z, k)
+
+
+@pytest.mark.parametrize("shape", [(33, 29), (64, 256)])
+def test_focal_mean3x3(shape):
+    z = synth.smooth_dem(shape, nan_frac=0.05)
+    agg = raster(z)
+    np.testing.assert_allclose(xs.focal.mean(agg).data, orc.focal_mean3x3(z), rtol=1e-12, equal_nan=True)
+    ex = [np.nan, float(z[3, 3])]
+    np.testing.assert_allclose(xs.focal.mean(agg, passes=3, excludes=ex).data,
+                               orc.focal_mean3x3(z, excludes=ex, passes=3), rtol=1e-12, equal_nan=True)
+    z64 = z.astype(np.float64) + 1e-9
+    np.testing.assert_allclose(xs.focal.mean(raster(z64)).data, orc.focal_mean3x3(z64), rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("scatter", [False, True])
+@pytest.mark.parametrize("vdtype", [np.float32, np.float64, np.int32])
+def test_zonal_vs_oracle(scatter, vdtype):
+    rows, cols = 300, 517
+    rng = np.random.default_rng(5)
+    if scatter:
+        zones = rng.integers(0, 57, size=(rows, cols)).astype(np.float64)
+        zones[rng.random((rows, cols)) < 0.01] = np.nan
+    else:
+        zones = synth.block_zones(rows, cols, n_zones=40, block=37)
+    vals = synth.asv_dem(rows, cols)
+    vals[rng.random((rows, cols)) < 0.01] = np.nan
+    if vdtype == np.int32:
+        vals = np.nan_to_num(vals).astype(np.int32)
+    else:
+        vals = vals.astype(vdtype)
+    names = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    df = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=names, nodata_values=0 if vdtype == np.int32 else None)
+    want = orc.zonal_stats(zones, vals, stats_funcs=names, nodata_values=0 if vdtype == np.int32 else None)
+    np.testing.assert_array_equal(df['zone'].to_numpy(), want['zone'])
+    np.testing.assert_array_equal(df['count'].to_numpy(), want['count'])          # integer-exact
+    np.testing.assert_array_equal(df['max'].to_numpy(), want['max'])
+    np.testing.assert_array_equal(df['min'].to_numpy(), want['min'])
+    for col in ('mean', 'sum', 'std', 'var'):
+        np.testing.assert_allclose(df[col].to_numpy(), want[col], rtol=RTOL, err_msg=col)
+
+
+def test_zonal_run_to_run_counts_and_many_zones():
+    rows, cols = 512, 512
+    zones = np.random.default_rng(1).integers(0, 5000, size=(rows, cols)).astype(np.int32)   # > LDS-privatised limit
+    vals = synth.asv_dem(rows, cols)
+    a = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=['count', 'sum', 'max'])
+    b = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=['count', 'sum', 'max'])
+    want = orc.zonal_stats(zones, vals, stats_funcs=['count', 'sum', 'max'])
+    np.testing.assert_array_equal(a['count'], b['count'])
+    np.testing.assert_array_equal(a['count'].to_numpy(), want['count'])
+    np.testing.assert_array_equal(a['max'].to_numpy(), want['max'])
+    np.testing.assert_allclose(a['sum'].to_numpy(), want['sum'], rtol=RTOL)
+
+
+def test_dataset_adapters():
+    z = synth.smooth_dem((16, 32))
+    ds = xs.Dataset({'a': raster(z), 'b': raster(z * 2)}, attrs={'k': 1})
+    out = xs.slope(ds)
+    assert isinstance(out, xs.Dataset) and set(out.data_vars) == {'a', 'b'} and out.attrs == {'k': 1}
+    np.testing.assert_array_equal(out['b'].data, xs.slope(raster(z * 2)).data)
+    assert out['a'].name == 'a'
+    bands = xs.Dataset({'B8': raster(z), 'B4': raster(z + 1)})
+    np.testing.assert_array_equal(xs.ndvi(bands, nir='B8', red='B4').data, xs.ndvi(raster(z), raster(z + 1)).data)
+    with pytest.raises(TypeError):
+        xs.ndvi(bands, nir='B8')
+    with pytest.raises(ValueError):
+        xs.ndvi(bands, nir='B8', red='nope')
+
+
+def test_row_shard_halo_contract():
+    """A shard computed with halo rows equals the same rows of the monolithic result
+    (dask map_overlap(depth, boundary=nan) semantics restricted to the row axis)."""
+    import ctypes
+    from xrspatial_amd import _lib
+    z = synth.smooth_dem((96, 256), nan_frac=0.01)
+    full = xs.DeviceArray.from_numpy(z)
+    k = circle_kernel(1, 1, 2)
+    kd = np.ascontiguousarray(k, dtype=np.float64)
+    want_slope = orc.slope(z, 30.0, 30.0)
+    want_focal = orc.focal_apply(z, k, 'mean')
+    for (y0, y1) in [(0, 32), (32, 64), (64, 96)]:
+        ht, hb = min(2, y0), min(2, 96 - y1)
+        shard = full.rows(y0, y1)
+        out = xs.DeviceArray((y1 - y0, 256), np.float32)
+        _lib.call("xrs_slope_f32", shard.ptr, out.ptr, y1 - y0, 256, 256, 256, 30.0, 30.0, min(ht, 1), min(hb, 1), None)
+        np.testing.assert_allclose(out.get(), want_slope[y0:y1], rtol=RTOL, equal_nan=True)
+        ptrs = (ctypes.c_void_p * 7)()
+        ptrs[0] = out.ptr
+        _lib.call("xrs_focal_stats_f32", shard.ptr, ptrs, 1, y1 - y0, 256, 256, 256, kd.ctypes.data, 5, 5, None, ht, hb, None)
+        np.testing.assert_allclose(out.get(), want_focal[y0:y1], rtol=1e-6, equal_nan=True)
+
+
+def test_fused_terrain_equals_separate():
+    from xrspatial_amd import _lib
+    z = synth.smooth_dem((64, 512), nan_frac=0.01)
+    src = xs.DeviceArray.from_numpy(z)
+    outs = [xs.DeviceArray(z.shape, np.float32) for _ in range(4)]
+    _lib.call("xrs_terrain_fused_f32", src.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr, outs[3].ptr,
+              64, 512, 512, 512, 30.0, 30.0, 225.0, 25.0, 0, 0, None)
+    agg = raster(z, res=(30.0, 30.0))
+    np.testing.assert_array_equal(outs[0].get(), xs.slope(agg).data)
+    np.testing.assert_array_equal(outs[1].get(), xs.aspect(agg).data)
+    np.testing.assert_array_equal(outs[2].get(), xs.curvature(agg).data)
+    np.testing.assert_array_equal(outs[3].get().astype(np.float64), xs.hillshade(agg).data)

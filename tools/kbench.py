@@ -1,0 +1,141 @@
+"""Per-kernel micro-benchmark on one MI355X: HIP-event timing of every hot-path kernel on a
+device-resident raster, printed as ms / Mcells/s / algorithmic GB/s (SURVEY.md §8d byte counts).
+
+    python tools/kbench.py [--size 16384] [--reps 20] [--only hillshade,focal5_mean]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import xrspatial_amd as xs  # noqa: E402
+from tests import synth  # noqa: E402
+from xrspatial_amd import _lib  # noqa: E402
+from xrspatial_amd.convolution import circle_kernel  # noqa: E402
+
+
+def device_raster(rows, cols, maker, band=2048):
+    out = xs.DeviceArray((rows, cols), np.float32)
+    for y0 in range(0, rows, band):
+        n = min(band, rows - y0)
+        host = maker(n, cols, y0)
+        _lib.call("xrs_memcpy_h2d", out.ptr + y0 * cols * 4, host.ctypes.data, host.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
+    return out
+
+
+class Timer:
+    def __init__(self):
+        self.e0, self.e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("xrs_event_create", ctypes.byref(self.e0))
+        _lib.call("xrs_event_create", ctypes.byref(self.e1))
+
+    def time(self, fn, reps, warmup=3, stream=None):
+        for _ in range(warmup):
+            fn()
+        _lib.call("xrs_stream_sync", stream)
+        times = []
+        for _ in range(reps):
+            _lib.call("xrs_event_record", self.e0, stream)
+            fn()
+            _lib.call("xrs_event_record", self.e1, stream)
+            _lib.call("xrs_event_sync", self.e1)
+            ms = ctypes.c_float()
+            _lib.call("xrs_event_elapsed_ms", self.e0, self.e1, ctypes.byref(ms))
+            times.append(ms.value)
+        return float(np.median(times)), float(np.min(times))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    _lib.require_device()
+    n = args.size
+    cells = n * n
+    name = ctypes.create_string_buffer(256)
+    _lib.call("xrs_device_name", 0, name, 256)
+    print("device:", name.value.decode(), " raster:", n, "x", n, flush=True)
+
+    t0 = time.time()
+    dem = device_raster(n, n, lambda r, c, y0: synth.asv_dem(r, c, y0=y0, total_rows=n))
+    b2 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 100 + y0))
+    b3 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 300 + y0))
+    zones = xs.DeviceArray((n, n), np.int32)
+    for y0 in range(0, n, 2048):
+        z = synth.block_zones(min(2048, n - y0), n, y0=y0)
+        _lib.call("xrs_memcpy_h2d", zones.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
+    print("inputs staged in %.1f s" % (time.time() - t0), flush=True)
+
+    outs = [xs.DeviceArray((n, n), np.float32) for _ in range(7)]
+    out64 = xs.DeviceArray((n, n), np.float64)
+    k5 = np.ascontiguousarray(circle_kernel(1, 1, 2))
+    k3 = np.ones((3, 3))
+    k25 = np.ascontiguousarray(circle_kernel(1, 1, 12))
+    w5 = np.ascontiguousarray(k5 / k5.sum())
+    work = xs.DeviceArray((1 << 16,), np.uint8)
+    ptr1 = (ctypes.c_void_p * 7)()
+    ptr1[0] = outs[0].ptr
+    ptr7 = (ctypes.c_void_p * 7)(*[o.ptr for o in outs])
+    nz = 1000
+    zc = xs.DeviceArray((nz,), np.uint64)
+    zs, zq = xs.DeviceArray((nz,), np.float64), xs.DeviceArray((nz,), np.float64)
+    zmn, zmx = xs.DeviceArray((nz,), np.float32), xs.DeviceArray((nz,), np.float32)
+    ex = np.array([np.nan])
+    L = _lib.call
+    S = None
+
+    def zonal():
+        L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
+        L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
+
+    # name -> (callable, algorithmic bytes per cell)
+    cases = {
+        "copy_d2d": (lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, S), 8),
+        "hillshade": (lambda: L("xrs_hillshade_f32", dem.ptr, outs[0].ptr, 0, n, n, n, n, 225.0, 25.0, 0, 0, S), 8),
+        "hillshade_f64out": (lambda: L("xrs_hillshade_f32", dem.ptr, out64.ptr, 1, n, n, n, n, 225.0, 25.0, 0, 0, S), 12),
+        "slope": (lambda: L("xrs_slope_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 1.0, 0, 0, S), 8),
+        "aspect": (lambda: L("xrs_aspect_f32", dem.ptr, outs[0].ptr, n, n, n, n, 0, 0, S), 8),
+        "curvature": (lambda: L("xrs_curvature_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 0, 0, S), 8),
+        "terrain_fused4": (lambda: L("xrs_terrain_fused_f32", dem.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr,
+                                     outs[3].ptr, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 20),
+        "ndvi": (lambda: L("xrs_normalized_ratio_f32", dem.ptr, b2.ptr, outs[0].ptr, cells, S), 12),
+        "evi": (lambda: L("xrs_evi_f32", dem.ptr, b2.ptr, b3.ptr, outs[0].ptr, cells, 6.0, 7.5, 1.0, 2.5, S), 16),
+        "savi": (lambda: L("xrs_savi_f32", dem.ptr, b2.ptr, outs[0].ptr, cells, 1.0, S), 12),
+        "focal5_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 8),
+        "focal3_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 8),
+        "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
+        "focal25_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),
+        "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
+        "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
+        "zonal_1000": (zonal, 8),
+    }
+    only = [s for s in args.only.split(",") if s]
+    timer = Timer()
+    results = {}
+    print(f"{'kernel':20s} {'ms(med)':>9s} {'ms(min)':>9s} {'Mcells/s':>11s} {'GB/s(alg)':>10s}")
+    for name_, (fn, bpc) in cases.items():
+        if only and name_ not in only:
+            continue
+        reps = 3 if name_ == "focal25_mean" else args.reps
+        med, mn = timer.time(fn, reps, warmup=2)
+        gbs = cells * bpc / (med * 1e-3) / 1e9
+        results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs}
+        print(f"{name_:20s} {med:9.3f} {mn:9.3f} {cells / (med * 1e-3) / 1e6:11.0f} {gbs:10.0f}", flush=True)
+    if args.json:
+        with open(args.json, "w") as fh:
+            json.dump({"size": n, "results": results}, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

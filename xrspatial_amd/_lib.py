@@ -1,0 +1,153 @@
+"""ctypes binding of libxrs_hip.so (C ABI declared in include/xrs_hip.h).
+
+There is deliberately NO CPU fallback: if the HIP library cannot be loaded, or no
+MI355X is visible, every compute entry point raises.  (The CPU oracle under
+`oracle/` is test infrastructure and is never imported from this package.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxrs_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_double = ctypes.c_double
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+c_uint = ctypes.c_uint
+
+
+class XrsError(RuntimeError):
+    """A libxrs_hip.so entry point returned non-zero."""
+
+
+# name -> argtypes (every function returns int unless listed in _RESTYPES)
+_PROTOTYPES = {
+    "xrs_version": [],
+    "xrs_last_error": [ctypes.c_char_p, c_size_t],
+    "xrs_device_count": [ctypes.POINTER(c_int)],
+    "xrs_set_device": [c_int],
+    "xrs_get_device": [ctypes.POINTER(c_int)],
+    "xrs_device_name": [c_int, ctypes.c_char_p, c_size_t],
+    "xrs_mem_info": [ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
+    "xrs_malloc": [ctypes.POINTER(c_void_p), c_size_t],
+    "xrs_free": [c_void_p],
+    "xrs_memcpy_h2d": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "xrs_memcpy_d2h": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "xrs_memcpy_d2d": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "xrs_memset": [c_void_p, c_int, c_size_t, c_void_p],
+    "xrs_stream_create": [ctypes.POINTER(c_void_p)],
+    "xrs_stream_destroy": [c_void_p],
+    "xrs_stream_sync": [c_void_p],
+    "xrs_device_sync": [],
+    "xrs_event_create": [ctypes.POINTER(c_void_p)],
+    "xrs_event_destroy": [c_void_p],
+    "xrs_event_record": [c_void_p, c_void_p],
+    "xrs_event_sync": [c_void_p],
+    "xrs_event_elapsed_ms": [c_void_p, c_void_p, ctypes.POINTER(c_float)],
+    "xrs_slope_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_double,
+                      c_int, c_int, c_void_p],
+    "xrs_aspect_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p],
+    "xrs_curvature_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_double,
+                          c_int, c_int, c_void_p],
+    "xrs_hillshade_f32": [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_double, c_double,
+                          c_int, c_int, c_void_p],
+    "xrs_terrain_fused_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                              c_int64, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p],
+    "xrs_normalized_ratio_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "xrs_evi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double,
+                    c_void_p],
+    "xrs_savi_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_double, c_void_p],
+    "xrs_kxk_workspace_bytes": [c_int, c_int],
+    "xrs_convolve2d_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
+                           c_void_p, c_int, c_int, c_void_p],
+    "xrs_focal_stats_f32": [c_void_p, ctypes.POINTER(c_void_p), c_uint, c_int64, c_int64, c_int64, c_int64,
+                            c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "xrs_focal_mean3x3": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
+                          c_int, c_int, c_void_p],
+    "xrs_zonal_init": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "xrs_zonal_partials_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrs_zonal_init_f64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrs_comm_unique_id": [c_void_p],
+    "xrs_comm_init_rank": [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int],
+    "xrs_comm_destroy": [c_void_p],
+    "xrs_halo_exchange_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "xrs_zonal_allreduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+}
+_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t}
+
+EXPORTED = tuple(_PROTOTYPES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libxrs_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise XrsError(
+                    f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                    "(or `make -C xrspatial_amd/csrc`).  There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, argtypes in _PROTOTYPES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = _RESTYPES.get(name, c_int)
+            _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(512)
+    load().xrs_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise XrsError(f"{what}: {last_error()}" if what else last_error())
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise XrsError on failure."""
+    check(getattr(load(), name)(*args), name)
+
+
+_device_ready = False
+
+
+def require_device():
+    """Fail loudly unless a HIP device is usable (selects LOCAL_RANK's GPU once)."""
+    global _device_ready
+    if _device_ready:
+        return
+    lib = load()
+    n = c_int(0)
+    rc = lib.xrs_device_count(ctypes.byref(n))
+    if rc != 0 or n.value < 1:
+        raise XrsError("no MI355X / HIP device visible (%s); xrspatial_amd has no CPU fallback"
+                       % (last_error() or "device count is 0"))
+    dev = int(os.environ.get("XRS_DEVICE", os.environ.get("LOCAL_RANK", "0"))) % n.value
+    check(lib.xrs_set_device(dev), "xrs_set_device")
+    _device_ready = True
+
+
+def device_available() -> bool:
+    try:
+        require_device()
+        return True
+    except (XrsError, OSError):
+        return False

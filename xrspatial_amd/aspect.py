@@ -1,0 +1,35 @@
+"""xrspatial.aspect drop-in (planar method).  Reference: xrspatial/aspect.py:274-388."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from ._launch import stencil
+from ._xr import DataArray
+from .dataset_support import supports_dataset
+from .utils import ArrayTypeFunctionMapping
+
+
+def _run(data):
+    # replaces _run_numpy (aspect.py:56-90): compass degrees, -1 on flat cells, NaN border
+    return stencil("xrs_aspect_f32", data, np.float32, ())
+
+
+@supports_dataset
+def aspect(agg: DataArray,
+           name: Optional[str] = 'aspect',
+           method: str = 'planar',
+           z_unit: str = 'meter') -> DataArray:
+    """Downslope direction of every cell, compass degrees (0 = north, clockwise), -1 if flat.
+
+    Same signature and results as `xrspatial.aspect` (planar method; the cell size
+    does not enter); runs on the MI355X.
+    """
+    if method not in ('planar', 'geodesic'):
+        raise ValueError(f"method must be 'planar' or 'geodesic', got {method!r}")
+    if method == 'geodesic':
+        raise NotImplementedError("geodesic aspect is not implemented by the MI355X backend yet")
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
+    out = mapper(agg)(agg.data)
+    return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

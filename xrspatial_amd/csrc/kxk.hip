@@ -1,0 +1,459 @@
+// k x k window kernels: convolve_2d, focal statistics (focal.apply / focal_stats), focal.mean 3x3.
+//
+// Reference runners replaced:
+//   _convolve_2d_numpy  xrspatial/convolution.py:285-313
+//   _apply_numpy + _calc_{mean,max,min,range,std,var,sum}  xrspatial/focal.py:305-326, 268-302
+//   _mean_numpy         xrspatial/focal.py:44-67
+//
+// Kernel shape: a 256-thread workgroup produces a TH x 256 output tile.  The input
+// region (TH + k-1 rows, 256 + 2*roundup4(k//2) columns) is fetched ONCE from HBM with
+// row-coalesced 16-byte loads into an LDS tile; cells outside the raster (or outside
+// the shard's halo) are written to LDS as NaN, which gives both edge rules for free:
+// convolve_2d propagates NaN (= the reference's NaN border), focal statistics skip NaN
+// (= the reference's window clipped to the raster).  Each lane then owns 4 adjacent
+// output columns and walks the window with a sliding 4-register view of every LDS row,
+// so one ds_read feeds four taps.  Accumulators follow the reference's CPU arithmetic:
+// float64 for mean / var / std / convolution (Numba nanmean / nanvar; `num = 0.0`),
+// float32 row-major for `sum` (Numba nansum keeps the array dtype).
+// No MFMA: 0/1 masks with NaN-skipping are not a dense contraction.
+#include "xrs_common.h"
+
+#include <cmath>
+
+using namespace xrs;
+
+namespace {
+
+constexpr int TW = 256;          // output tile width = 64 lanes x 4 columns
+constexpr int MAX_K = 61;        // one uint64 bit-row per kernel row (plus a <= 3 bit alignment shift)
+
+struct KxkArgs {
+    const float *in;
+    float *out[XRS_NUM_STATS];    // convolve uses out[0]
+    long rows, cols, ld_in, ld_out;
+    int halo_top, halo_bot;
+    int krows, kcols;             // runtime sizes (also valid for the compile-time variants)
+    int th;                       // output rows per tile (multiple of 4)
+    int lpad, lw;                 // LDS: columns left of the tile, LDS row pitch (floats)
+    const double *weights;        // device: krows*kcols float64 weights (convolve)
+    long tiles_x, n_tiles;
+    unsigned long long mask_rows[MAX_K];   // bit kx of entry ky: tap (ky, kx) has kernel == 1 (focal)
+};
+
+// Cooperative tile load.  VEC: raster is 16-byte friendly (cols, ld, base), else scalar.
+template <bool VEC>
+__device__ __forceinline__ void load_tile(const KxkArgs &a, float *tile, long X0, long Y0, int ry) {
+    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+    const int trows = a.th + a.krows - 1;
+    const float qnan = nan_f32();
+    if (VEC) {
+        const int lw4 = a.lw >> 2;
+        const int total = trows * lw4;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int r = i / lw4, c4 = i - r * lw4;
+            const long y = Y0 - ry + r;
+            const long x = X0 - a.lpad + (long)c4 * 4;
+            float4 v = make_float4(qnan, qnan, qnan, qnan);
+            if (y >= y_lo && y < y_hi && x >= 0 && x < a.cols)
+                v = *reinterpret_cast<const float4 *>(a.in + y * a.ld_in + x);
+            *reinterpret_cast<float4 *>(tile + r * a.lw + c4 * 4) = v;
+        }
+    } else {
+        const int total = trows * a.lw;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int r = i / a.lw, c = i - r * a.lw;
+            const long y = Y0 - ry + r;
+            const long x = X0 - a.lpad + c;
+            float v = qnan;
+            if (y >= y_lo && y < y_hi && x >= 0 && x < a.cols) v = a.in[y * a.ld_in + x];
+            tile[i] = v;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_row(float *out, long ld, long y, long x0, long cols, const float (&v)[4]) {
+    if (!out) return;
+    float *p = out + y * ld + x0;
+    if (VEC) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (x0 + o < cols) p[o] = v[o];
+    }
+}
+
+// Visit every tap of the kernel for the 4 adjacent outputs a lane owns:
+//   f(ky, kx, v0, v1, v2, v3)  with v_o = input cell under tap (ky, kx) of output column o.
+// LDS rows are read as aligned 16-byte slots (ds_read_b128, conflict-free for
+// consecutive lanes); a lane's slots start at its own float4, lpad-rx cells left of tap 0.
+// KH/KW > 0: compile-time shape, fully unrolled, register-indexed.  0: runtime shape,
+// 8-register sliding view advanced one slot per 4 taps.
+template <int KH, int KW, typename F>
+__device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile, int orow, int lane, F &&f) {
+    if constexpr (KH > 0) {
+        constexpr int RX = KW / 2, LP = (RX + 3) & ~3, NW = 4 + 2 * LP, SH = LP - RX;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.lw) + lane;
+            float w[NW];
+#pragma unroll
+            for (int i = 0; i < NW / 4; ++i) {
+                const float4 q = r4[i];
+                w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+            }
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) f(ky, kx, w[SH + kx], w[SH + kx + 1], w[SH + kx + 2], w[SH + kx + 3]);
+        }
+    } else {
+        const int kh = a.krows, kw = a.kcols;
+        const int sh = a.lpad - kw / 2;
+        const int nchunks = (sh + kw + 3) >> 2;
+        for (int ky = 0; ky < kh; ++ky) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.lw) + lane;
+            float4 cur = r4[0];
+            for (int jc = 0; jc < nchunks; ++jc) {
+                const float4 nx = r4[jc + 1];
+                const float w[8] = {cur.x, cur.y, cur.z, cur.w, nx.x, nx.y, nx.z, nx.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int kx = jc * 4 + jj - sh;
+                    if (kx >= 0 && kx < kw) f(ky, kx, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
+                }
+                cur = nx;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ focal statistics
+template <int KH, int KW, bool MEAN_ONLY, bool VEC>
+__global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const long X0 = tx * TW, Y0 = ty * a.th;
+    load_tile<VEC>(a, tile, X0, Y0, a.krows / 2);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const long x0 = X0 + lane * 4;
+    if (x0 >= a.cols) return;
+    const int rpw = a.th >> 2;                       // output rows per wave
+
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int orow = wy * rpw + rr;
+        const long y = Y0 + orow;
+        if (y >= a.rows) break;
+
+        double sum64[4] = {0, 0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0};
+        float sum32[4] = {0, 0, 0, 0};
+        float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+        // pass 1, row-major over the window = the order the reference's reducers visit the scratch
+        walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
+            if (!(a.mask_rows[ky] >> kx & 1ull)) return;      // wave-uniform
+            const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const bool ok = !isnan(v[o]);
+                sum64[o] += ok ? (double)v[o] : 0.0;
+                cnt[o] += ok ? 1 : 0;
+                if (!MEAN_ONLY) {
+                    sum32[o] = ok ? sum32[o] + v[o] : sum32[o];
+                    mn[o] = fminf(mn[o], v[o]);
+                    mx[o] = fmaxf(mx[o], v[o]);
+                }
+            }
+        });
+
+        double mean[4];
+        float o_tmp[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            mean[o] = sum64[o] / (double)cnt[o];       // 0/0 -> NaN like np.divide
+            o_tmp[o] = (float)mean[o];
+        }
+        store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
+        if (MEAN_ONLY) continue;
+
+        if (a.out[XRS_STAT_MAX]) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o_tmp[o] = cnt[o] ? mx[o] : nan_f32();
+            store_row<VEC>(a.out[XRS_STAT_MAX], a.ld_out, y, x0, a.cols, o_tmp);
+        }
+        if (a.out[XRS_STAT_MIN]) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o_tmp[o] = cnt[o] ? mn[o] : nan_f32();
+            store_row<VEC>(a.out[XRS_STAT_MIN], a.ld_out, y, x0, a.cols, o_tmp);
+        }
+        if (a.out[XRS_STAT_RANGE]) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o_tmp[o] = cnt[o] ? mx[o] - mn[o] : nan_f32();
+            store_row<VEC>(a.out[XRS_STAT_RANGE], a.ld_out, y, x0, a.cols, o_tmp);
+        }
+        store_row<VEC>(a.out[XRS_STAT_SUM], a.ld_out, y, x0, a.cols, sum32);
+
+        if (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR]) {
+            // pass 2: squared deviations from the float64 mean (Numba nanvar is two-pass)
+            double ssd[4] = {0, 0, 0, 0};
+            walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
+                if (!(a.mask_rows[ky] >> kx & 1ull)) return;
+                const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const double d = (double)v[o] - mean[o];
+                    ssd[o] += isnan(v[o]) ? 0.0 : d * d;
+                }
+            });
+            float o_var[4], o_std[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const double var = ssd[o] / (double)cnt[o];
+                o_var[o] = (float)var;
+                o_std[o] = (float)sqrt(var);
+            }
+            store_row<VEC>(a.out[XRS_STAT_VAR], a.ld_out, y, x0, a.cols, o_var);
+            store_row<VEC>(a.out[XRS_STAT_STD], a.ld_out, y, x0, a.cols, o_std);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ convolve_2d
+template <int KH, int KW, bool VEC>
+__global__ void __launch_bounds__(256) convolve_kernel(const KxkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const long X0 = tx * TW, Y0 = ty * a.th;
+    load_tile<VEC>(a, tile, X0, Y0, a.krows / 2);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const long x0 = X0 + lane * 4;
+    if (x0 >= a.cols) return;
+    const int rpw = a.th >> 2;
+    const int kw = KW ? KW : a.kcols;
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int orow = wy * rpw + rr;
+        const long y = Y0 + orow;
+        if (y >= a.rows) break;
+        double acc[4] = {0, 0, 0, 0};
+        walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
+            const double wt = a.weights[ky * kw + kx];     // wave-uniform address: scalar load
+            acc[0] += wt * (double)v0;
+            acc[1] += wt * (double)v1;
+            acc[2] += wt * (double)v2;
+            acc[3] += wt * (double)v3;
+        });
+        const float o[4] = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+        store_row<VEC>(a.out[0], a.ld_out, y, x0, a.cols, o);
+    }
+}
+
+// -------------------------------------------------------------------- focal.mean 3x3
+struct Mean3Args {
+    const void *in;
+    double *out;
+    long rows, cols, ld_in, ld_out;
+    int halo_top, halo_bot;
+    int n_excl;
+    double excl[8];
+};
+
+template <typename InT>
+__global__ void __launch_bounds__(256) focal_mean3_kernel(const Mean3Args a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.rows * a.cols) return;
+    const long y = idx / a.cols, x = idx - y * a.cols;
+    const InT *in = static_cast<const InT *>(a.in);
+    const double c = (double)in[y * a.ld_in + x];
+    bool excl = false;
+    for (int e = 0; e < a.n_excl; ++e)
+        excl = excl || c == a.excl[e] || (isnan(c) && isnan(a.excl[e]));
+    double res = c;
+    if (!excl) {
+        const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+        double s = 0.0;
+        int n = 0;
+        for (long yy = y - 1; yy <= y + 1; ++yy) {
+            if (yy < y_lo || yy >= y_hi) continue;
+            for (long xx = x - 1; xx <= x + 1; ++xx) {
+                if (xx < 0 || xx >= a.cols) continue;
+                const double v = (double)in[yy * a.ld_in + xx];
+                if (!isnan(v)) { s += v; ++n; }
+            }
+        }
+        res = s / (double)n;
+    }
+    a.out[y * a.ld_out + x] = res;
+}
+
+// --------------------------------------------------------------------------- host side
+int plan_tile(KxkArgs &a, size_t *lds_bytes) {
+    const int rx = a.kcols / 2;
+    a.lpad = (rx + 3) & ~3;
+    a.lw = TW + 2 * a.lpad + 4;      // one spare 16-byte slot: the runtime walk reads whole slots
+    for (int th = 16; th >= 4; th >>= 1) {
+        const size_t bytes = (size_t)(th + a.krows - 1) * a.lw * sizeof(float);
+        if (bytes <= 64 * 1024) {
+            a.th = th;
+            *lds_bytes = bytes;
+            return 0;
+        }
+    }
+    return fail("kernel %dx%d needs more than 64 KiB of LDS per tile (limit ~49x49 this release)", a.krows, a.kcols);
+}
+
+int check_common(const char *who, const float *in, long rows, long cols, long ld_in, long ld_out,
+                 const double *kernel, int krows, int kcols, int ht, int hb) {
+    if (!in) return fail("%s: null input", who);
+    if (rows < 0 || cols < 0 || ld_in < cols || ld_out < cols) return fail("%s: bad shape", who);
+    if (!kernel || krows <= 0 || kcols <= 0 || !(krows & 1) || !(kcols & 1))
+        return fail("%s: kernel must be odd x odd, got %dx%d", who, krows, kcols);
+    if (krows > MAX_K || kcols > MAX_K) return fail("%s: kernel larger than %d", who, MAX_K);
+    if (ht < 0 || hb < 0) return fail("%s: negative halo", who);
+    return 0;
+}
+
+bool vec_ok(const KxkArgs &a, unsigned out_mask) {
+    bool v = (a.cols % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) && aligned16(a.in);
+    for (int i = 0; i < XRS_NUM_STATS; ++i)
+        if ((out_mask >> i & 1) && a.out[i]) v = v && aligned16(a.out[i]);
+    return v;
+}
+
+template <int KH, int KW, bool MEAN_ONLY>
+int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
+    const unsigned grid = (unsigned)xcd_grid(a.n_tiles);
+    if (vec)
+        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MEAN_ONLY, true>), dim3(grid), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MEAN_ONLY, false>), dim3(grid), dim3(256), lds, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool MEAN_ONLY>
+int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
+    if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY>(a, vec, lds, s);
+    if (MEAN_ONLY) {
+        // the unrolled all-statistics bodies need > 170 VGPRs beyond 3x3; the runtime walk needs 72
+        if (a.krows == 5 && a.kcols == 5) return launch_focal<5, 5, true>(a, vec, lds, s);
+        if (a.krows == 7 && a.kcols == 7) return launch_focal<7, 7, true>(a, vec, lds, s);
+    }
+    return launch_focal<0, 0, MEAN_ONLY>(a, vec, lds, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xrs_kxk_workspace_bytes(int krows, int kcols) {
+    if (krows <= 0 || kcols <= 0) return 0;
+    return (size_t)krows * kcols * sizeof(double);       // float64 weights of convolve2d
+}
+
+int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                       int64_t ld_out, const double *kernel, int krows, int kcols, void *work_dev,
+                       int halo_top, int halo_bot, void *stream) {
+    if (int rc = check_common("xrs_convolve2d_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
+                              halo_top, halo_bot)) return rc;
+    if (!out_dev || !work_dev) return fail("xrs_convolve2d_f32: null output/workspace");
+    if (rows == 0 || cols == 0) return 0;
+    KxkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev; a.out[0] = out_dev;
+    a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
+    a.halo_top = halo_top; a.halo_bot = halo_bot; a.krows = krows; a.kcols = kcols;
+    size_t lds;
+    if (int rc = plan_tile(a, &lds)) return rc;
+    hipStream_t s = as_stream(stream);
+    XRS_HIP(hipMemcpyAsync(work_dev, kernel, (size_t)krows * kcols * sizeof(double), hipMemcpyHostToDevice, s));
+    a.weights = static_cast<const double *>(work_dev);
+    a.tiles_x = (cols + TW - 1) / TW;
+    a.n_tiles = a.tiles_x * ((rows + a.th - 1) / a.th);
+    const unsigned grid = (unsigned)xcd_grid(a.n_tiles);
+    const bool vec = vec_ok(a, 1u);
+#define XRS_CONV(KH, KW)                                                                              \
+    do {                                                                                              \
+        if (vec) hipLaunchKernelGGL((convolve_kernel<KH, KW, true>), dim3(grid), dim3(256), lds, s, a);  \
+        else hipLaunchKernelGGL((convolve_kernel<KH, KW, false>), dim3(grid), dim3(256), lds, s, a);     \
+    } while (0)
+    if (krows == 3 && kcols == 3) XRS_CONV(3, 3);
+    else if (krows == 5 && kcols == 5) XRS_CONV(5, 5);
+    else XRS_CONV(0, 0);
+#undef XRS_CONV
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned stat_mask, int64_t rows,
+                        int64_t cols, int64_t ld_in, int64_t ld_out, const double *kernel, int krows,
+                        int kcols, void *work_dev, int halo_top, int halo_bot, void *stream) {
+    if (int rc = check_common("xrs_focal_stats_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
+                              halo_top, halo_bot)) return rc;
+    if (!outs_dev) return fail("xrs_focal_stats_f32: null outputs");
+    stat_mask &= (1u << XRS_NUM_STATS) - 1;
+    if (!stat_mask) return 0;
+    KxkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev;
+    for (int i = 0; i < XRS_NUM_STATS; ++i) {
+        if (stat_mask >> i & 1) {
+            if (!outs_dev[i]) return fail("xrs_focal_stats_f32: statistic %d selected but its output is NULL", i);
+            a.out[i] = outs_dev[i];
+        }
+    }
+    if (rows == 0 || cols == 0) return 0;
+    a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
+    a.halo_top = halo_top; a.halo_bot = halo_bot; a.krows = krows; a.kcols = kcols;
+    size_t lds;
+    if (int rc = plan_tile(a, &lds)) return rc;
+    hipStream_t s = as_stream(stream);
+
+    // `kernel == 1` exactly selects a tap (focal.py:323)
+    for (int ky = 0; ky < krows; ++ky) {
+        unsigned long long bits = 0;
+        for (int kx = 0; kx < kcols; ++kx)
+            if (kernel[ky * kcols + kx] == 1.0) bits |= 1ull << kx;
+        a.mask_rows[ky] = bits;
+    }
+    (void)work_dev;   // reserved (row-run tables for large masks); the bit-rows travel as kernel arguments
+
+    a.tiles_x = (cols + TW - 1) / TW;
+    a.n_tiles = a.tiles_x * ((rows + a.th - 1) / a.th);
+    const bool vec = vec_ok(a, stat_mask);
+    if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
+    // the all-statistics kernel always produces the mean internally; give it somewhere to go
+    return dispatch_focal<false>(a, vec, lds, s);
+}
+
+int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_t rows, int64_t cols,
+                      int64_t ld_in, int64_t ld_out, const double *excludes, int n_excludes, int halo_top,
+                      int halo_bot, void *stream) {
+    if (!in_dev || !out_dev) return fail("xrs_focal_mean3x3: null pointer");
+    if (rows < 0 || cols < 0 || ld_in < cols || ld_out < cols) return fail("xrs_focal_mean3x3: bad shape");
+    if (n_excludes < 0 || n_excludes > 8) return fail("xrs_focal_mean3x3: at most 8 exclude values");
+    if (rows == 0 || cols == 0) return 0;
+    Mean3Args a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev; a.out = out_dev; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
+    a.halo_top = halo_top; a.halo_bot = halo_bot; a.n_excl = n_excludes;
+    for (int i = 0; i < n_excludes; ++i) a.excl[i] = excludes[i];
+    const long grid = (rows * cols + 255) / 256;
+    if (grid > 0x7fffffffL) return fail("xrs_focal_mean3x3: raster too large");
+    if (in_is_f64)
+        hipLaunchKernelGGL(focal_mean3_kernel<double>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(focal_mean3_kernel<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

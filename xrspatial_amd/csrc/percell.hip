@@ -1,0 +1,119 @@
+// Per-cell multispectral indices: ndvi (normalized ratio), evi, savi.
+//
+// Reference runners replaced:
+//   _normalized_ratio_cpu  xrspatial/multispectral.py:825-841  (pure float32)
+//   _evi_cpu               xrspatial/multispectral.py:175-188  (float64 denominator)
+//   _savi_cpu              xrspatial/multispectral.py:876-890  (float64 once L enters)
+// Streaming kernels, 12-16 B/cell, no reuse: 16-byte loads/stores, a capped grid
+// with a grid-stride loop, IEEE float32 / float64 division (bit-exact vs the CPU path).
+#include "xrs_common.h"
+
+// bit-exact vs the CPU path: no FMA contraction (Numba does not contract either)
+#pragma clang fp contract(off)
+
+using namespace xrs;
+
+namespace {
+
+__device__ __forceinline__ float nratio(float a, float b) {
+    const float num = a - b, den = a + b;
+    return den == 0.0f ? nan_f32() : num / den;
+}
+
+__device__ __forceinline__ float evi1(float nir, float red, float blue, double c1, double c2, double L, double gain) {
+    const float num = nir - red;
+    const double den = (double)nir + c1 * (double)red - c2 * (double)blue + L;
+    return den != 0.0 ? (float)(gain * ((double)num / den)) : nan_f32();
+}
+
+__device__ __forceinline__ float savi1(float nir, float red, double L, double onepl) {
+    const float num = nir - red;
+    const double soma = (double)(nir + red) + L;
+    const double den = soma * onepl;
+    return den != 0.0 ? (float)((double)num / den) : nan_f32();
+}
+
+struct CellArgs {
+    const float *a, *b, *c;
+    float *out;
+    long n;
+    double p0, p1, p2, p3;
+};
+
+enum : int { K_NRATIO = 0, K_EVI = 1, K_SAVI = 2 };
+
+template <int K>
+__device__ __forceinline__ float cell(const CellArgs &q, float a, float b, float c) {
+    if (K == K_NRATIO) return nratio(a, b);
+    if (K == K_EVI) return evi1(a, b, c, q.p0, q.p1, q.p2, q.p3);
+    return savi1(a, b, q.p0, q.p1);
+}
+
+template <int K, bool VEC>
+__global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
+    const long stride = (long)gridDim.x * 256;
+    if (VEC) {
+        const long n4 = q.n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 a = reinterpret_cast<const float4 *>(q.a)[i];
+            const float4 b = reinterpret_cast<const float4 *>(q.b)[i];
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (K == K_EVI) c = reinterpret_cast<const float4 *>(q.c)[i];
+            float4 o;
+            o.x = cell<K>(q, a.x, b.x, c.x);
+            o.y = cell<K>(q, a.y, b.y, c.y);
+            o.z = cell<K>(q, a.z, b.z, c.z);
+            o.w = cell<K>(q, a.w, b.w, c.w);
+            reinterpret_cast<float4 *>(q.out)[i] = o;
+        }
+        // tail (n % 4 cells)
+        const long t = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x;
+        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], K == K_EVI ? q.c[t] : 0.f);
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < q.n; i += stride)
+            q.out[i] = cell<K>(q, q.a[i], q.b[i], K == K_EVI ? q.c[i] : 0.f);
+    }
+}
+
+template <int K>
+int launch(const CellArgs &q, hipStream_t s) {
+    if (q.n <= 0) return 0;
+    const bool vec = aligned16(q.a) && aligned16(q.b) && aligned16(q.out) && (K != K_EVI || aligned16(q.c));
+    const long work = vec ? ((q.n + 3) >> 2) : q.n;
+    long grid = (work + 255) / 256;
+    const long cap = 256L * 16;            // 256 CUs x 16 workgroups, grid-stride beyond
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    if (vec)
+        hipLaunchKernelGGL((percell_kernel<K, true>), dim3((unsigned)grid), dim3(256), 0, s, q);
+    else
+        hipLaunchKernelGGL((percell_kernel<K, false>), dim3((unsigned)grid), dim3(256), 0, s, q);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xrs_normalized_ratio_f32(const float *a_dev, const float *b_dev, float *out_dev, int64_t n, void *stream) {
+    if (n > 0 && (!a_dev || !b_dev || !out_dev)) return fail("xrs_normalized_ratio_f32: null pointer");
+    CellArgs q{a_dev, b_dev, nullptr, out_dev, n, 0, 0, 0, 0};
+    return launch<K_NRATIO>(q, as_stream(stream));
+}
+
+int xrs_evi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev, int64_t n,
+                double c1, double c2, double soil_factor, double gain, void *stream) {
+    if (n > 0 && (!nir_dev || !red_dev || !blue_dev || !out_dev)) return fail("xrs_evi_f32: null pointer");
+    CellArgs q{nir_dev, red_dev, blue_dev, out_dev, n, c1, c2, soil_factor, gain};
+    return launch<K_EVI>(q, as_stream(stream));
+}
+
+int xrs_savi_f32(const float *nir_dev, const float *red_dev, float *out_dev, int64_t n, double soil_factor,
+                 void *stream) {
+    if (n > 0 && (!nir_dev || !red_dev || !out_dev)) return fail("xrs_savi_f32: null pointer");
+    CellArgs q{nir_dev, red_dev, nullptr, out_dev, n, soil_factor, 1.0 + soil_factor, 0, 0};
+    return launch<K_SAVI>(q, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+// 3x3 terrain family: slope, aspect, curvature, hillshade (single and fused).
+//
+// Reference runners replaced (CPU arithmetic is the contract):
+//   slope      xrspatial/slope.py:56-76       aspect     xrspatial/aspect.py:56-90
+//   curvature  xrspatial/curvature.py:31-49   hillshade  xrspatial/hillshade.py:20-35
+//
+// Kernel shape (HBM-bound, 4 B in + 4 B out per cell, no MFMA):
+//   * a 256-thread workgroup = 4 waves stacked in y; each wave owns a strip of
+//     256 columns (64 lanes x one 16-byte float4) by RB rows.
+//   * every lane keeps its (RB+2) x 6 neighbourhood in VGPRs: one aligned
+//     global_load_dwordx4 per row plus two single-dword loads for the columns
+//     left/right of its float4 (those lines are in L1/L2 because the neighbouring
+//     lane / strip fetches them as its own float4).  All (RB+2)*3 loads of a lane
+//     are independent and issued before the first use, which is what keeps
+//     enough bytes in flight to cover HBM latency.
+//   * no LDS: a 3-wide window needs no cross-lane traffic beyond the two halo
+//     dwords (measured against an LDS-tile variant).
+//   * the NaN border is written by the same kernel (the reference pre-fills the
+//     output with NaN and overwrites the interior: twice the write traffic).
+//   * tiles are numbered row-major and dealt to XCDs in contiguous bands
+//     (xrs::xcd_tile) so vertically adjacent strips share an L2.
+// A scalar one-thread-per-cell kernel handles rasters whose width / pitch /
+// base address are not multiples of 16 bytes.
+#include "xrs_common.h"
+
+using namespace xrs;
+
+namespace {
+
+enum : int { OP_SLOPE = 1, OP_ASPECT = 2, OP_CURV = 4, OP_HILL = 8 };
+
+struct TerrainArgs {
+    const float *in;
+    void *out[4];            // slope, aspect, curvature, hillshade
+    long rows, cols, ld_in, ld_out;
+    int halo_top, halo_bot;
+    double inv8cx, inv8cy;   // slope: 1 / (8 * cellsize)
+    double curv_scale;       // curvature: -200 / cellsize^2
+    float sin_alt, cos_alt, cos_az, sin_az;   // hillshade: az = (360-azimuth) deg - pi/2
+    long tiles_x, n_tiles;
+};
+
+// 3x3 neighbourhood, n* = row y-1, s* = row y+1.
+struct Nb { float nw, n, ne, w, c, e, sw, s, se; };
+
+__device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double inv8cy) {
+    // slope.py:64-75: a,b,c = row y+1; g,h,i = row y-1; sums in float64.
+    const double dx = ((((double)q.se + 2.0 * (double)q.e) + (double)q.ne) -
+                       (((double)q.sw + 2.0 * (double)q.w) + (double)q.nw)) * inv8cx;
+    const double dy = ((((double)q.nw + 2.0 * (double)q.n) + (double)q.ne) -
+                       (((double)q.sw + 2.0 * (double)q.s) + (double)q.se)) * inv8cy;
+    const float fx = (float)dx, fy = (float)dy;
+    return atanf(sqrtf(fx * fx + fy * fy)) * 57.29578f;
+}
+
+__device__ __forceinline__ float aspect_cell(const Nb &q) {
+    // aspect.py:66-88: a,b,c = row y-1; g,h,i = row y+1; /8; float64 flat test.
+    const double dx = ((((double)q.ne + 2.0 * (double)q.e) + (double)q.se) -
+                       (((double)q.nw + 2.0 * (double)q.w) + (double)q.sw)) * 0.125;
+    const double dy = ((((double)q.sw + 2.0 * (double)q.s) + (double)q.se) -
+                       (((double)q.nw + 2.0 * (double)q.n) + (double)q.ne)) * 0.125;
+    if (dx == 0.0 && dy == 0.0) return -1.0f;
+    // compass = 90 - atan2(dy, -dx) wrapped to [0, 360)  ==  atan2(-dx, dy) wrapped:
+    // evaluating it this way keeps full relative accuracy near 0 degrees.
+    float deg = atan2f((float)(-dx), (float)dy) * 57.29577951308232f;
+    return deg < 0.0f ? deg + 360.0f : deg;
+}
+
+__device__ __forceinline__ float curvature_cell(const Nb &q, double scale) {
+    // curvature.py:37-39: pair sums float32, the rest float64.
+    const double d = (double)(q.s + q.n) * 0.5 - (double)q.c;
+    const double e = (double)(q.e + q.w) * 0.5 - (double)q.c;
+    return (float)((d + e) * scale);
+}
+
+__device__ __forceinline__ float hillshade_cell(const Nb &q, float sin_alt, float cos_alt,
+                                                float cos_az, float sin_az) {
+    // hillshade.py:24-31 with the trigonometry folded away: for gx = d/drow, gy = d/dcol,
+    //   sin(pi/2 - atan g) = 1/sqrt(1+g^2),  cos(pi/2 - atan g) = g/sqrt(1+g^2),
+    //   cos(A - atan2(-gx, gy)) = (cosA*gy - sinA*gx)/g
+    // => shaded = (sin_alt + cos_alt*(cosA*gy - sinA*gx)) / sqrt(1 + gx^2 + gy^2).
+    const float gx = (q.s - q.n) * 0.5f;
+    const float gy = (q.e - q.w) * 0.5f;
+    const float num = fmaf(cos_alt, fmaf(cos_az, gy, -sin_az * gx), sin_alt);
+    const float shaded = num * rsqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
+    return (shaded + 1.0f) * 0.5f;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT *p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<double>(double *p, const float (&v)[4]) {
+    reinterpret_cast<double2 *>(p)[0] = make_double2((double)v[0], (double)v[1]);
+    reinterpret_cast<double2 *>(p)[1] = make_double2((double)v[2], (double)v[3]);
+}
+
+// ---------------------------------------------------------------- fast path
+template <int OPS, typename HillT, int RB>
+__global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a) {
+    const long tile = xcd_tile(blockIdx.x, a.n_tiles);
+    if (tile < 0) return;
+    const long ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const long x0 = tx * 256 + lane * 4;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (x0 >= a.cols || y0 >= a.rows) return;
+
+    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;   // valid input rows [y_lo, y_hi)
+    const bool has_l = x0 > 0, has_r = x0 + 4 < a.cols;
+
+    // v[r][0..5] = columns x0-1 .. x0+4 of input row y0 + r - 1
+    float v[RB + 2][6];
+#pragma unroll
+    for (int r = 0; r < RB + 2; ++r) {
+        const long y = y0 + r - 1;
+        const bool ok = y >= y_lo && y < y_hi;
+        const float *p = a.in + y * a.ld_in + x0;
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float l = 0.f, rr = 0.f;
+        if (ok) {
+            c4 = *reinterpret_cast<const float4 *>(p);
+            if ((OPS & (OP_SLOPE | OP_ASPECT)) || (r >= 1 && r <= RB)) {   // diagonal-free ops need halo columns on centre rows only
+                if (has_l) l = p[-1];
+                if (has_r) rr = p[4];
+            }
+        }
+        v[r][0] = l; v[r][1] = c4.x; v[r][2] = c4.y; v[r][3] = c4.z; v[r][4] = c4.w; v[r][5] = rr;
+    }
+
+    const float qnan = nan_f32();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const long y = y0 + r;
+        if (y >= a.rows) break;
+        const bool row_border = (y - 1 < y_lo) || (y + 1 >= y_hi);
+        float o_slope[4], o_aspect[4], o_curv[4], o_hill[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const long x = x0 + o;
+            const bool border = row_border || x == 0 || x == a.cols - 1;
+            Nb q;
+            q.nw = v[r][o];     q.n = v[r][o + 1];     q.ne = v[r][o + 2];
+            q.w = v[r + 1][o];  q.c = v[r + 1][o + 1]; q.e = v[r + 1][o + 2];
+            q.sw = v[r + 2][o]; q.s = v[r + 2][o + 1]; q.se = v[r + 2][o + 2];
+            // (a.out[i] tests are wave-uniform: the fused instantiation skips absent products)
+            if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_cell(q, a.inv8cx, a.inv8cy);
+            if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_cell(q);
+            if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
+            if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
+        }
+        const long off = y * a.ld_out + x0;
+        if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off, o_slope);
+        if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off, o_aspect);
+        if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off, o_curv);
+        if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off, o_hill);
+    }
+}
+
+// ------------------------------------------------------------- generic path
+template <typename HillT>
+__global__ void __launch_bounds__(256) terrain_cell_kernel(const TerrainArgs a, const int ops) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.rows * a.cols) return;
+    const long y = idx / a.cols, x = idx - y * a.cols;
+    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+    const bool border = (y - 1 < y_lo) || (y + 1 >= y_hi) || x == 0 || x == a.cols - 1;
+    float r_slope, r_aspect, r_curv, r_hill;
+    r_slope = r_aspect = r_curv = r_hill = nan_f32();
+    if (!border) {
+        const float *p = a.in + y * a.ld_in + x;
+        Nb q;
+        q.nw = p[-a.ld_in - 1]; q.n = p[-a.ld_in]; q.ne = p[-a.ld_in + 1];
+        q.w = p[-1];            q.c = p[0];        q.e = p[1];
+        q.sw = p[a.ld_in - 1];  q.s = p[a.ld_in];  q.se = p[a.ld_in + 1];
+        if (ops & OP_SLOPE) r_slope = slope_cell(q, a.inv8cx, a.inv8cy);
+        if (ops & OP_ASPECT) r_aspect = aspect_cell(q);
+        if (ops & OP_CURV) r_curv = curvature_cell(q, a.curv_scale);
+        if (ops & OP_HILL) r_hill = hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
+    }
+    const long off = y * a.ld_out + x;
+    if ((ops & OP_SLOPE) && a.out[0]) static_cast<float *>(a.out[0])[off] = r_slope;
+    if ((ops & OP_ASPECT) && a.out[1]) static_cast<float *>(a.out[1])[off] = r_aspect;
+    if ((ops & OP_CURV) && a.out[2]) static_cast<float *>(a.out[2])[off] = r_curv;
+    if ((ops & OP_HILL) && a.out[3]) static_cast<HillT *>(a.out[3])[off] = (HillT)r_hill;
+}
+
+constexpr int RB_DEFAULT = 4;
+
+template <int OPS, typename HillT>
+int launch_strip(TerrainArgs &a, hipStream_t s) {
+    constexpr int RB = RB_DEFAULT;
+    a.tiles_x = (a.cols + 255) / 256;
+    const long tiles_y = (a.rows + 4 * RB - 1) / (4 * RB);
+    a.n_tiles = a.tiles_x * tiles_y;
+    const long grid = xcd_grid(a.n_tiles);
+    if (grid > 0x7fffffffL) return fail("terrain: raster too large for one launch");
+    hipLaunchKernelGGL((terrain_strip_kernel<OPS, HillT, RB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int terrain_dispatch(TerrainArgs &a, int ops, bool hill_f64, hipStream_t s) {
+    if (a.rows <= 0 || a.cols <= 0) return 0;
+    if (a.rows < 0 || a.cols < 0 || a.ld_in < a.cols || a.ld_out < a.cols)
+        return fail("terrain: bad shape rows=%ld cols=%ld ld_in=%ld ld_out=%ld", a.rows, a.cols, a.ld_in, a.ld_out);
+    if (a.halo_top < 0 || a.halo_bot < 0) return fail("terrain: negative halo");
+    bool fast = (a.cols % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) && aligned16(a.in);
+    for (int i = 0; i < 4; ++i)
+        if ((ops >> i & 1) && a.out[i]) fast = fast && aligned16(a.out[i]);
+    if (hill_f64 && (a.ld_out % 2)) fast = false;
+    if (fast) {
+        switch (ops) {
+            case OP_SLOPE: return launch_strip<OP_SLOPE, float>(a, s);
+            case OP_ASPECT: return launch_strip<OP_ASPECT, float>(a, s);
+            case OP_CURV: return launch_strip<OP_CURV, float>(a, s);
+            case OP_HILL: return hill_f64 ? launch_strip<OP_HILL, double>(a, s) : launch_strip<OP_HILL, float>(a, s);
+            default: return launch_strip<15, float>(a, s);
+        }
+    }
+    const long n = a.rows * a.cols;
+    const long grid = (n + 255) / 256;
+    if (grid > 0x7fffffffL) return fail("terrain: raster too large for the unaligned path");
+    if (hill_f64)
+        hipLaunchKernelGGL(terrain_cell_kernel<double>, dim3((unsigned)grid), dim3(256), 0, s, a, ops);
+    else
+        hipLaunchKernelGGL(terrain_cell_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a, ops);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+TerrainArgs base_args(const float *in, long rows, long cols, long ld_in, long ld_out, int ht, int hb) {
+    TerrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
+    a.halo_top = ht; a.halo_bot = hb;
+    return a;
+}
+
+void set_hillshade(TerrainArgs &a, double azimuth, double altitude) {
+    // hillshade.py:23-31: azimuth = 360 - azimuth; A = azimuth*pi/180 - pi/2
+    const double kPi = 3.14159265358979323846;
+    const double az = (360.0 - azimuth) * kPi / 180.0 - kPi / 2.0;
+    const double alt = altitude * kPi / 180.0;
+    a.sin_alt = (float)sin(alt); a.cos_alt = (float)cos(alt);
+    a.cos_az = (float)cos(az);   a.sin_az = (float)sin(az);
+}
+
+}  // namespace
+
+extern "C" {
+
+int xrs_slope_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                  int64_t ld_out, double cellsize_x, double cellsize_y, int halo_top, int halo_bot,
+                  void *stream) {
+    if (!in_dev || !out_dev) return fail("xrs_slope_f32: null pointer");
+    TerrainArgs a = base_args(in_dev, rows, cols, ld_in, ld_out, halo_top, halo_bot);
+    a.out[0] = out_dev;
+    a.inv8cx = 1.0 / (8 * cellsize_x);
+    a.inv8cy = 1.0 / (8 * cellsize_y);
+    return terrain_dispatch(a, OP_SLOPE, false, as_stream(stream));
+}
+
+int xrs_aspect_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                   int64_t ld_out, int halo_top, int halo_bot, void *stream) {
+    if (!in_dev || !out_dev) return fail("xrs_aspect_f32: null pointer");
+    TerrainArgs a = base_args(in_dev, rows, cols, ld_in, ld_out, halo_top, halo_bot);
+    a.out[1] = out_dev;
+    return terrain_dispatch(a, OP_ASPECT, false, as_stream(stream));
+}
+
+int xrs_curvature_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                      int64_t ld_out, double cellsize, int halo_top, int halo_bot, void *stream) {
+    if (!in_dev || !out_dev) return fail("xrs_curvature_f32: null pointer");
+    TerrainArgs a = base_args(in_dev, rows, cols, ld_in, ld_out, halo_top, halo_bot);
+    a.out[2] = out_dev;
+    a.curv_scale = -200.0 / (cellsize * cellsize);
+    return terrain_dispatch(a, OP_CURV, false, as_stream(stream));
+}
+
+int xrs_hillshade_f32(const float *in_dev, void *out_dev, int out_f64, int64_t rows, int64_t cols,
+                      int64_t ld_in, int64_t ld_out, double azimuth, double angle_altitude,
+                      int halo_top, int halo_bot, void *stream) {
+    if (!in_dev || !out_dev) return fail("xrs_hillshade_f32: null pointer");
+    TerrainArgs a = base_args(in_dev, rows, cols, ld_in, ld_out, halo_top, halo_bot);
+    a.out[3] = out_dev;
+    set_hillshade(a, azimuth, angle_altitude);
+    return terrain_dispatch(a, OP_HILL, out_f64 != 0, as_stream(stream));
+}
+
+int xrs_terrain_fused_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                          float *hillshade_dev, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                          double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
+                          int halo_top, int halo_bot, void *stream) {
+    if (!in_dev) return fail("xrs_terrain_fused_f32: null input");
+    TerrainArgs a = base_args(in_dev, rows, cols, ld_in, ld_out, halo_top, halo_bot);
+    a.out[0] = slope_dev; a.out[1] = aspect_dev; a.out[2] = curvature_dev; a.out[3] = hillshade_dev;
+    a.inv8cx = 1.0 / (8 * cellsize_x);
+    a.inv8cy = 1.0 / (8 * cellsize_y);
+    const double cs = (cellsize_x + cellsize_y) / 2;       // curvature.py:241
+    a.curv_scale = -200.0 / (cs * cs);
+    set_hillshade(a, azimuth, angle_altitude);
+    int ops = 0;
+    if (slope_dev) ops |= OP_SLOPE;
+    if (aspect_dev) ops |= OP_ASPECT;
+    if (curvature_dev) ops |= OP_CURV;
+    if (hillshade_dev) ops |= OP_HILL;
+    if (!ops) return 0;
+    // single products go through their specialised kernel; any combination uses the fused one
+    const int single = (ops & (ops - 1)) == 0 ? ops : 15;
+    return terrain_dispatch(a, single, false, as_stream(stream));
+}
+
+}  // extern "C"

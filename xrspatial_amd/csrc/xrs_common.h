@@ -1,0 +1,62 @@
+// Shared helpers for libxrs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/xrs_hip.h"
+
+namespace xrs {
+
+// Per-thread last-error text: the only mutable state in the library.
+inline char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+inline int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define XRS_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return ::xrs::fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                               __FILE__, __LINE__);                                    \
+    } while (0)
+
+#define XRS_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess)                                                          \
+            return ::xrs::fail("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                    \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// blockIdx -> tile index so that each XCD owns one contiguous run of tiles.
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed,
+// used for speed only): with tiles numbered row-major, XCD k then streams through
+// its own horizontal band of the raster and every halo row / halo column it
+// re-reads was fetched into ITS L2 by a neighbouring tile.  Returns -1 for the
+// (< 8) surplus blocks of the padded grid.
+__device__ __forceinline__ long xcd_tile(long block, long n_tiles) {
+    const long per_xcd = (n_tiles + 7) >> 3;
+    const long t = (block & 7) * per_xcd + (block >> 3);
+    return ((block >> 3) < per_xcd && t < n_tiles) ? t : -1;
+}
+inline long xcd_grid(long n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
+
+__device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); }
+
+}  // namespace xrs

@@ -1,0 +1,288 @@
+// zonal.stats partial reductions: one streaming pass over (zone index, value).
+//
+// Reference path replaced: _stats_numpy / _sort_and_stride / _calc_stats,
+// xrspatial/zonal.py:121-163, 280-332 (two full argsorts + a Python loop over zones).
+// The algebra is the reference's own dask path: per-block count / sum / sum of squares /
+// min / max (_DASK_BLOCK_STATS, zonal.py:83-89) combined by sum / nanmin / nanmax (:92-99),
+// mean = sum/count, var = (sumsq - sum^2/n)/n (:100-102).
+//
+// Kernel shape (HBM-bound, 8 B/cell read-only, no sort):
+//   * each lane loads 4 consecutive cells (one int4 of zone indices + one float4 of values)
+//     and folds them when they share a zone;
+//   * when every lane of the wavefront holds the same zone (the common case for real zone
+//     rasters: zones are spatially coherent) the 64 lane partials are reduced with
+//     wave64 shuffles and ONE lane touches the accumulators; otherwise lanes fall back to
+//     individual LDS atomics;
+//   * accumulators are privatised per workgroup in LDS (sum f64, sumsq f64, min, max, count u32
+//     = 28 B/zone for float32 values, up to 64 KiB) and flushed once per workgroup with device-scope atomics.
+// Counts are integers: bit-exact whatever the order.  float64 sums depend on arrival order
+// at the 1e-16 level.
+#include "xrs_common.h"
+
+using namespace xrs;
+
+namespace {
+
+
+template <typename VT>
+struct ZonalArgs {
+    const int32_t *zidx;
+    const VT *vals;
+    long n;
+    int nz;
+    VT nodata;
+    int has_nodata;
+    unsigned long long *count;
+    double *sum, *sumsq;
+    VT *mn, *mx;
+};
+
+template <typename VT> struct Bits;
+template <> struct Bits<float> {
+    using U = unsigned;
+    static __device__ __forceinline__ float from(U u) { return __uint_as_float(u); }
+    static __device__ __forceinline__ U to(float f) { return __float_as_uint(f); }
+};
+template <> struct Bits<double> {
+    using U = unsigned long long;
+    static __device__ __forceinline__ double from(U u) { return __longlong_as_double((long long)u); }
+    static __device__ __forceinline__ U to(double f) { return (U)__double_as_longlong(f); }
+};
+
+template <typename VT>
+__device__ __forceinline__ void atomic_min_dev(VT *addr, VT v) {
+    using U = typename Bits<VT>::U;
+    U *a = reinterpret_cast<U *>(addr);
+    U old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v < Bits<VT>::from(old)) {
+        const U assumed = old;
+        old = atomicCAS(a, assumed, Bits<VT>::to(v));
+        if (old == assumed) break;
+    }
+}
+template <typename VT>
+__device__ __forceinline__ void atomic_max_dev(VT *addr, VT v) {
+    using U = typename Bits<VT>::U;
+    U *a = reinterpret_cast<U *>(addr);
+    U old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v > Bits<VT>::from(old)) {
+        const U assumed = old;
+        old = atomicCAS(a, assumed, Bits<VT>::to(v));
+        if (old == assumed) break;
+    }
+}
+
+template <typename VT>
+struct Part {            // a partial reduction for ONE zone
+    int z;               // -1: empty
+    unsigned c;
+    double s, q;
+    VT mn, mx;
+};
+
+template <typename VT>
+__device__ __forceinline__ bool cell_ok(const ZonalArgs<VT> &a, int z, VT v) {
+    // zonal.py:156: isfinite(values) & (values != nodata); zones outside [0, nz) are not selected
+    return z >= 0 && z < a.nz && isfinite(v) && !(a.has_nodata && v == a.nodata);
+}
+
+template <typename VT, bool LDS>
+struct Acc {
+    unsigned *c32; unsigned long long *c64;
+    double *s, *q;
+    VT *mn, *mx;
+    __device__ __forceinline__ void add(const Part<VT> &p) const {
+        if (LDS) {
+            atomicAdd(&c32[p.z], p.c);
+            atomicAdd(&s[p.z], p.s);
+            atomicAdd(&q[p.z], p.q);
+            __hip_atomic_fetch_min(&mn[p.z], p.mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&mx[p.z], p.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            atomicAdd(&c64[p.z], (unsigned long long)p.c);
+            atomicAdd(&s[p.z], p.s);
+            atomicAdd(&q[p.z], p.q);
+            atomic_min_dev(&mn[p.z], p.mn);
+            atomic_max_dev(&mx[p.z], p.mx);
+        }
+    }
+};
+
+template <typename VT, bool LDS, bool VEC>
+__global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Acc<VT, LDS> acc;
+    if (LDS) {
+        // layout: sum f64[nz] | sumsq f64[nz] | min VT[nz] | max VT[nz] | count u32[nz]
+        acc.s = reinterpret_cast<double *>(smem);
+        acc.q = acc.s + a.nz;
+        acc.mn = reinterpret_cast<VT *>(acc.q + a.nz);
+        acc.mx = acc.mn + a.nz;
+        acc.c32 = reinterpret_cast<unsigned *>(acc.mx + a.nz);
+        for (int z = threadIdx.x; z < a.nz; z += 256) {
+            acc.s[z] = 0.0; acc.q[z] = 0.0; acc.c32[z] = 0u;
+            acc.mn[z] = INFINITY; acc.mx[z] = -INFINITY;
+        }
+        __syncthreads();
+    } else {
+        acc.c64 = a.count; acc.s = a.sum; acc.q = a.sumsq; acc.mn = a.mn; acc.mx = a.mx;
+    }
+
+    const long n4 = VEC ? (a.n >> 2) : 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4 + (stride - n4 % stride) % stride; i += stride) {
+        // (loop bound padded to a multiple of the stride so whole waves stay converged for the shuffles)
+        int z[4] = {-1, -1, -1, -1};
+        VT v[4] = {0, 0, 0, 0};
+        if (i < n4) {
+            const int4 zi = reinterpret_cast<const int4 *>(a.zidx)[i];
+            z[0] = zi.x; z[1] = zi.y; z[2] = zi.z; z[3] = zi.w;
+            if constexpr (sizeof(VT) == 4) {
+                const float4 vf = reinterpret_cast<const float4 *>(a.vals)[i];
+                v[0] = vf.x; v[1] = vf.y; v[2] = vf.z; v[3] = vf.w;
+            } else {
+                const double2 va = reinterpret_cast<const double2 *>(a.vals)[2 * i];
+                const double2 vb = reinterpret_cast<const double2 *>(a.vals)[2 * i + 1];
+                v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[3] = vb.y;
+            }
+        }
+        // fold the lane's 4 cells while they stay in one zone; spill the partial when the zone changes
+        Part<VT> p; p.z = -1; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
+        bool lane_single = true;       // all valid cells of this lane fell into p.z
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!cell_ok(a, z[k], v[k])) continue;
+            if (p.z >= 0 && p.z != z[k]) {
+                acc.add(p);
+                lane_single = false;
+                p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
+            }
+            p.z = z[k];
+            const double d = (double)v[k];
+            p.c += 1; p.s += d; p.q += d * d;
+            p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
+        }
+        // wave-level: if every lane's surviving partial is for the same zone, shuffle-reduce it
+        const unsigned long long have = __ballot(p.z >= 0);
+        if (!have) continue;
+        const int first = __ffsll((long long)have) - 1;
+        const int z0 = __shfl(p.z, first);
+        const bool uniform = __all((p.z < 0 || p.z == z0) && lane_single);
+        if (uniform) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                p.c += __shfl_down(p.c, off);
+                p.s += __shfl_down(p.s, off);
+                p.q += __shfl_down(p.q, off);
+                const VT omn = __shfl_down(p.mn, off), omx = __shfl_down(p.mx, off);
+                p.mn = omn < p.mn ? omn : p.mn;
+                p.mx = omx > p.mx ? omx : p.mx;
+            }
+            if ((threadIdx.x & 63) == 0) { p.z = z0; acc.add(p); }
+        } else if (p.z >= 0) {
+            acc.add(p);
+        }
+    }
+
+    // scalar tail (n % 4 cells, or everything when the buffers are not 16-byte aligned)
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        const int z = a.zidx[i];
+        const VT v = a.vals[i];
+        if (cell_ok(a, z, v)) {
+            Part<VT> p; p.z = z; p.c = 1; p.s = (double)v; p.q = (double)v * (double)v; p.mn = v; p.mx = v;
+            acc.add(p);
+        }
+    }
+
+    if (LDS) {
+        __syncthreads();
+        for (int z = threadIdx.x; z < a.nz; z += 256) {
+            const unsigned c = acc.c32[z];
+            if (c) {
+                atomicAdd(&a.count[z], (unsigned long long)c);
+                atomicAdd(&a.sum[z], acc.s[z]);
+                atomicAdd(&a.sumsq[z], acc.q[z]);
+                atomic_min_dev(&a.mn[z], acc.mn[z]);
+                atomic_max_dev(&a.mx[z], acc.mx[z]);
+            }
+        }
+    }
+}
+
+template <typename VT>
+__global__ void zonal_init_kernel(unsigned long long *count, double *sum, double *sumsq, VT *mn, VT *mx, int nz) {
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (z < nz) { count[z] = 0ull; sum[z] = 0.0; sumsq[z] = 0.0; mn[z] = INFINITY; mx[z] = -INFINITY; }
+}
+
+
+
+template <typename VT>
+int zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev, VT *max_dev, int n_zones,
+               void *stream) {
+    if (n_zones < 0) return fail("xrs_zonal_init: negative n_zones");
+    if (n_zones == 0) return 0;
+    if (!count_dev || !sum_dev || !sumsq_dev || !min_dev || !max_dev) return fail("xrs_zonal_init: null pointer");
+    hipLaunchKernelGGL(zonal_init_kernel<VT>, dim3((n_zones + 255) / 256), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(count_dev), sum_dev, sumsq_dev, min_dev, max_dev, n_zones);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename VT>
+int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n, int n_zones, VT nodata,
+                   int has_nodata, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev,
+                   VT *max_dev, void *stream) {
+    if (n < 0 || n_zones < 0) return fail("xrs_zonal_partials: negative size");
+    if (n == 0 || n_zones == 0) return 0;
+    if (!zone_idx_dev || !values_dev || !count_dev || !sum_dev || !sumsq_dev || !min_dev || !max_dev)
+        return fail("xrs_zonal_partials: null pointer");
+    ZonalArgs<VT> a;
+    a.zidx = zone_idx_dev; a.vals = values_dev; a.n = n; a.nz = n_zones;
+    a.nodata = nodata; a.has_nodata = has_nodata;
+    a.count = reinterpret_cast<unsigned long long *>(count_dev);
+    a.sum = sum_dev; a.sumsq = sumsq_dev; a.mn = min_dev; a.mx = max_dev;
+    const bool vec = aligned16(zone_idx_dev) && aligned16(values_dev);
+    const size_t per_zone = 16 + 2 * sizeof(VT) + 4;
+    const bool lds = (size_t)n_zones * per_zone <= 64 * 1024;
+    const size_t smem = lds ? (size_t)n_zones * per_zone : 0;
+    // a u32 per-workgroup count cannot overflow: cap the cells one workgroup can see below 2^32
+    long grid = ((vec ? (n + 3) / 4 : n) + 255) / 256;
+    const long cap = 256L * 8;                  // 256 CUs x 8 workgroups, grid-stride beyond
+    if (grid > cap) grid = cap;
+    if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;
+    hipStream_t s = as_stream(stream);
+#define XRS_ZL(L, V) hipLaunchKernelGGL((zonal_kernel<VT, L, V>), dim3((unsigned)grid), dim3(256), smem, s, a)
+    if (lds && vec) XRS_ZL(true, true);
+    else if (lds) XRS_ZL(true, false);
+    else if (vec) XRS_ZL(false, true);
+    else XRS_ZL(false, false);
+#undef XRS_ZL
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xrs_zonal_init(uint64_t *c, double *s, double *q, float *mn, float *mx, int nz, void *stream) {
+    return zonal_init<float>(c, s, q, mn, mx, nz, stream);
+}
+int xrs_zonal_init_f64(uint64_t *c, double *s, double *q, double *mn, double *mx, int nz, void *stream) {
+    return zonal_init<double>(c, s, q, mn, mx, nz, stream);
+}
+int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones,
+                           float nodata, int has_nodata, uint64_t *count_dev, double *sum_dev,
+                           double *sumsq_dev, float *min_dev, float *max_dev, void *stream) {
+    return zonal_partials<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev,
+                                 sumsq_dev, min_dev, max_dev, stream);
+}
+int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones,
+                           double nodata, int has_nodata, uint64_t *count_dev, double *sum_dev,
+                           double *sumsq_dev, double *min_dev, double *max_dev, void *stream) {
+    return zonal_partials<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev,
+                                  sumsq_dev, min_dev, max_dev, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Device-resident arrays: the fifth backend slot next to numpy / cupy / dask / dask+cupy.
+
+A `DeviceArray` owns (or views) a C-order buffer in MI355X HBM obtained from
+xrs_malloc.  A DataArray whose `.data` is a DeviceArray stays on the device across
+calls (the reference's analogue is a cupy-backed DataArray, utils.py:124-143);
+a numpy-backed DataArray is copied in and out around each call.
+
+Freed buffers go to a small size-keyed free list so steady-state pipelines
+(bench.py, repeated calls) do not pay hipMalloc/hipFree per call.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_pool = {}
+_pool_lock = threading.Lock()
+_POOL_MAX_BYTES = 64 << 30
+_pool_bytes = 0
+
+
+def _raw_alloc(nbytes: int) -> int:
+    global _pool_bytes
+    nbytes = max(int(nbytes), 16)
+    with _pool_lock:
+        lst = _pool.get(nbytes)
+        if lst:
+            _pool_bytes -= nbytes
+            return lst.pop()
+    _lib.require_device()
+    p = ctypes.c_void_p()
+    try:
+        _lib.call("xrs_malloc", ctypes.byref(p), nbytes)
+    except _lib.XrsError:
+        empty_cache()
+        _lib.call("xrs_malloc", ctypes.byref(p), nbytes)
+    return p.value
+
+
+def _raw_free(ptr: int, nbytes: int):
+    global _pool_bytes
+    nbytes = max(int(nbytes), 16)
+    with _pool_lock:
+        if _pool_bytes + nbytes <= _POOL_MAX_BYTES:
+            _pool.setdefault(nbytes, []).append(ptr)
+            _pool_bytes += nbytes
+            return
+    _lib.load().xrs_free(ptr)
+
+
+def empty_cache():
+    """Return every cached buffer to the driver."""
+    global _pool_bytes
+    with _pool_lock:
+        for lst in _pool.values():
+            for p in lst:
+                _lib.load().xrs_free(p)
+        _pool.clear()
+        _pool_bytes = 0
+
+
+class DeviceArray:
+    """C-contiguous n-d array in HBM.  Minimal duck array: shape / dtype / ndim / size / get()."""
+
+    __array_priority__ = 1000
+
+    def __init__(self, shape, dtype=np.float32, _ptr=None, _base=None):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._base = _base                  # a view keeps its owner alive
+        if _ptr is None:
+            self.ptr = _raw_alloc(self.nbytes)
+            self._owns = True
+        else:
+            self.ptr = int(_ptr)
+            self._owns = False
+
+    # -- construction ---------------------------------------------------------
+    @classmethod
+    def from_numpy(cls, arr, dtype=None, stream=None):
+        arr = np.ascontiguousarray(arr if dtype is None else np.asarray(arr).astype(dtype, copy=False))
+        out = cls(arr.shape, arr.dtype)
+        if arr.nbytes:
+            _lib.call("xrs_memcpy_h2d", out.ptr, arr.ctypes.data, arr.nbytes, stream)
+            _lib.call("xrs_stream_sync", stream)      # `arr` may be a temporary
+        return out
+
+    @classmethod
+    def empty(cls, shape, dtype=np.float32):
+        return cls(shape, dtype)
+
+    # -- duck-array surface ---------------------------------------------------
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def get(self, stream=None) -> np.ndarray:
+        """Copy to a new NumPy array (cupy's spelling)."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            _lib.call("xrs_memcpy_d2h", out.ctypes.data, self.ptr, out.nbytes, stream)
+            _lib.call("xrs_stream_sync", stream)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
+
+    def rows(self, start, stop):
+        """View of rows [start, stop) (first axis), sharing this buffer."""
+        row_bytes = self.nbytes // self.shape[0] if self.shape[0] else 0
+        return DeviceArray((stop - start,) + self.shape[1:], self.dtype,
+                           _ptr=self.ptr + start * row_bytes, _base=self)
+
+    def astype(self, dtype):
+        if np.dtype(dtype) == self.dtype:
+            return self
+        return DeviceArray.from_numpy(self.get().astype(dtype))
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr:x})"
+
+    # xarray treats objects with these hooks as duck arrays and leaves them wrapped
+    def __array_function__(self, func, types, args, kwargs):
+        return NotImplemented
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return NotImplemented
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owns", False) and self.ptr:
+                _raw_free(self.ptr, self.nbytes)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def is_device_array(x) -> bool:
+    return isinstance(x, DeviceArray)
+
+
+def to_device_f32(data) -> DeviceArray:
+    """`data.astype(np.float32)` of the reference runners, landing in HBM."""
+    if isinstance(data, DeviceArray):
+        return data.astype(np.float32)
+    return DeviceArray.from_numpy(np.asarray(data), dtype=np.float32)
+
+
+def synchronize():
+    _lib.call("xrs_device_sync")

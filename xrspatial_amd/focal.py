@@ -1,0 +1,166 @@
+"""Focal statistics.  Reference: xrspatial/focal.py (mean :162-265, apply :343-473,
+focal_stats :800-878).  `hotspots` is not part of this backend yet."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._launch import finish, get_stream, plane_args
+from ._xr import DataArray
+from .convolution import _kernel_f64, custom_kernel
+from .dataset_support import supports_dataset
+from .device import DeviceArray, to_device_f32
+from .utils import ArrayTypeFunctionMapping
+
+# order of the XRS_STAT_* enum in include/xrs_hip.h
+_STAT_INDEX = {'mean': 0, 'max': 1, 'min': 2, 'range': 3, 'std': 4, 'var': 5, 'sum': 6}
+
+
+class _BuiltinReducer:
+    """Stands in for the reference's `@ngjit _calc_*` functions (focal.py:268-302).
+
+    `apply(raster, kernel, func=_calc_sum)` upstream takes a Numba-compiled callable; a GPU
+    backend can only run the built-in reducers, so they are exported under the same names
+    as tokens that `apply` recognises.  Any other callable raises NotImplementedError
+    (the reference's own cupy slot does the same, focal.py:461-465)."""
+
+    def __init__(self, stat):
+        self.stat = stat
+
+    def __repr__(self):
+        return f"<built-in focal reducer '{self.stat}'>"
+
+
+_calc_mean = _BuiltinReducer('mean')
+_calc_sum = _BuiltinReducer('sum')
+_calc_min = _BuiltinReducer('min')
+_calc_max = _BuiltinReducer('max')
+_calc_std = _BuiltinReducer('std')
+_calc_range = _BuiltinReducer('range')
+_calc_var = _BuiltinReducer('var')
+
+
+def _focal_stats_hip(data, kernel, stats, stacked=None):
+    """One pass over `data`, all requested statistics; returns {stat: array}.
+
+    `stacked`: optional (len(stats), rows, cols) DeviceArray whose planes receive the results."""
+    _lib.require_device()
+    like_numpy = not isinstance(data, DeviceArray)
+    k = _kernel_f64(kernel)
+    src = to_device_f32(data)
+    rows, cols, ld = plane_args(src)
+    if stacked is not None:
+        outs = {s: DeviceArray((rows, cols), np.float32, _ptr=stacked.ptr + i * rows * cols * 4, _base=stacked)
+                for i, s in enumerate(stats)}
+    else:
+        outs = {s: DeviceArray((rows, cols), np.float32) for s in dict.fromkeys(stats)}
+    ptrs = (ctypes.c_void_p * 7)()
+    mask = 0
+    for s, arr in outs.items():
+        ptrs[_STAT_INDEX[s]] = arr.ptr
+        mask |= 1 << _STAT_INDEX[s]
+    stream = get_stream()
+    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, ld, ld, k.ctypes.data,
+              k.shape[0], k.shape[1], None, 0, 0, stream)
+    if like_numpy:
+        return {s: arr.get(stream) for s, arr in outs.items()}
+    return outs
+
+
+def _mean_hip(data, excludes, passes):
+    # replaces the passes loop over _mean_numpy (focal.py:44-67, 257-259); float64 result
+    _lib.require_device()
+    like_numpy = not isinstance(data, DeviceArray)
+    if isinstance(data, DeviceArray):
+        cur = data if data.dtype in (np.float32, np.float64) else data.astype(np.float64)
+    else:
+        host = np.asarray(data)
+        # float32 rasters are widened on the fly by the first pass; everything else is cast like
+        # the reference's `.astype(float)`
+        cur = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+    rows, cols = cur.shape
+    ex = np.asarray(list(excludes), dtype=np.float64)
+    stream = get_stream()
+    if passes <= 0:
+        out = DeviceArray.from_numpy(cur.get().astype(np.float64))
+    for _ in range(int(passes)):
+        out = DeviceArray((rows, cols), np.float64)
+        _lib.call("xrs_focal_mean3x3", cur.ptr, int(cur.dtype == np.float64), out.ptr, rows, cols, cols, cols,
+                  ex.ctypes.data, len(ex), 0, 0, stream)
+        cur = out
+    return finish(out, like_numpy)
+
+
+@supports_dataset
+def mean(agg, passes=1, excludes=[np.nan], name='mean'):
+    """3x3 NaN-skipping moving average, `passes` times; cells equal to a value in `excludes`
+    are passed through.  Same signature and results (float64) as `xrspatial.focal.mean`."""
+    if len(agg.shape) != 2:
+        raise ValueError("`agg` must be 2D")
+    if len(excludes) > 8:
+        raise ValueError("at most 8 exclude values are supported by the MI355X backend")
+    mapper = ArrayTypeFunctionMapping(numpy_func=_mean_hip, hip_func=_mean_hip)
+    out = mapper(agg)(agg.data, tuple(excludes), passes)
+    return DataArray(out, name=name, dims=agg.dims, coords=agg.coords, attrs=agg.attrs)
+
+
+def _reducer_name(func):
+    if isinstance(func, _BuiltinReducer):
+        return func.stat
+    if isinstance(func, str) and func in _STAT_INDEX:
+        return func
+    raise NotImplementedError(
+        "apply() on the MI355X backend supports the built-in reducers "
+        "(_calc_mean/_calc_sum/_calc_min/_calc_max/_calc_std/_calc_var/_calc_range); "
+        f"got {func!r}")
+
+
+def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
+    """Reduce the cells under `kernel == 1` around every cell with `func` (default: mean).
+
+    Same signature as `xrspatial.focal.apply`; window clipped at the raster edge, NaN
+    cells skipped, float32 result."""
+    if not isinstance(raster, DataArray):
+        raise TypeError("`raster` must be instance of DataArray")
+    if raster.ndim != 2:
+        raise ValueError("`raster` must be 2D")
+    kernel = custom_kernel(kernel)
+    stat = _reducer_name(func)
+
+    def run(data, kernel, stat):
+        return _focal_stats_hip(data, kernel, [stat])[stat]
+
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    out = mapper(raster)(raster.data, kernel, stat)
+    return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
+
+
+def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 'var', 'sum']):
+    """All requested focal statistics as a 3-D (stats, y, x) float32 DataArray.
+
+    Same signature and results as `xrspatial.focal.focal_stats`; the reference makes one
+    full pass per statistic, this backend computes them in a single pass over the raster."""
+    if not isinstance(agg, DataArray):
+        raise TypeError("`agg` must be instance of DataArray")
+    if agg.ndim != 2:
+        raise ValueError("`agg` must be 2D")
+    kernel = custom_kernel(kernel)
+    stats_funcs = list(stats_funcs)
+    for s in stats_funcs:
+        if s not in _STAT_INDEX:
+            raise KeyError(s)
+    if not isinstance(agg.data, (np.ndarray, DeviceArray)):
+        raise TypeError("Unsupported Array Type: {}".format(type(agg)))
+    if isinstance(agg.data, np.ndarray):
+        planes = _focal_stats_hip(agg.data, kernel, stats_funcs)
+        stacked = np.stack([planes[s] for s in stats_funcs])
+    else:
+        if len(set(stats_funcs)) != len(stats_funcs):
+            raise ValueError("duplicate statistics requested")
+        stacked = DeviceArray((len(stats_funcs),) + tuple(agg.shape), np.float32)
+        _focal_stats_hip(agg.data, kernel, stats_funcs, stacked=stacked)
+    coords = dict(agg.coords.items())
+    coords['stats'] = np.array(stats_funcs, dtype=object)
+    return DataArray(stacked, dims=('stats',) + tuple(agg.dims), coords=coords, attrs=agg.attrs)

@@ -1,0 +1,62 @@
+"""xrspatial.hillshade drop-in.  Reference: xrspatial/hillshade.py:103-208."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._launch import finish, get_stream, plane_args
+from ._xr import DataArray
+from .dataset_support import supports_dataset
+from .device import DeviceArray, to_device_f32
+
+# The reference's NumPy runner returns float64 under NumPy >= 2 (its final combine is
+# promoted by a np.float64 scalar) and float32 under NumPy 1.x; its CuPy
+# runner returns float32.  Mirror both: numpy in -> what NumPy would give, device in -> f32.
+_NUMPY_RESULT_DTYPE = np.float64 if int(np.__version__.split('.')[0]) >= 2 else np.float32
+
+
+def _run_numpy(data, azimuth, angle_altitude):
+    return _hill(data, _NUMPY_RESULT_DTYPE, azimuth, angle_altitude)
+
+
+def _run_hip(data, azimuth, angle_altitude):
+    return _hill(data, np.float32, azimuth, angle_altitude)
+
+
+def _hill(data, out_dtype, azimuth, angle_altitude):
+    # replaces _run_numpy (hillshade.py:20-35); the entry point has an `out_f64` flag after `out`
+    _lib.require_device()
+    like_numpy = not isinstance(data, DeviceArray)
+    if len(data.shape) != 2:
+        raise ValueError("expected a 2D raster")
+    src = to_device_f32(data)
+    rows, cols, ld = plane_args(src)
+    out = DeviceArray((rows, cols), out_dtype)
+    _lib.call("xrs_hillshade_f32", src.ptr, out.ptr, int(np.dtype(out_dtype) == np.float64), rows, cols,
+              ld, ld, float(azimuth), float(angle_altitude), 0, 0, get_stream())
+    return finish(out, like_numpy)
+
+
+@supports_dataset
+def hillshade(agg: DataArray,
+              azimuth: int = 225,
+              angle_altitude: int = 25,
+              name: Optional[str] = 'hillshade',
+              shadows: bool = False) -> DataArray:
+    """Illumination of every cell for a light at `azimuth` / `angle_altitude` (degrees), in [0, 1].
+
+    Same signature and results as `xrspatial.hillshade`; runs on the MI355X.
+    `shadows=True` needs the reference's OptiX ray tracer (NVIDIA RT cores) and
+    raises RuntimeError here exactly as upstream does without rtxpy.
+    """
+    if shadows:
+        raise RuntimeError("Can only calculate shadows if cupy and rtxpy are available")
+    if isinstance(agg.data, np.ndarray):
+        out = _run_numpy(agg.data, azimuth, angle_altitude)
+    elif isinstance(agg.data, DeviceArray):
+        out = _run_hip(agg.data, azimuth, angle_altitude)
+    else:
+        raise TypeError('Unsupported Array Type: {}'.format(type(agg.data)))
+    return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

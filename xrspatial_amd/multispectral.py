@@ -1,0 +1,102 @@
+"""Per-cell multispectral indices: ndvi, evi, savi (and the other normalized-ratio
+indices that share ndvi's kernel: nbr, nbr2, ndmi).  Reference: xrspatial/multispectral.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._launch import finish, get_stream
+from ._xr import DataArray
+from .dataset_support import supports_dataset_bands
+from .device import DeviceArray, to_device_f32
+from .utils import ArrayTypeFunctionMapping, validate_arrays
+
+
+def _percell(fn_name, bands, extra):
+    """bands: tuple of same-shape arrays -> float32 result of the same shape."""
+    _lib.require_device()
+    like_numpy = not isinstance(bands[0], DeviceArray)
+    dev = [to_device_f32(b) for b in bands]           # `.astype('f4')` of the reference wrappers
+    out = DeviceArray(dev[0].shape, np.float32)
+    _lib.call(fn_name, *[d.ptr for d in dev], out.ptr, out.size, *extra, get_stream())
+    return finish(out, like_numpy)
+
+
+def _normalized_ratio(arr1, arr2):
+    # replaces _normalized_ratio_cpu (multispectral.py:825-841)
+    return _percell("xrs_normalized_ratio_f32", (arr1, arr2), ())
+
+
+def _wrap(out, name, like):
+    return DataArray(out, name=name, coords=like.coords, dims=like.dims, attrs=like.attrs)
+
+
+def _nr_index(band1, band2, name):
+    validate_arrays(band1, band2)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_normalized_ratio, hip_func=_normalized_ratio)
+    return _wrap(mapper(band1)(band1.data, band2.data), name, band1)
+
+
+@supports_dataset_bands(nir='nir_agg', red='red_agg')
+def ndvi(nir_agg, red_agg, name='ndvi'):
+    """Normalized Difference Vegetation Index (nir - red) / (nir + red); NaN where nir + red == 0.
+    Same signature and float32 results as `xrspatial.multispectral.ndvi` (:653-733)."""
+    return _nr_index(nir_agg, red_agg, name)
+
+
+@supports_dataset_bands(nir='nir_agg', swir2='swir2_agg')
+def nbr(nir_agg, swir2_agg, name='nbr'):
+    """Normalized Burn Ratio (nir - swir2) / (nir + swir2)  (multispectral.py:476-560)."""
+    return _nr_index(nir_agg, swir2_agg, name)
+
+
+@supports_dataset_bands(swir1='swir1_agg', swir2='swir2_agg')
+def nbr2(swir1_agg, swir2_agg, name='nbr2'):
+    """Normalized Burn Ratio 2 (swir1 - swir2) / (swir1 + swir2)  (multispectral.py:563-650)."""
+    return _nr_index(swir1_agg, swir2_agg, name)
+
+
+@supports_dataset_bands(nir='nir_agg', swir1='swir1_agg')
+def ndmi(nir_agg, swir1_agg, name='ndmi'):
+    """Normalized Difference Moisture Index (nir - swir1) / (nir + swir1)  (multispectral.py:737-823)."""
+    return _nr_index(nir_agg, swir1_agg, name)
+
+
+@supports_dataset_bands(nir='nir_agg', red='red_agg', blue='blue_agg')
+def evi(nir_agg, red_agg, blue_agg, c1=6.0, c2=7.5, soil_factor=1.0, gain=2.5, name='evi'):
+    """Enhanced Vegetation Index gain * (nir - red) / (nir + c1*red - c2*blue + soil_factor).
+    Same signature, validation and float32 results as `xrspatial.multispectral.evi` (:226-346)."""
+    if not red_agg.shape == nir_agg.shape == blue_agg.shape:
+        raise ValueError("input layers expected to have equal shapes")
+    if not isinstance(c1, (float, int)):
+        raise ValueError("c1 must be numeric")
+    if not isinstance(c2, (float, int)):
+        raise ValueError("c2 must be numeric")
+    if soil_factor > 1.0 or soil_factor < -1.0:
+        raise ValueError("soil factor must be between [-1.0, 1.0]")
+    if gain < 0:
+        raise ValueError("gain must be greater than 0")
+    validate_arrays(nir_agg, red_agg, blue_agg)
+
+    def run(nir, red, blue):   # replaces _evi_cpu (multispectral.py:175-188)
+        return _percell("xrs_evi_f32", (nir, red, blue),
+                        (float(c1), float(c2), float(soil_factor), float(gain)))
+
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data, blue_agg.data), name, nir_agg)
+
+
+@supports_dataset_bands(nir='nir_agg', red='red_agg')
+def savi(nir_agg, red_agg, soil_factor=1.0, name='savi'):
+    """Soil Adjusted Vegetation Index (nir - red) / ((nir + red + L) * (1 + L)).
+    Same signature, validation and float32 results as `xrspatial.multispectral.savi` (:927-1013)."""
+    validate_arrays(red_agg, nir_agg)
+    if not -1.0 <= soil_factor <= 1.0:
+        raise ValueError("soil factor must be between [-1.0, 1.0]")
+
+    def run(nir, red):         # replaces _savi_cpu (multispectral.py:876-890)
+        return _percell("xrs_savi_f32", (nir, red), (float(soil_factor),))
+
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data), name, nir_agg)

@@ -1,0 +1,37 @@
+"""xrspatial.slope drop-in (planar method).  Reference: xrspatial/slope.py:271-371."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from ._launch import stencil
+from ._xr import DataArray
+from .dataset_support import supports_dataset
+from .utils import ArrayTypeFunctionMapping, get_dataarray_resolution
+
+
+def _run(data, cellsize_x, cellsize_y):
+    # replaces _run_numpy/_cpu (slope.py:56-83): float32 cast, float64 Horn sums, NaN border
+    return stencil("xrs_slope_f32", data, np.float32, (float(cellsize_x), float(cellsize_y)))
+
+
+@supports_dataset
+def slope(agg: DataArray,
+          name: Optional[str] = 'slope',
+          method: str = 'planar',
+          z_unit: str = 'meter') -> DataArray:
+    """Slope (degrees) of every cell from its 3x3 neighbourhood.
+
+    Same signature and results as `xrspatial.slope` (planar Horn method,
+    cell size from `attrs['res']` or the coordinates); runs on the MI355X.
+    `method='geodesic'` is not part of this backend yet.
+    """
+    if method not in ('planar', 'geodesic'):
+        raise ValueError(f"method must be 'planar' or 'geodesic', got {method!r}")
+    if method == 'geodesic':
+        raise NotImplementedError("geodesic slope is not implemented by the MI355X backend yet")
+    cellsize_x, cellsize_y = get_dataarray_resolution(agg)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
+    out = mapper(agg)(agg.data, cellsize_x, cellsize_y)
+    return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

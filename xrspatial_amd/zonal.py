@@ -1,0 +1,194 @@
+"""zonal.stats drop-in.  Reference: xrspatial/zonal.py:422-667 (`stats`), NumPy backend :280-332.
+
+The reference sorts the whole raster twice (np.unique + np.argsort) and then loops over zones
+in Python.  Here the host only maps zone ids to dense indices; ONE streaming pass on the
+MI355X produces per-zone count / sum / sum-of-squares / min / max (the per-block partials of the
+reference's own dask path, zonal.py:83-102), from which mean / std / var follow.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+from ._launch import get_stream
+from ._xr import DataArray, Dataset
+from .device import DeviceArray
+from .utils import validate_arrays
+
+_DEVICE_STATS = ('mean', 'max', 'min', 'sum', 'std', 'var', 'count')
+_DEFAULT_STATS = _DEVICE_STATS + ('majority',)
+_DENSE_RANGE_LIMIT = 1 << 26
+
+
+def _dense_zone_index(zones: np.ndarray):
+    """unique finite zone ids (ascending, zones dtype) and an int32 dense index per cell (-1: no zone).
+
+    Same set the reference obtains with np.unique(zones[np.isfinite(zones)]) (zonal.py:290),
+    but integral ids in a bounded range are mapped with O(N) table lookups instead of a sort.
+    """
+    flat = zones.ravel()
+    if np.issubdtype(flat.dtype, np.floating):
+        finite = np.isfinite(flat)
+        vals = flat[finite]
+    else:
+        finite = None
+        vals = flat
+    idx = np.full(flat.shape, -1, dtype=np.int32)
+    if vals.size == 0:
+        return flat[:0].copy(), idx.reshape(zones.shape)
+    lo, hi = vals.min(), vals.max()
+    integral = np.issubdtype(vals.dtype, np.integer) or bool(np.all(vals == np.floor(vals)))
+    if integral and float(hi) - float(lo) < _DENSE_RANGE_LIMIT:
+        off = vals.astype(np.int64) - np.int64(lo)
+        present = np.zeros(int(np.int64(hi) - np.int64(lo)) + 1, dtype=bool)
+        present[off] = True
+        lut = np.cumsum(present, dtype=np.int64).astype(np.int32) - 1
+        uniq = (np.flatnonzero(present) + np.int64(lo)).astype(flat.dtype)
+        dense = lut[off]
+    else:
+        uniq, inv = np.unique(vals, return_inverse=True)
+        dense = inv.astype(np.int32)
+    if finite is None:
+        idx = dense.astype(np.int32, copy=False)
+    else:
+        idx[finite] = dense
+    return uniq, idx.reshape(zones.shape)
+
+
+def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
+    """Per-zone (count, sum, sumsq, min, max) NumPy arrays for dense `zone_idx` (device or host arrays).
+
+    `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
+    all-reduced over it so every rank returns the global result."""
+    _lib.require_device()
+    stream = get_stream()
+    zdev = zone_idx if isinstance(zone_idx, DeviceArray) else DeviceArray.from_numpy(
+        np.ascontiguousarray(zone_idx, dtype=np.int32))
+    if isinstance(values, DeviceArray):
+        vdev = values if values.dtype in (np.float32, np.float64) else values.astype(np.float64)
+    else:
+        host = np.asarray(values)
+        vdev = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+    f64 = vdev.dtype == np.float64
+    vt = np.float64 if f64 else np.float32
+    cnt = DeviceArray((n_zones,), np.uint64)
+    s1 = DeviceArray((n_zones,), np.float64)
+    s2 = DeviceArray((n_zones,), np.float64)
+    mn = DeviceArray((n_zones,), vt)
+    mx = DeviceArray((n_zones,), vt)
+    sfx = "_f64" if f64 else ""
+    _lib.call("xrs_zonal_init" + sfx, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, n_zones, stream)
+    has_nodata = nodata_values is not None
+    nodata = float(nodata_values) if has_nodata else 0.0
+    _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
+              n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
+    if comm is not None:
+        _lib.call("xrs_zonal_allreduce", comm.handle, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, int(f64),
+                  n_zones, stream)
+    return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream)
+
+
+def finalize_stats(stat_names, count, s1, s2, mn, mx):
+    """Per-zone statistics from the partials (formulas of zonal.py:100-102); zones without a valid
+    cell are NaN in every column, count included (zonal.py:153-161 pre-fills NaN)."""
+    n = count.astype(np.float64)
+    empty = count == 0
+    with np.errstate(all="ignore"):
+        mean = s1 / n
+        var = (s2 - s1 * s1 / n) / n
+        var = np.where(var < 0, 0.0, var)         # rounding guard; the exact value is >= 0
+    table = {'mean': mean, 'max': mx.astype(np.float64), 'min': mn.astype(np.float64), 'sum': s1,
+             'std': np.sqrt(var), 'var': var, 'count': n}
+    out = {}
+    for name in stat_names:
+        col = np.array(table[name], dtype=np.float64)
+        col[empty] = np.nan
+        out[name] = col
+    return out
+
+
+def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, comm=None):
+    zones_host = zones_data.get() if isinstance(zones_data, DeviceArray) else np.asarray(zones_data)
+    unique_zones, idx = _dense_zone_index(zones_host)
+    if zone_ids is None:
+        selected = unique_zones
+    else:
+        wanted = np.unique(zone_ids)
+        selected = [z for z in wanted if z in unique_zones]
+    count, s1, s2, mn, mx = zonal_partials(idx, values_data, len(unique_zones), nodata_values, comm)
+    cols = finalize_stats(stat_names, count, s1, s2, mn, mx)
+    keep = [i for i, z in enumerate(unique_zones) if z in selected]
+    frame = {'zone': selected}
+    for name in stat_names:
+        frame[name] = cols[name][keep]
+    return pd.DataFrame(frame)
+
+
+def stats(
+    zones,
+    values,
+    zone_ids: Optional[List[Union[int, float]]] = None,
+    stats_funcs: Union[Dict, List] = [
+        "mean",
+        "max",
+        "min",
+        "sum",
+        "std",
+        "var",
+        "count",
+        "majority",
+    ],
+    nodata_values: Union[int, float] = None,
+    return_type: str = 'pandas.DataFrame',
+):
+    """Summary statistics of `values` for every zone of `zones`.
+
+    Same signature as `xrspatial.zonal.stats`.  Supported on the MI355X backend: the seven
+    partial-sum statistics mean / max / min / sum / std / var / count, `zone_ids`,
+    `nodata_values`, Dataset `values`, `return_type='pandas.DataFrame'`.  `majority`, custom
+    callables and `return_type='xarray.DataArray'` need per-zone histograms / a back-projection
+    pass and raise NotImplementedError in this release -- when
+    `stats_funcs` is left at its default, `majority` is dropped with the other seven computed,
+    which is exactly what the reference's dask backend does (zonal.py:219-222)."""
+    if isinstance(values, Dataset):
+        if return_type != 'pandas.DataFrame':
+            raise ValueError("return_type must be 'pandas.DataFrame' when values is a Dataset")
+        dfs = []
+        for var_name in values.data_vars:
+            df = stats(zones, values[var_name], zone_ids, stats_funcs, nodata_values, 'pandas.DataFrame')
+            df = df.rename(columns={c: f'{var_name}_{c}' for c in df.columns if c != 'zone'})
+            dfs.append(df)
+        result = dfs[0]
+        for df in dfs[1:]:
+            result = result.merge(df, on='zone', how='outer')
+        return result
+
+    validate_arrays(zones, values)
+    if not (issubclass(zones.data.dtype.type, np.integer) or issubclass(zones.data.dtype.type, np.floating)):
+        raise ValueError("`zones` must be an array of integers or floats.")
+    if not (issubclass(values.data.dtype.type, np.integer) or issubclass(values.data.dtype.type, np.floating)):
+        raise ValueError("`values` must be an array of integers or floats.")
+    if len(values.shape) != 2:
+        raise ValueError("`values` must be 2D (pass a Dataset for several layers)")
+
+    if isinstance(stats_funcs, dict):
+        raise NotImplementedError(
+            "custom stats callables cannot run on the MI355X backend; pass a list of names from "
+            f"{list(_DEVICE_STATS)}")
+    names = list(stats_funcs)
+    for name in names:
+        if name not in _DEFAULT_STATS:
+            raise ValueError(f"Invalid stat name. {name} option not supported.")
+    if 'majority' in names:
+        if names == list(_DEFAULT_STATS):
+            names = list(_DEVICE_STATS)
+        else:
+            raise NotImplementedError("'majority' is not implemented on the MI355X backend yet")
+    if return_type != 'pandas.DataFrame':
+        raise NotImplementedError("return_type='xarray.DataArray' is not implemented on the MI355X backend yet")
+    if not isinstance(values.data, (np.ndarray, DeviceArray)):
+        raise TypeError("Unsupported Array Type: {}".format(type(values)))
+    return _stats_hip(zones.data, values.data, zone_ids, names, nodata_values)

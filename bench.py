@@ -1,0 +1,247 @@
+"""Headline benchmark: Mcells/s for hillshade + focal mean (5x5 circle) on a float32 DEM resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one raster: `hillshade(dem)` followed by the 5x5
+circular focal mean `focal.apply(dem, circle_kernel(1, 1, 2))` (BASELINE.json `metric`:
+"hillshade+focal.mean on 16k^2 f32 DEM"; SURVEY.md fact 4 maps "focal.mean(5x5)" onto focal.apply).
+Both go through the C ABI of libxrs_hip.so on this process's HIP stream.  Inputs are staged in HBM
+before the timed region.
+
+N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+one process per GPU, weak scaling -- every rank owns a 16384 x 16384 row-shard of a
+(16384*N) x 16384 raster; each step starts with ONE RCCL halo exchange (2 rows each way over xGMI,
+enough for both operators) and then runs the same two kernels with halo_top/halo_bot set.
+torch.distributed (gloo) is used only for rendezvous, the barriers and the max-over-ranks of the
+elapsed time; no tensor ever touches the GPU through torch.
+
+Prints ONE JSON line (rank 0): metric/value in Mcells/s (raster cells through the whole step, all
+ranks), `roofline` for the dominant kernel (HIP-event time on the launch stream, algorithmic
+8 B/cell), `cpu_baseline` = the CPU oracle timed on this box on a bounded band of the same raster.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 16384
+COLS = 16384
+HALO = 2                      # 5x5 focal window; hillshade needs 1 of them
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+ALG_BYTES_PER_CELL = 8        # 4 B read + 4 B written per cell, either kernel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ.setdefault("XRS_DEVICE", str(local_rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    # Load the HIP library (and with it /opt/rocm's runtime) BEFORE torch is imported.
+    if not os.path.exists(os.path.join(ROOT, "xrspatial_amd", "libxrs_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    import xrspatial_amd as xs
+    from tests import synth
+    from xrspatial_amd import _lib
+    from xrspatial_amd.convolution import circle_kernel
+    _lib.require_device()
+    L = _lib.call
+
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from xrspatial_amd.distributed import Comm
+        comm = Comm.from_torch_distributed(dist)
+
+    rows, cols = args.rows, args.cols
+    total_rows = rows * world
+    y_begin = rank * rows
+    ht = HALO if rank > 0 else 0
+    hb = HALO if rank < world - 1 else 0
+
+    stream = ctypes.c_void_p()
+    L("xrs_stream_create", ctypes.byref(stream))
+
+    # shard buffer = HALO spare rows + owned rows + HALO spare rows; the owned part starts at `dem`
+    buf = xs.DeviceArray((rows + 2 * HALO, cols), np.float32)
+    dem_ptr = buf.ptr + HALO * cols * 4
+    band = 2048
+    for y0 in range(0, rows, band):
+        n = min(band, rows - y0)
+        host = synth.asv_dem(n, cols, y0=y_begin + y0, total_rows=total_rows)
+        L("xrs_memcpy_h2d", dem_ptr + y0 * cols * 4, host.ctypes.data, host.nbytes, stream)
+        L("xrs_stream_sync", stream)
+    out_hill = xs.DeviceArray((rows, cols), np.float32)
+    out_focal = xs.DeviceArray((rows, cols), np.float32)
+    kernel = np.ascontiguousarray(circle_kernel(1, 1, 2), dtype=np.float64)
+    kr, kc = kernel.shape
+    outs = (ctypes.c_void_p * 7)()
+    outs[0] = out_focal.ptr
+
+    def make_event():
+        e = ctypes.c_void_p()
+        L("xrs_event_create", ctypes.byref(e))
+        return e
+
+    def step(events=None):
+        if comm is not None:
+            L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, stream)
+        if events:
+            L("xrs_event_record", events[0], stream)
+        L("xrs_hillshade_f32", dem_ptr, out_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0,
+          min(ht, 1), min(hb, 1), stream)
+        if events:
+            L("xrs_event_record", events[1], stream)
+        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc, None,
+          ht, hb, stream)
+        if events:
+            L("xrs_event_record", events[2], stream)
+
+    def fence():
+        L("xrs_stream_sync", stream)
+        L("xrs_device_sync")
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[make_event() for _ in range(3)] for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    L("xrs_stream_sync", stream)
+    L("xrs_device_sync")
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
+    ms = ctypes.c_float()
+    hill_ms, focal_ms = [], []
+    for e in events:
+        L("xrs_event_elapsed_ms", e[0], e[1], ctypes.byref(ms))
+        hill_ms.append(ms.value)
+        L("xrs_event_elapsed_ms", e[1], e[2], ctypes.byref(ms))
+        focal_ms.append(ms.value)
+    hill_avg, focal_avg = float(np.mean(hill_ms)), float(np.mean(focal_ms))
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    cells_rank = rows * cols
+    ms_per_step = elapsed / args.steps * 1e3
+    value = cells_rank * world / (elapsed / args.steps) / 1e6
+    dom_name, dom_ms = ("focal_stats_kernel<5,5,mean>", focal_avg) if focal_avg >= hill_avg else \
+        ("terrain_strip_kernel<hillshade>", hill_avg)
+    achieved = ALG_BYTES_PER_CELL * cells_rank / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):              # HBM bytes/launch from a separate rocprofv3 --pmc run (see profiles/README.md)
+        try:
+            traffic = json.load(open(tfile)).get(dom_name.split("<")[0])
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "Mcells/s for hillshade+focal.mean(5x5) on 16k^2 f32 DEM",
+        "value": round(value, 1),
+        "unit": "Mcells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"hillshade + focal.apply(mean, circle_kernel r=2 -> 5x5/13 taps) on a "
+                        f"{rows}x{cols} float32 DEM per GPU (BASELINE configs[1]/[2] raster), HBM-resident",
+            "rows_per_gpu": rows, "cols": cols, "global_rows": total_rows,
+            "sharding": "rows" if world > 1 else "none",
+            "halo_exchange": f"RCCL send/recv, {HALO} rows per neighbour per step" if world > 1 else None,
+            "kernel_ms": {"hillshade": round(hill_avg, 4), "focal_mean_5x5": round(focal_avg, 4)},
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dom_name,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL * cells_rank,
+            "launch_ms": round(dom_ms, 4),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cols, kernel)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cols, kernel):
+    """The CPU oracle (a port of the reference's CPU path) timed on this box, 1 core -- the reference's
+    Numba kernels are single-threaded (xrspatial/utils.py:31) -- on a bounded band of the same DEM."""
+    from oracle import c_oracle as corc
+    from oracle import xrs_oracle as orc
+    from tests import synth
+    band_rows = 1024
+    dem = synth.asv_dem(band_rows, cols, y0=0, total_rows=ROWS_PER_GPU)
+    corc.build()
+    corc.focal_apply(dem[:8], kernel, 'mean')          # load the library outside the timed region
+    t0 = time.perf_counter()
+    orc.hillshade(dem)                                 # the reference's hillshade IS this NumPy code
+    t1 = time.perf_counter()
+    corc.focal_apply(dem, kernel, 'mean', nthreads=1)  # Numba-like scalar loop
+    t2 = time.perf_counter()
+    cells = band_rows * cols
+    return {
+        "value": round(cells / (t2 - t0) / 1e6, 2),
+        "unit": "Mcells/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"rows 0..{band_rows - 1} of the {ROWS_PER_GPU}x{cols} DEM ({cells / 1e6:.1f} Mcells): "
+                  f"hillshade via the NumPy restatement ({t1 - t0:.2f} s) + focal mean 5x5 via the C port "
+                  f"({t2 - t1:.2f} s)",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -222,24 +222,29 @@ def cpu_baseline(cols, kernel):
     from oracle import c_oracle as corc
     from oracle import xrs_oracle as orc
     from tests import synth
-    band_rows = 1024
-    dem = synth.asv_dem(band_rows, cols, y0=0, total_rows=ROWS_PER_GPU)
+    chunk, n_chunks = 1024, 16          # the whole 16384-row raster in 1024-row bands (~10-20 s of CPU)
     corc.build()
-    corc.focal_apply(dem[:8], kernel, 'mean')          # load the library outside the timed region
-    t0 = time.perf_counter()
-    orc.hillshade(dem)                                 # the reference's hillshade IS this NumPy code
-    t1 = time.perf_counter()
-    corc.focal_apply(dem, kernel, 'mean', nthreads=1)  # Numba-like scalar loop
-    t2 = time.perf_counter()
-    cells = band_rows * cols
+    corc.focal_apply(np.zeros((8, 8), np.float32), kernel, 'mean')     # load the library outside the timed region
+    t_hill = t_focal = 0.0
+    cells = 0
+    for c in range(n_chunks):
+        dem = synth.asv_dem(chunk, cols, y0=c * chunk, total_rows=ROWS_PER_GPU)
+        t0 = time.perf_counter()
+        orc.hillshade(dem)                                 # the reference's hillshade IS this NumPy code
+        t1 = time.perf_counter()
+        corc.focal_apply(dem, kernel, 'mean', nthreads=1)  # Numba-like scalar loop
+        t2 = time.perf_counter()
+        t_hill += t1 - t0
+        t_focal += t2 - t1
+        cells += dem.size
     return {
-        "value": round(cells / (t2 - t0) / 1e6, 2),
+        "value": round(cells / (t_hill + t_focal) / 1e6, 2),
         "unit": "Mcells/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"rows 0..{band_rows - 1} of the {ROWS_PER_GPU}x{cols} DEM ({cells / 1e6:.1f} Mcells): "
-                  f"hillshade via the NumPy restatement ({t1 - t0:.2f} s) + focal mean 5x5 via the C port "
-                  f"({t2 - t1:.2f} s)",
+        "sample": f"the {ROWS_PER_GPU}x{cols} DEM in {n_chunks} bands of {chunk} rows ({cells / 1e6:.0f} Mcells): "
+                  f"hillshade via the NumPy restatement ({t_hill:.1f} s) + focal mean 5x5 via the C port "
+                  f"({t_focal:.1f} s), one thread (the reference's Numba kernels are single-threaded)",
     }
 
 

@@ -20,11 +20,18 @@ from xrspatial_amd import _lib  # noqa: E402
 from xrspatial_amd.convolution import circle_kernel  # noqa: E402
 
 
+FAST_INPUTS = False   # --fast-inputs: stage ONE generated band and repeat it (profiling runs; same bytes moved)
+
+
 def device_raster(rows, cols, maker, band=2048):
     out = xs.DeviceArray((rows, cols), np.float32)
+    cache = None
     for y0 in range(0, rows, band):
         n = min(band, rows - y0)
-        host = maker(n, cols, y0)
+        if FAST_INPUTS and cache is not None and cache.shape[0] == n:
+            host = cache
+        else:
+            host = cache = maker(n, cols, y0)
         _lib.call("xrs_memcpy_h2d", out.ptr + y0 * cols * 4, host.ctypes.data, host.nbytes, None)
         _lib.call("xrs_stream_sync", None)
     return out
@@ -58,7 +65,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
+    ap.add_argument("--fast-inputs", action="store_true")
     args = ap.parse_args()
+    global FAST_INPUTS
+    FAST_INPUTS = args.fast_inputs
     _lib.require_device()
     n = args.size
     cells = n * n

@@ -19,13 +19,15 @@
 #include "xrs_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace xrs;
 
 namespace {
 
 constexpr int TW = 256;          // output tile width = 64 lanes x 4 columns
-constexpr int MAX_K = 61;        // one uint64 bit-row per kernel row (plus a <= 3 bit alignment shift)
+constexpr int TH_FAST = 16;      // output tile height of the compile-time-shape kernels (4 rows per wave)
+constexpr int MAX_K = 63;        // one uint64 bit-row per kernel row
 
 struct KxkArgs {
     const float *in;
@@ -34,41 +36,76 @@ struct KxkArgs {
     int halo_top, halo_bot;
     int krows, kcols;             // runtime sizes (also valid for the compile-time variants)
     int th;                       // output rows per tile (multiple of 4)
-    int lpad, lw;                 // LDS: columns left of the tile, LDS row pitch (floats)
+    int lpad;                     // roundup4(kcols/2): 16-byte aligned global column where a tile row starts
+    int pitch;                    // LDS row pitch in floats = 256 + roundup4(2*(kcols/2))
+    int ntaps;                    // number of kernel == 1 taps (focal)
+    double inv_ntaps;
     const double *weights;        // device: krows*kcols float64 weights (convolve)
     long tiles_x, n_tiles;
     unsigned long long mask_rows[MAX_K];   // bit kx of entry ky: tap (ky, kx) has kernel == 1 (focal)
 };
 
-// Cooperative tile load.  VEC: raster is 16-byte friendly (cols, ld, base), else scalar.
+// LDS tile: element (r, c) holds raster cell (Y0 - ry + r, X0 - rx + c), so the window of the lane
+// that owns output columns X0+4*lane .. +3 starts at the 16-byte aligned LDS column 4*lane and is read
+// with ds_read_b128.  The shift by rx happens once, at the LDS write.  Cells outside the raster (or
+// outside the shard's halo rows) are stored as NaN.  Returns true if this thread stored any
+// non-finite value (so the workgroup can pick the NaN-free fast path).
+__device__ __forceinline__ bool put4(float *trow, int c0, int pitch, const float4 v) {
+    // c0 = LDS column of v.x (may be -3..-1 at the left edge; columns >= pitch are dropped)
+    if ((c0 & 3) == 0) {
+        if (c0 >= 0 && c0 + 3 < pitch) *reinterpret_cast<float4 *>(trow + c0) = v;
+    } else if ((c0 & 1) == 0) {
+        if (c0 >= 0 && c0 + 1 < pitch) *reinterpret_cast<float2 *>(trow + c0) = make_float2(v.x, v.y);
+        if (c0 + 2 >= 0 && c0 + 3 < pitch) *reinterpret_cast<float2 *>(trow + c0 + 2) = make_float2(v.z, v.w);
+    } else {
+        if (c0 >= 0 && c0 < pitch) trow[c0] = v.x;
+        if (c0 + 1 >= 0 && c0 + 1 < pitch) trow[c0 + 1] = v.y;
+        if (c0 + 2 >= 0 && c0 + 2 < pitch) trow[c0 + 2] = v.z;
+        if (c0 + 3 >= 0 && c0 + 3 < pitch) trow[c0 + 3] = v.w;
+    }
+    return !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+}
+
 template <bool VEC>
-__device__ __forceinline__ void load_tile(const KxkArgs &a, float *tile, long X0, long Y0, int ry) {
+__device__ __forceinline__ bool load_tile(const KxkArgs &a, float *tile, long X0, long Y0) {
     const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+    const int ry = a.krows / 2, rx = a.kcols / 2;
     const int trows = a.th + a.krows - 1;
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const float qnan = nan_f32();
+    bool bad = false;
     if (VEC) {
-        const int lw4 = a.lw >> 2;
-        const int total = trows * lw4;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int r = i / lw4, c4 = i - r * lw4;
+        // wave wy stages tile rows wy, wy+4, ...: one full-wave float4 load per row + a short tail
+        const int nj = (TW + 2 * a.lpad) >> 2;
+        const int sh = a.lpad - rx;
+        for (int r = wy; r < trows; r += 4) {
             const long y = Y0 - ry + r;
-            const long x = X0 - a.lpad + (long)c4 * 4;
-            float4 v = make_float4(qnan, qnan, qnan, qnan);
-            if (y >= y_lo && y < y_hi && x >= 0 && x < a.cols)
-                v = *reinterpret_cast<const float4 *>(a.in + y * a.ld_in + x);
-            *reinterpret_cast<float4 *>(tile + r * a.lw + c4 * 4) = v;
+            const bool yok = y >= y_lo && y < y_hi;
+            const float *grow = a.in + y * a.ld_in + (X0 - a.lpad);
+            float *trow = tile + r * a.pitch;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j >= nj) break;
+                const long x = X0 - a.lpad + 4L * j;
+                float4 v = make_float4(qnan, qnan, qnan, qnan);
+                if (yok && x >= 0 && x < a.cols) v = *reinterpret_cast<const float4 *>(grow + 4 * j);
+                bad |= put4(trow, 4 * j - sh, a.pitch, v);
+            }
         }
     } else {
-        const int total = trows * a.lw;
+        const int total = trows * a.pitch;
         for (int i = threadIdx.x; i < total; i += 256) {
-            const int r = i / a.lw, c = i - r * a.lw;
+            const int r = i / a.pitch, c = i - r * a.pitch;
             const long y = Y0 - ry + r;
-            const long x = X0 - a.lpad + c;
+            const long x = X0 - rx + c;
             float v = qnan;
             if (y >= y_lo && y < y_hi && x >= 0 && x < a.cols) v = a.in[y * a.ld_in + x];
             tile[i] = v;
+            bad |= !isfinite(v);
         }
     }
+    return bad;
 }
 
 template <bool VEC>
@@ -86,40 +123,38 @@ __device__ __forceinline__ void store_row(float *out, long ld, long y, long x0, 
 
 // Visit every tap of the kernel for the 4 adjacent outputs a lane owns:
 //   f(ky, kx, v0, v1, v2, v3)  with v_o = input cell under tap (ky, kx) of output column o.
-// LDS rows are read as aligned 16-byte slots (ds_read_b128, conflict-free for
-// consecutive lanes); a lane's slots start at its own float4, lpad-rx cells left of tap 0.
-// KH/KW > 0: compile-time shape, fully unrolled, register-indexed.  0: runtime shape,
-// 8-register sliding view advanced one slot per 4 taps.
+// KH/KW > 0: compile-time shape, fully unrolled, register-indexed.  0: runtime shape, an
+// 8-register sliding view advanced one 16-byte slot per 4 taps (the slot after the last needed
+// one is read and ignored; the tile allocation carries 64 bytes of slack for it).
 template <int KH, int KW, typename F>
 __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile, int orow, int lane, F &&f) {
     if constexpr (KH > 0) {
-        constexpr int RX = KW / 2, LP = (RX + 3) & ~3, NW = 4 + 2 * LP, SH = LP - RX;
+        constexpr int NS = (4 + 2 * (KW / 2) + 3) / 4;     // 16-byte slots per lane per row
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.lw) + lane;
-            float w[NW];
+            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.pitch) + lane;
+            float w[4 * NS];
 #pragma unroll
-            for (int i = 0; i < NW / 4; ++i) {
+            for (int i = 0; i < NS; ++i) {
                 const float4 q = r4[i];
                 w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
             }
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) f(ky, kx, w[SH + kx], w[SH + kx + 1], w[SH + kx + 2], w[SH + kx + 3]);
+            for (int kx = 0; kx < KW; ++kx) f(ky, kx, w[kx], w[kx + 1], w[kx + 2], w[kx + 3]);
         }
     } else {
         const int kh = a.krows, kw = a.kcols;
-        const int sh = a.lpad - kw / 2;
-        const int nchunks = (sh + kw + 3) >> 2;
+        const int nchunks = (kw + 3) >> 2;
         for (int ky = 0; ky < kh; ++ky) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.lw) + lane;
+            const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.pitch) + lane;
             float4 cur = r4[0];
             for (int jc = 0; jc < nchunks; ++jc) {
                 const float4 nx = r4[jc + 1];
                 const float w[8] = {cur.x, cur.y, cur.z, cur.w, nx.x, nx.y, nx.z, nx.w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int kx = jc * 4 + jj - sh;
-                    if (kx >= 0 && kx < kw) f(ky, kx, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
+                    const int kx = jc * 4 + jj;
+                    if (kx < kw) f(ky, kx, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
                 }
                 cur = nx;
             }
@@ -127,17 +162,20 @@ __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile,
     }
 }
 
-// ------------------------------------------------------------------ focal statistics
-template <int KH, int KW, bool MEAN_ONLY, bool VEC>
-__global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
-    if (t < 0) return;
-    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const long X0 = tx * TW, Y0 = ty * a.th;
-    load_tile<VEC>(a, tile, X0, Y0, a.krows / 2);
-    __syncthreads();
+// Fast reciprocal of a small positive count in float64: v_rcp_f64 + one Newton step (error ~1e-16,
+// invisible after the float32 rounding of the result).  0 -> NaN after the multiply, like 0/0.
+__device__ __forceinline__ double rcp_count(int n) {
+    const double c = (double)n;
+    double r = __builtin_amdgcn_rcp(c);
+    r = fma(fma(-c, r, 1.0), r, r);
+    return n ? r : nan("");
+}
 
+// ------------------------------------------------------------------ focal statistics
+// All statistics / any kernel shape.  Per output row: pass 1 walks the window row-major (the order the
+// reference's reducers visit their scratch array), pass 2 (std / var only) accumulates squared deviations.
+template <int KH, int KW, bool MEAN_ONLY, bool VEC>
+__device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float *tile, long X0, long Y0) {
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const long x0 = X0 + lane * 4;
     if (x0 >= a.cols) return;
@@ -154,7 +192,6 @@ __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
         float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-        // pass 1, row-major over the window = the order the reference's reducers visit the scratch
         walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
             if (!(a.mask_rows[ky] >> kx & 1ull)) return;      // wave-uniform
             const float v[4] = {v0, v1, v2, v3};
@@ -175,7 +212,7 @@ __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
         float o_tmp[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            mean[o] = sum64[o] / (double)cnt[o];       // 0/0 -> NaN like np.divide
+            mean[o] = sum64[o] * rcp_count(cnt[o]);
             o_tmp[o] = (float)mean[o];
         }
         store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
@@ -199,7 +236,6 @@ __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
         store_row<VEC>(a.out[XRS_STAT_SUM], a.ld_out, y, x0, a.cols, sum32);
 
         if (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR]) {
-            // pass 2: squared deviations from the float64 mean (Numba nanvar is two-pass)
             double ssd[4] = {0, 0, 0, 0};
             walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
                 if (!(a.mask_rows[ky] >> kx & 1ull)) return;
@@ -213,7 +249,7 @@ __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
             float o_var[4], o_std[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                const double var = ssd[o] / (double)cnt[o];
+                const double var = ssd[o] * rcp_count(cnt[o]);
                 o_var[o] = (float)var;
                 o_std[o] = (float)sqrt(var);
             }
@@ -221,6 +257,206 @@ __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
             store_row<VEC>(a.out[XRS_STAT_STD], a.ld_out, y, x0, a.cols, o_std);
         }
     }
+}
+
+template <int KH, int KW, bool MEAN_ONLY, bool VEC>
+__global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const long X0 = tx * TW, Y0 = ty * a.th;
+    load_tile<VEC>(a, tile, X0, Y0);
+    __syncthreads();
+    focal_rows_general<KH, KW, MEAN_ONLY, VEC>(a, tile, X0, Y0);
+}
+
+// Mean only, compile-time kernel shape, 16-byte friendly raster: the headline kernel.
+// Each wave owns 4 output rows x 256 columns.  If the staged tile holds only finite in-raster cells
+// (the overwhelmingly common case) the window walk is inverted: every LDS row is read ONCE
+// (ds_read_b128), converted to float64 ONCE, and added into the accumulators of all the output rows
+// whose window covers it; the count is the constant number of taps.  Tiles that touch a raster edge
+// or hold NaN/inf take the general per-output-row path with NaN skipping and counting.
+template <int KH, int KW>
+__global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    constexpr int RPW = TH_FAST / 4, RX = KW / 2, NV = 4 + 2 * RX, NS = (NV + 3) / 4;
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const long X0 = tx * TW, Y0 = ty * TH_FAST;
+    const bool bad = load_tile<true>(a, tile, X0, Y0);
+    if (__syncthreads_or(bad)) {
+        focal_rows_general<KH, KW, true, true>(a, tile, X0, Y0);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const long x0 = X0 + lane * 4;          // (finite tile => whole tile inside the raster)
+
+    double acc[RPW][4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+
+#pragma unroll
+    for (int ir = 0; ir < RPW + KH - 1; ++ir) {            // tile row wy*RPW + ir
+        const float4 *r4 = reinterpret_cast<const float4 *>(tile + (wy * RPW + ir) * a.pitch) + lane;
+        double d[4 * NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float4 q = r4[i];
+            d[4 * i] = (double)q.x; d[4 * i + 1] = (double)q.y; d[4 * i + 2] = (double)q.z; d[4 * i + 3] = (double)q.w;
+        }
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int orow = ir - ky;                      // compile-time after unrolling
+            if (orow < 0 || orow >= RPW) continue;
+            const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                if (bits >> kx & 1u) {                     // wave-uniform
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long y = Y0 + wy * RPW + r;
+        float *p = a.out[XRS_STAT_MEAN] + y * a.ld_out + x0;
+        *reinterpret_cast<float4 *>(p) = make_float4((float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                                                     (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
+    }
+}
+
+// Mean only, compile-time shape, register-resident variant (no LDS): the 3x3 terrain kernels' strip
+// layout applied to a k-wide window.  Each wave owns 256 columns x RB rows; a lane loads, per input
+// row, its own float4 plus the RX cells left and right of it (L1/L2 hits: they are the neighbouring
+// lanes' float4s), converts each value to float64 ONCE, and adds it into every output row it belongs
+// to.  All (RB+KH-1) row loads of a lane are independent and issued up front.
+// Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
+// row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
+// sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
+template <int KH, int KW, int RB, bool INTERIOR>
+__device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
+    constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
+    const long x0 = x_tile + lane * 4;
+    const unsigned loff = (unsigned)lane * 4u;
+    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+    const float qnan = nan_f32();
+
+    // v[r][0..NV) = columns x0-RX .. x0+3+RX of input row y0 - RY + r
+    float v[NR][NV];
+    const bool has_l = INTERIOR || x0 >= 4;          // x0 is a multiple of 4 and RX <= 3
+    const bool has_r = INTERIOR || x0 + 8 <= a.cols;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const long y = y0 - RY + r;
+        const bool ok = INTERIOR || (y >= y_lo && y < y_hi);
+        const float *p = (a.in + y * a.ld_in + x_tile) + loff;       // scalar row base + lane offset
+        if (!INTERIOR) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[r][i] = qnan;
+        }
+        if (ok) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(p);
+            v[r][RX] = c4.x; v[r][RX + 1] = c4.y; v[r][RX + 2] = c4.z; v[r][RX + 3] = c4.w;
+            if (RX == 1) {
+                if (has_l) v[r][0] = p[-1];
+                if (has_r) v[r][NV - 1] = p[4];
+            } else if (RX == 2) {
+                if (has_l) { const float2 l2 = *reinterpret_cast<const float2 *>(p - 2); v[r][0] = l2.x; v[r][1] = l2.y; }
+                if (has_r) { const float2 r2 = *reinterpret_cast<const float2 *>(p + 4); v[r][NV - 2] = r2.x; v[r][NV - 1] = r2.y; }
+            } else {                                           // RX == 3 (7-wide): aligned float4 each side, 3 used
+                if (has_l) { const float4 l4 = *reinterpret_cast<const float4 *>(p - 4); v[r][0] = l4.y; v[r][1] = l4.z; v[r][2] = l4.w; }
+                if (has_r) { const float4 r4 = *reinterpret_cast<const float4 *>(p + 4); v[r][NV - 3] = r4.x; v[r][NV - 2] = r4.y; v[r][NV - 1] = r4.z; }
+            }
+        }
+    }
+
+    float *out = a.out[XRS_STAT_MEAN] + y0 * a.ld_out + x_tile;      // scalar
+    if (INTERIOR) {
+        double acc[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+#pragma unroll
+        for (int ir = 0; ir < NR; ++ir) {
+            double d[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
+                    }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
+        if (__any(bad)) return false;          // caller re-runs this strip through the NaN-aware body
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            *reinterpret_cast<float4 *>(out + r * a.ld_out + loff) =
+                make_float4((float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                            (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
+        return true;
+    }
+    // edge / NaN body: per output row, row-major over the window, skip NaN, count
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (y0 + r >= a.rows) break;
+        double sum[4] = {0, 0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+                if (bits >> kx & 1u) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float x = v[r + ky][kx + o];
+                        const bool okv = !isnan(x);
+                        sum[o] += okv ? (double)x : 0.0;
+                        cnt[o] += okv ? 1 : 0;
+                    }
+                }
+        }
+        *reinterpret_cast<float4 *>(out + r * a.ld_out + loff) =
+            make_float4((float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
+                        (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3])));
+    }
+    return true;
+}
+
+template <int KH, int KW, int RB>
+__global__ void __launch_bounds__(256, 4) focal_mean_direct_kernel(const KxkArgs a) {
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = tx * TW;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    const bool interior = x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - KH / 2 >= -(long)a.halo_top &&
+                          y0 + RB + KH / 2 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
+    if (interior && focal_mean_direct_body<KH, KW, RB, true>(a, x_tile, y0, lane)) return;
+    if (x_tile + lane * 4 >= a.cols) return;
+    focal_mean_direct_body<KH, KW, RB, false>(a, x_tile, y0, lane);
 }
 
 // ------------------------------------------------------------------------ convolve_2d
@@ -231,7 +467,7 @@ __global__ void __launch_bounds__(256) convolve_kernel(const KxkArgs a) {
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * TW, Y0 = ty * a.th;
-    load_tile<VEC>(a, tile, X0, Y0, a.krows / 2);
+    load_tile<VEC>(a, tile, X0, Y0);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
@@ -298,9 +534,9 @@ __global__ void __launch_bounds__(256) focal_mean3_kernel(const Mean3Args a) {
 int plan_tile(KxkArgs &a, size_t *lds_bytes) {
     const int rx = a.kcols / 2;
     a.lpad = (rx + 3) & ~3;
-    a.lw = TW + 2 * a.lpad + 4;      // one spare 16-byte slot: the runtime walk reads whole slots
+    a.pitch = TW + ((2 * rx + 3) & ~3);
     for (int th = 16; th >= 4; th >>= 1) {
-        const size_t bytes = (size_t)(th + a.krows - 1) * a.lw * sizeof(float);
+        const size_t bytes = ((size_t)(th + a.krows - 1) * a.pitch + 16) * sizeof(float);   // + one slot of read slack
         if (bytes <= 64 * 1024) {
             a.th = th;
             *lds_bytes = bytes;
@@ -339,14 +575,42 @@ int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
     return 0;
 }
 
+template <int KH, int KW>
+int launch_mean_fast(const KxkArgs &a, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((focal_mean_fast_kernel<KH, KW>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), lds, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KH, int KW>
+int launch_mean_direct(KxkArgs a, hipStream_t s) {
+    constexpr int RB = 4;
+    a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
+    hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+// XRS_FOCAL_VARIANT=lds forces the LDS-tile kernels for small masks (A/B measurements; default: direct)
+bool prefer_lds() {
+    const char *e = getenv("XRS_FOCAL_VARIANT");
+    return e && strcmp(e, "lds") == 0;
+}
+
 template <bool MEAN_ONLY>
 int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
-    if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY>(a, vec, lds, s);
-    if (MEAN_ONLY) {
-        // the unrolled all-statistics bodies need > 170 VGPRs beyond 3x3; the runtime walk needs 72
-        if (a.krows == 5 && a.kcols == 5) return launch_focal<5, 5, true>(a, vec, lds, s);
-        if (a.krows == 7 && a.kcols == 7) return launch_focal<7, 7, true>(a, vec, lds, s);
+    if (MEAN_ONLY && vec && !prefer_lds()) {
+        if (a.krows == 3 && a.kcols == 3) return launch_mean_direct<3, 3>(a, s);
+        if (a.krows == 5 && a.kcols == 5) return launch_mean_direct<5, 5>(a, s);
+        // (7x7 would need 256 VGPRs in registers: it stays on the LDS-tile kernel)
     }
+    if (MEAN_ONLY && vec && a.th == TH_FAST) {
+        if (a.krows == 3 && a.kcols == 3) return launch_mean_fast<3, 3>(a, lds, s);
+        if (a.krows == 5 && a.kcols == 5) return launch_mean_fast<5, 5>(a, lds, s);
+        if (a.krows == 7 && a.kcols == 7) return launch_mean_fast<7, 7>(a, lds, s);
+    }
+    // (the unrolled all-statistics bodies need > 170 VGPRs beyond 3x3; the runtime walk needs ~72)
+    if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY>(a, vec, lds, s);
     return launch_focal<0, 0, MEAN_ONLY>(a, vec, lds, s);
 }
 
@@ -423,7 +687,9 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         for (int kx = 0; kx < kcols; ++kx)
             if (kernel[ky * kcols + kx] == 1.0) bits |= 1ull << kx;
         a.mask_rows[ky] = bits;
+        a.ntaps += __builtin_popcountll(bits);
     }
+    a.inv_ntaps = a.ntaps ? 1.0 / a.ntaps : 0.0;
     (void)work_dev;   // reserved (row-run tables for large masks); the bit-rows travel as kernel arguments
 
     a.tiles_x = (cols + TW - 1) / TW;

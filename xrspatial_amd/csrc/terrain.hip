@@ -99,26 +99,24 @@ __device__ __forceinline__ void store4<double>(double *p, const float (&v)[4]) {
 }
 
 // ---------------------------------------------------------------- fast path
-template <int OPS, typename HillT, int RB>
-__global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a) {
-    const long tile = xcd_tile(blockIdx.x, a.n_tiles);
-    if (tile < 0) return;
-    const long ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const long x0 = tx * 256 + lane * 4;
-    const long y0 = ty * (4 * RB) + (long)wy * RB;
-    if (x0 >= a.cols || y0 >= a.rows) return;
-
+// INTERIOR: wave-uniform fact that the wave's whole (RB+2) x 258 input window lies inside the raster
+// (true for all but the waves along the raster edge): loads are unconditional, addressed as a scalar row
+// base + one per-lane offset (global_load ... s[base], offset:imm), and no border/NaN selects exist.
+template <int OPS, typename HillT, int RB, bool INTERIOR>
+__device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_tile, long y0, int lane) {
+    const long x0 = x_tile + lane * 4;
     const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;   // valid input rows [y_lo, y_hi)
-    const bool has_l = x0 > 0, has_r = x0 + 4 < a.cols;
+    const bool has_l = INTERIOR || x0 > 0, has_r = INTERIOR || x0 + 4 < a.cols;
+    const unsigned loff = (unsigned)lane * 4u;
 
     // v[r][0..5] = columns x0-1 .. x0+4 of input row y0 + r - 1
     float v[RB + 2][6];
 #pragma unroll
     for (int r = 0; r < RB + 2; ++r) {
         const long y = y0 + r - 1;
-        const bool ok = y >= y_lo && y < y_hi;
-        const float *p = a.in + y * a.ld_in + x0;
+        const bool ok = INTERIOR || (y >= y_lo && y < y_hi);
+        const float *rowbase = a.in + y * a.ld_in + x_tile;            // wave-uniform
+        const float *p = rowbase + loff;
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float l = 0.f, rr = 0.f;
         if (ok) {
@@ -135,13 +133,13 @@ __global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a)
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const long y = y0 + r;
-        if (y >= a.rows) break;
-        const bool row_border = (y - 1 < y_lo) || (y + 1 >= y_hi);
+        if (!INTERIOR && y >= a.rows) break;
+        const bool row_border = !INTERIOR && ((y - 1 < y_lo) || (y + 1 >= y_hi));
         float o_slope[4], o_aspect[4], o_curv[4], o_hill[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const long x = x0 + o;
-            const bool border = row_border || x == 0 || x == a.cols - 1;
+            const bool border = !INTERIOR && (row_border || x == 0 || x == a.cols - 1);
             Nb q;
             q.nw = v[r][o];     q.n = v[r][o + 1];     q.ne = v[r][o + 2];
             q.w = v[r + 1][o];  q.c = v[r + 1][o + 1]; q.e = v[r + 1][o + 2];
@@ -152,11 +150,31 @@ __global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a)
             if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
             if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
         }
-        const long off = y * a.ld_out + x0;
-        if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off, o_slope);
-        if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off, o_aspect);
-        if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off, o_curv);
-        if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off, o_hill);
+        const long off = y * a.ld_out + x_tile;                         // wave-uniform
+        if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off + loff, o_slope);
+        if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off + loff, o_aspect);
+        if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off + loff, o_curv);
+        if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off + loff, o_hill);
+    }
+}
+
+template <int OPS, typename HillT, int RB>
+__global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a) {
+    const long tile = xcd_tile(blockIdx.x, a.n_tiles);
+    if (tile < 0) return;
+    const long ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave index as a scalar
+    const long x_tile = tx * 256;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    const bool interior = x_tile >= 4 && x_tile + 256 + 4 <= a.cols &&
+                          y0 - 1 >= -(long)a.halo_top && y0 + RB + 1 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
+    if (interior) {
+        terrain_strip_body<OPS, HillT, RB, true>(a, x_tile, y0, lane);
+    } else {
+        if (x_tile + lane * 4 >= a.cols) return;
+        terrain_strip_body<OPS, HillT, RB, false>(a, x_tile, y0, lane);
     }
 }
 

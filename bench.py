@@ -165,8 +165,8 @@ def main():
     cells_rank = rows * cols
     ms_per_step = elapsed / args.steps * 1e3
     value = cells_rank * world / (elapsed / args.steps) / 1e6
-    dom_name, dom_ms = ("focal_stats_kernel<5,5,mean>", focal_avg) if focal_avg >= hill_avg else \
-        ("terrain_strip_kernel<hillshade>", hill_avg)
+    dom_name, dom_ms = ("focal_mean_direct_kernel<5,5,4>", focal_avg) if focal_avg >= hill_avg else \
+        ("terrain_strip_kernel<hillshade,float,4>", hill_avg)
     achieved = ALG_BYTES_PER_CELL * cells_rank / (dom_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")

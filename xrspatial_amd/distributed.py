@@ -98,3 +98,43 @@ def combine_zonal_partials(parts):
     mn = np.min([p[3] for p in parts], axis=0)
     mx = np.max([p[4] for p in parts], axis=0)
     return count, s1, s2, mn, mx
+
+
+# ---------------------------------------------------------------------------------------------
+# Host-staged variants over an initialised torch.distributed process group (any backend; the CPU
+# tests use gloo).  They implement exactly the exchange / reduction pattern of xrs_halo_exchange_f32
+# and xrs_zonal_allreduce -- same neighbours, same rows, same reduction ops -- on NumPy buffers, for
+# flows whose shards live in host memory and for validating the sharding algebra without GPUs.
+
+def halo_exchange_host(dist, shard_with_halo: np.ndarray, halo: int):
+    """In place: fill rows [0, halo) from rank-1's last owned rows and rows [-halo, end) from rank+1's
+    first owned rows.  `shard_with_halo` has shape (rows + 2*halo, cols); outer ranks' outer halos are
+    left untouched (the caller passes halo_top/halo_bot = 0 there)."""
+    import torch
+    if halo == 0 or dist.get_world_size() == 1:
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = torch.from_numpy(shard_with_halo)             # shares memory
+    rows = buf.shape[0] - 2 * halo
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, buf[halo:2 * halo].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.irecv, buf[0:halo], rank - 1))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, buf[rows:rows + halo].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, buf[rows + halo:rows + 2 * halo], rank + 1))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def zonal_allreduce_host(dist, count, s1, s2, mn, mx):
+    """All-reduce per-zone partials across ranks: sum / sum / sum / min / max."""
+    import torch
+    out = []
+    for arr, op in ((count.astype(np.int64), dist.ReduceOp.SUM), (s1, dist.ReduceOp.SUM), (s2, dist.ReduceOp.SUM),
+                    (mn, dist.ReduceOp.MIN), (mx, dist.ReduceOp.MAX)):
+        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
+        dist.all_reduce(t, op=op)
+        out.append(t.numpy())
+    out[0] = out[0].astype(np.uint64)
+    return tuple(out)

@@ -152,7 +152,8 @@ def stats(
     callables and `return_type='xarray.DataArray'` need per-zone histograms / a back-projection
     pass and raise NotImplementedError in this release -- when
     `stats_funcs` is left at its default, `majority` is dropped with the other seven computed,
-    which is exactly what the reference's dask backend does (zonal.py:219-222)."""
+    which is what the reference's dask backend returns (its test expects no
+    `majority` column: xrspatial/tests/test_zonal.py:77-90, 408-426)."""
     if isinstance(values, Dataset):
         if return_type != 'pandas.DataFrame':
             raise ValueError("return_type must be 'pandas.DataFrame' when values is a Dataset")

@@ -355,3 +355,76 @@ def test_fused_terrain_equals_separate():
     np.testing.assert_array_equal(outs[1].get(), xs.aspect(agg).data)
     np.testing.assert_array_equal(outs[2].get(), xs.curvature(agg).data)
     np.testing.assert_array_equal(outs[3].get().astype(np.float64), xs.hillshade(agg).data)
+
+
+# ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
+@pytest.fixture(scope="module")
+def dem16k():
+    n = 16384
+    dev = xs.DeviceArray((n, n), np.float32)
+    bands = {}
+    from xrspatial_amd import _lib
+    for y0 in range(0, n, 2048):
+        host = synth.asv_dem(2048, n, y0=y0, total_rows=n)
+        if y0 in (0, 6144, 14336):
+            bands[y0] = host
+        _lib.call("xrs_memcpy_h2d", dev.ptr + y0 * n * 4, host.ctypes.data, host.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
+    return n, dev, bands
+
+
+def test_full_size_bands_match_oracle(dem16k):
+    """BASELINE configs[1]/[2] raster: the device results on 16384^2 are compared with the C oracle on
+    row bands (top edge, interior, bottom edge), where the oracle finishes in seconds."""
+    n, dev, bands = dem16k
+    agg = xs.DataArray(dev, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+    k5 = circle_kernel(1, 1, 2)
+    results = {
+        'slope': xs.slope(agg).data, 'aspect': xs.aspect(agg).data, 'curvature': xs.curvature(agg).data,
+        'hillshade': xs.hillshade(agg).data, 'focal5': apply(agg, k5).data,
+    }
+    for y0, band in bands.items():
+        # interior rows of the band only (the oracle sees the band as a whole raster: its own first/last
+        # rows are edges); the raster's true top/bottom edges are checked on the first/last band
+        lo, hi = (0 if y0 == 0 else 2), (2048 if y0 + 2048 == n else 2046)
+        want = {
+            'slope': corc.slope(band, 1.0, 1.0, nthreads=8), 'aspect': corc.aspect(band, nthreads=8),
+            'curvature': corc.curvature(band, 1.0, nthreads=8), 'hillshade': orc.hillshade(band[:256 + 4])[:256 + 2],
+            'focal5': corc.focal_apply(band, k5, 'mean', nthreads=8),
+        }
+        for name, dev_out in results.items():
+            rows = slice(lo, min(hi, want[name].shape[0] - (0 if name != 'hillshade' else 0)))
+            if name == 'hillshade':
+                rows = slice(lo, 256)
+            got = dev_out.rows(y0 + rows.start, y0 + rows.stop).get()
+            np.testing.assert_allclose(got, want[name][rows], rtol=RTOL, atol=1e-6, equal_nan=True,
+                                       err_msg=f"{name} band {y0}")
+
+
+def test_full_size_properties(dem16k):
+    """Size-independent properties on the full 16384^2 raster."""
+    n, dev, _ = dem16k
+    agg = xs.DataArray(dev, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+    # NaN border: exactly the 1-cell frame, nothing else (the DEM has no NaN)
+    for fn in (xs.slope, xs.hillshade):
+        out = fn(agg).data
+        top, bot = out.rows(0, 2).get(), out.rows(n - 2, n).get()
+        assert np.isnan(top[0]).all() and np.isnan(bot[1]).all()
+        assert not np.isnan(top[1, 1:-1]).any() and np.isnan(top[1, [0, -1]]).all()
+        mid = out.rows(8000, 8002).get()
+        assert np.isnan(mid[:, [0, -1]]).all() and not np.isnan(mid[:, 1:-1]).any()
+    # ndvi(a, a) == 0 wherever a != 0; ndvi(a, -a) is NaN (zero denominator)
+    z = xs.ndvi(agg, agg).data.rows(5000, 5004).get()
+    assert (z == 0).all()
+    # a 5x5 mean of a constant raster is that constant everywhere, edges included (clipped window)
+    const = xs.DeviceArray.from_numpy(np.full((4096, 4096), 7.25, np.float32))
+    m = apply(xs.DataArray(const), circle_kernel(1, 1, 2)).data.get()
+    assert (m == np.float32(7.25)).all()
+    # zonal: counts over 1000 block zones add up to the number of cells, bit-exact, and sums are linear
+    zones = xs.DeviceArray.from_numpy(synth.block_zones(4096, 4096))
+    vals = dev.rows(0, 1024)            # 1024 x 16384 == 4096 x 4096 cells, same memory reinterpreted
+    vals4k = xs.DeviceArray((4096, 4096), np.float32, _ptr=vals.ptr, _base=vals)
+    df = xs.zonal_stats(xs.DataArray(zones), xs.DataArray(vals4k), stats_funcs=['count', 'sum', 'mean'])
+    assert int(df['count'].sum()) == 4096 * 4096
+    host_sum = float(vals4k.get().astype(np.float64).sum())
+    assert abs(df['sum'].sum() - host_sum) <= 1e-9 * abs(host_sum)

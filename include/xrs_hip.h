@@ -159,6 +159,22 @@ int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev
                            uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                            double *min_dev, double *max_dev, void *stream);
 
+/* majority (most frequent valid value per zone, ties -> smallest; NaN for zones without a valid
+ * cell), computed by two device radix sorts + run voting; replaces _stats_majority applied per zone
+ * (xrspatial/zonal.py:56-68, 144-163).  `work_dev` must hold
+ * xrs_zonal_majority_workspace_bytes(n, n_zones, values_f64) bytes.  n < 2^31 cells per call. */
+size_t xrs_zonal_majority_workspace_bytes(int64_t n, int n_zones, int values_f64);
+int xrs_zonal_majority_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones,
+                           float nodata, int has_nodata, void *work_dev, size_t work_bytes,
+                           double *majority_dev, void *stream);
+int xrs_zonal_majority_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones,
+                           double nodata, int has_nodata, void *work_dev, size_t work_bytes,
+                           double *majority_dev, void *stream);
+/* return_type='xarray.DataArray' of zonal.stats (xrspatial/zonal.py:313-332): out[s][cell] =
+ * table[s][zone_idx[cell]] (row-major n_stats x n_zones float64 table), NaN where the cell has no zone. */
+int xrs_zonal_backproject_f64(const int32_t *zone_idx_dev, int64_t n, const double *table_dev, int n_stats,
+                              int n_zones, double *out_dev, void *stream);
+
 /* ----------------------------------------------------- multi-GPU (RCCL, xGMI)
  * One process per GPU.  Rank 0 creates a 128-byte id and ships it to the other
  * ranks by any out-of-band means; every rank then calls xrs_comm_init_rank.

@@ -137,15 +137,16 @@ def test_zonal_goldens(golden, golden_tables):
     z0, v0 = zones.data.copy(), values.data.copy()
     df = xs.zonal_stats(zones, values)
     exp = golden_tables["zonal_default"]
-    assert list(df.columns) == ['zone', 'mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    assert list(df.columns) == ['zone', 'mean', 'max', 'min', 'sum', 'std', 'var', 'count', 'majority']
     assert (df['zone'] == exp['zone']).all()
     for col in df.columns[1:]:
         np.testing.assert_allclose(df[col], exp[col], rtol=1e-5, atol=1e-7)
     np.testing.assert_array_equal(zones.data, z0)
     np.testing.assert_array_equal(values.data, v0)
     ids = golden_tables["zonal_zone_ids__0"]
-    df = xs.zonal_stats(zones, values, zone_ids=ids, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
+    df = xs.zonal_stats(zones, values, zone_ids=ids)
     exp = golden_tables["zonal_zone_ids__1"]
+    assert len(df.columns) == len(exp)
     assert (df['zone'] == exp['zone']).all()
     for col in df.columns[1:]:
         np.testing.assert_allclose(df[col], exp[col], rtol=1e-5, atol=1e-7)
@@ -290,6 +291,36 @@ def test_zonal_vs_oracle(scatter, vdtype):
     np.testing.assert_array_equal(df['min'].to_numpy(), want['min'])
     for col in ('mean', 'sum', 'std', 'var'):
         np.testing.assert_allclose(df[col].to_numpy(), want[col], rtol=RTOL, err_msg=col)
+
+
+def test_zonal_majority_and_dataarray(golden, golden_tables):
+    # majority ties -> smallest value (test_zonal.py:567-590)
+    z = np.array([[1, 1, 1, 1], [1, 1, 2, 2], [2, 2, 2, 2]])
+    v = np.array([[1, 1, 2, 2], [3, 3, 5, 5], [5, 5, 6, 6]])
+    df = xs.zonal_stats(raster(z), raster(v), stats_funcs=['majority'])
+    assert df['zone'].tolist() == [1, 2] and df['majority'].tolist() == [1, 5]
+    # return_type='xarray.DataArray' goldens (test_zonal.py:94-129, 166-202, 430-494)
+    zones, values = raster(golden["zonal_zones"]), raster(golden["zonal_values"])
+    da = xs.zonal_stats(zones, values, return_type='xarray.DataArray')
+    assert da.dims == ('stats', 'y', 'x') and da.shape == (8, 3, 8)
+    np.testing.assert_allclose(da.data, golden["zonal_default_da"], rtol=1e-5, atol=1e-7, equal_nan=True)
+    ids = golden_tables["zonal_zone_ids_da__0"]
+    da = xs.zonal_stats(zones, values, zone_ids=ids, return_type='xarray.DataArray')
+    np.testing.assert_allclose(da.data, golden["zonal_zone_ids_da__1"], rtol=1e-5, atol=1e-7, equal_nan=True)
+    # seeded: majority over quantised values vs the oracle, float32 / float64 / int, with nodata
+    rng = np.random.default_rng(11)
+    zz = rng.integers(0, 23, size=(200, 333)).astype(np.int32)
+    for dtype in (np.float32, np.float64, np.int64):
+        vv = rng.integers(-5, 6, size=zz.shape).astype(dtype)
+        if dtype != np.int64:
+            vv[rng.random(zz.shape) < 0.02] = np.nan
+            vv[vv == 0] *= -1.0                                   # some -0.0
+        got = xs.zonal_stats(raster(zz), raster(vv), stats_funcs=['majority', 'count'], nodata_values=3)
+        want = orc.zonal_stats(zz, vv, stats_funcs=['majority', 'count'], nodata_values=3)
+        np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'])
+        np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+    with pytest.raises(NotImplementedError):
+        xs.zonal_stats(zones, values, stats_funcs={'double_sum': lambda a: a.sum() * 2})
 
 
 def test_zonal_run_to_run_counts_and_many_zones():

@@ -76,13 +76,19 @@ _PROTOTYPES = {
     "xrs_zonal_init_f64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrs_zonal_majority_workspace_bytes": [c_int64, c_int, c_int],
+    "xrs_zonal_majority_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p,
+                               c_void_p],
+    "xrs_zonal_majority_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                               c_void_p],
+    "xrs_zonal_backproject_f64": [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrs_comm_unique_id": [c_void_p],
     "xrs_comm_init_rank": [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int],
     "xrs_comm_destroy": [c_void_p],
     "xrs_halo_exchange_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
     "xrs_zonal_allreduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
-_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t}
+_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t}
 
 EXPORTED = tuple(_PROTOTYPES)
 

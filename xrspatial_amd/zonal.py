@@ -58,13 +58,7 @@ def _dense_zone_index(zones: np.ndarray):
     return uniq, idx.reshape(zones.shape)
 
 
-def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
-    """Per-zone (count, sum, sumsq, min, max) NumPy arrays for dense `zone_idx` (device or host arrays).
-
-    `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
-    all-reduced over it so every rank returns the global result."""
-    _lib.require_device()
-    stream = get_stream()
+def _stage(zone_idx, values):
     zdev = zone_idx if isinstance(zone_idx, DeviceArray) else DeviceArray.from_numpy(
         np.ascontiguousarray(zone_idx, dtype=np.int32))
     if isinstance(values, DeviceArray):
@@ -72,6 +66,17 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
     else:
         host = np.asarray(values)
         vdev = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+    return zdev, vdev
+
+
+def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
+    """Per-zone (count, sum, sumsq, min, max) NumPy arrays for dense `zone_idx` (device or host arrays).
+
+    `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
+    all-reduced over it so every rank returns the global result."""
+    _lib.require_device()
+    stream = get_stream()
+    zdev, vdev = _stage(zone_idx, values)
     f64 = vdev.dtype == np.float64
     vt = np.float64 if f64 else np.float32
     cnt = DeviceArray((n_zones,), np.uint64)
@@ -91,7 +96,23 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
     return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream)
 
 
-def finalize_stats(stat_names, count, s1, s2, mn, mx):
+def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
+    """Per-zone most frequent valid value (ties -> smallest), float64, NaN for empty zones."""
+    _lib.require_device()
+    stream = get_stream()
+    zdev, vdev = _stage(zone_idx, values)
+    f64 = vdev.dtype == np.float64
+    out = DeviceArray((n_zones,), np.float64)
+    nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(vdev.size, n_zones, int(f64)))
+    work = DeviceArray((nbytes,), np.uint8)
+    has_nodata = nodata_values is not None
+    nodata = float(nodata_values) if has_nodata else 0.0
+    _lib.call("xrs_zonal_majority_f64" if f64 else "xrs_zonal_majority_f32", zdev.ptr, vdev.ptr, vdev.size,
+              n_zones, nodata, int(has_nodata), work.ptr, nbytes, out.ptr, stream)
+    return out.get(stream)
+
+
+def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None):
     """Per-zone statistics from the partials (formulas of zonal.py:100-102); zones without a valid
     cell are NaN in every column, count included (zonal.py:153-161 pre-fills NaN)."""
     n = count.astype(np.float64)
@@ -101,7 +122,7 @@ def finalize_stats(stat_names, count, s1, s2, mn, mx):
         var = (s2 - s1 * s1 / n) / n
         var = np.where(var < 0, 0.0, var)         # rounding guard; the exact value is >= 0
     table = {'mean': mean, 'max': mx.astype(np.float64), 'min': mn.astype(np.float64), 'sum': s1,
-             'std': np.sqrt(var), 'var': var, 'count': n}
+             'std': np.sqrt(var), 'var': var, 'count': n, 'majority': majority}
     out = {}
     for name in stat_names:
         col = np.array(table[name], dtype=np.float64)
@@ -110,7 +131,8 @@ def finalize_stats(stat_names, count, s1, s2, mn, mx):
     return out
 
 
-def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, comm=None):
+def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, return_type, comm=None):
+    like_numpy = not isinstance(values_data, DeviceArray)
     zones_host = zones_data.get() if isinstance(zones_data, DeviceArray) else np.asarray(zones_data)
     unique_zones, idx = _dense_zone_index(zones_host)
     if zone_ids is None:
@@ -118,13 +140,27 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, com
     else:
         wanted = np.unique(zone_ids)
         selected = [z for z in wanted if z in unique_zones]
-    count, s1, s2, mn, mx = zonal_partials(idx, values_data, len(unique_zones), nodata_values, comm)
-    cols = finalize_stats(stat_names, count, s1, s2, mn, mx)
+    nz = len(unique_zones)
+    idx_dev = DeviceArray.from_numpy(idx)
+    _, vdev = _stage(idx_dev, values_data)
+    count, s1, s2, mn, mx = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
+    majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in stat_names else None
+    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, majority)
     keep = [i for i, z in enumerate(unique_zones) if z in selected]
-    frame = {'zone': selected}
-    for name in stat_names:
-        frame[name] = cols[name][keep]
-    return pd.DataFrame(frame)
+    if return_type == 'pandas.DataFrame':
+        frame = {'zone': selected}
+        for name in stat_names:
+            frame[name] = cols[name][keep]
+        return pd.DataFrame(frame)
+    # back-projection (zonal.py:313-332): every cell gets its zone's statistic, NaN outside selected zones
+    table = np.full((len(stat_names), max(nz, 1)), np.nan)
+    for i, name in enumerate(stat_names):
+        table[i, keep] = cols[name][keep]
+    tdev = DeviceArray.from_numpy(table)
+    out = DeviceArray((len(stat_names),) + tuple(idx.shape), np.float64)
+    _lib.call("xrs_zonal_backproject_f64", idx_dev.ptr, idx.size, tdev.ptr, len(stat_names), max(nz, 1), out.ptr,
+              get_stream())
+    return out.get(get_stream()) if like_numpy else out
 
 
 def stats(
@@ -146,14 +182,10 @@ def stats(
 ):
     """Summary statistics of `values` for every zone of `zones`.
 
-    Same signature as `xrspatial.zonal.stats`.  Supported on the MI355X backend: the seven
-    partial-sum statistics mean / max / min / sum / std / var / count, `zone_ids`,
-    `nodata_values`, Dataset `values`, `return_type='pandas.DataFrame'`.  `majority`, custom
-    callables and `return_type='xarray.DataArray'` need per-zone histograms / a back-projection
-    pass and raise NotImplementedError in this release -- when
-    `stats_funcs` is left at its default, `majority` is dropped with the other seven computed,
-    which is what the reference's dask backend returns (its test expects no
-    `majority` column: xrspatial/tests/test_zonal.py:77-90, 408-426)."""
+    Same signature as `xrspatial.zonal.stats`.  All eight default statistics (mean / max / min / sum /
+    std / var / count from one streaming partial-sum pass, majority from a device sort), `zone_ids`,
+    `nodata_values`, Dataset `values` and both return types run on the MI355X.  Custom callables
+    (`stats_funcs` as a dict) are arbitrary Python and raise NotImplementedError here."""
     if isinstance(values, Dataset):
         if return_type != 'pandas.DataFrame':
             raise ValueError("return_type must be 'pandas.DataFrame' when values is a Dataset")
@@ -183,13 +215,13 @@ def stats(
     for name in names:
         if name not in _DEFAULT_STATS:
             raise ValueError(f"Invalid stat name. {name} option not supported.")
-    if 'majority' in names:
-        if names == list(_DEFAULT_STATS):
-            names = list(_DEVICE_STATS)
-        else:
-            raise NotImplementedError("'majority' is not implemented on the MI355X backend yet")
-    if return_type != 'pandas.DataFrame':
-        raise NotImplementedError("return_type='xarray.DataArray' is not implemented on the MI355X backend yet")
+    if return_type not in ('pandas.DataFrame', 'xarray.DataArray'):
+        raise ValueError(f"unknown return_type {return_type!r}")
     if not isinstance(values.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(values)))
-    return _stats_hip(zones.data, values.data, zone_ids, names, nodata_values)
+    result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type)
+    if return_type == 'xarray.DataArray':
+        coords = dict(values.coords.items())
+        coords['stats'] = names
+        return DataArray(result, coords=coords, dims=('stats',) + tuple(values.dims), attrs=values.attrs)
+    return result

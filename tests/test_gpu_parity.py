@@ -216,6 +216,8 @@ KERNELS = {
     'row3': np.array([[1, 1, 1]], dtype=float),
     'circle9': circle_kernel(1, 1, 4),
     'circle25': circle_kernel(1, 1, 12),
+    'box11x15': np.ones((11, 15)),
+    'annulus21': annulus_kernel(1, 1, 10, 6),
     'weights5x3': np.arange(15, dtype=float).reshape(5, 3) / 7.0,
 }
 
@@ -237,6 +239,18 @@ def test_kxk_vs_oracle(kname, shape):
             np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=stat)
     np.testing.assert_allclose(apply(agg, k).data, corc.focal_apply(z, k, 'mean'), rtol=1e-6, equal_nan=True)
     np.testing.assert_array_equal(apply(agg, k, _calc_sum).data, corc.focal_apply(z, k, 'sum'))
+
+
+def test_focal_runs_kernel_inf_and_nan_tiles():
+    # the prefix-sum kernel: a tile with +-inf takes its direct fallback, NaN tiles count taps
+    z = synth.smooth_dem((90, 300), nan_frac=0.03)
+    z[40, 200] = np.inf
+    z[70, 20] = -np.inf
+    k = circle_kernel(1, 1, 12)
+    np.testing.assert_allclose(apply(raster(z), k).data, corc.focal_apply(z, k, 'mean', nthreads=8),
+                               rtol=1e-6, equal_nan=True)
+    z2 = synth.smooth_dem((64, 384))                  # no NaN: constant-count path
+    np.testing.assert_allclose(apply(raster(z2), k).data, corc.focal_apply(z2, k, 'mean', nthreads=8), rtol=1e-6)
 
 
 def test_focal_all_nan_window_and_device_backend():

@@ -675,11 +675,17 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         }
     }
     if (rows == 0 || cols == 0) return 0;
+    hipStream_t s = as_stream(stream);
+    if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols > 49) {
+        // large run-structured masks (circles, boxes, annuli): prefix-sum kernel, O(rows of the mask) per cell
+        const int rc = try_launch_focal_mean_runs(in_dev, a.out[XRS_STAT_MEAN], rows, cols, ld_in, ld_out, kernel,
+                                                  krows, kcols, halo_top, halo_bot, s);
+        if (rc >= 0) return rc;
+    }
     a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
     a.halo_top = halo_top; a.halo_bot = halo_bot; a.krows = krows; a.kcols = kcols;
     size_t lds;
     if (int rc = plan_tile(a, &lds)) return rc;
-    hipStream_t s = as_stream(stream);
 
     // `kernel == 1` exactly selects a tap (focal.py:323)
     for (int ky = 0; ky < krows; ++ky) {

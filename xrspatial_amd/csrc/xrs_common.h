@@ -59,4 +59,10 @@ inline long xcd_grid(long n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
 
 __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); }
 
+// kxk_runs.hip: prefix-sum focal mean for large run-structured masks.  0 = launched, -1 = mask not
+// suitable (caller uses the tap kernels), > 0 = error.
+int try_launch_focal_mean_runs(const float *in, float *out, long rows, long cols, long ld_in, long ld_out,
+                               const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                               hipStream_t s);
+
 }  // namespace xrs

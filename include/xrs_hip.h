@@ -190,6 +190,8 @@ int xrs_comm_init_rank(void **comm, const void *id128, int nranks, int rank);
 int xrs_comm_destroy(void *comm);
 int xrs_halo_exchange_f32(void *comm, float *shard_dev, int64_t rows, int64_t cols, int64_t ld,
                           int halo, void *stream);
+/* single-GPU loop-back check of the RCCL send/recv plumbing (test support, not on the data path) */
+int xrs_comm_selftest_f32(void *comm, const float *src_dev, float *dst_dev, int64_t count, void *stream);
 int xrs_zonal_allreduce(void *comm, uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                         void *min_dev, void *max_dev, int minmax_f64, int n_zones, void *stream);
 

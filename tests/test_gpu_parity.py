@@ -473,3 +473,30 @@ def test_full_size_properties(dem16k):
     assert int(df['count'].sum()) == 4096 * 4096
     host_sum = float(vals4k.get().astype(np.float64).sum())
     assert abs(df['sum'].sum() - host_sum) <= 1e-9 * abs(host_sum)
+
+
+def test_rccl_plumbing_single_gpu():
+    """RCCL on one GPU: 1-rank communicator, loop-back send/recv, in-place all-reduce of zonal partials.
+    (The neighbour exchange itself needs >= 2 GPUs; its protocol is covered by tests/test_distributed_cpu.py.)"""
+    from xrspatial_amd import _lib
+    from xrspatial_amd.distributed import Comm
+    comm = Comm(Comm.new_id(), 1, 0)
+    src = xs.DeviceArray.from_numpy(np.arange(4096, dtype=np.float32))
+    dst = xs.DeviceArray.from_numpy(np.zeros(4096, dtype=np.float32))
+    _lib.call("xrs_comm_selftest_f32", comm.handle, src.ptr, dst.ptr, 4096, None)
+    _lib.call("xrs_stream_sync", None)
+    np.testing.assert_array_equal(dst.get(), np.arange(4096, dtype=np.float32))
+    # halo exchange with one rank is a no-op; zonal all-reduce with one rank returns the same partials
+    shard = xs.DeviceArray.from_numpy(np.ones((8 + 4, 16), np.float32))
+    comm.halo_exchange(shard, 2)
+    from xrspatial_amd.zonal import zonal_partials
+    z = np.random.default_rng(0).integers(0, 5, size=1000).astype(np.int32)
+    v = np.random.default_rng(1).random(1000).astype(np.float32)
+    a = zonal_partials(z, v, 5)
+    b = zonal_partials(z, v, 5, comm=comm)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in (1, 2):      # float64 sums: atomic arrival order differs run to run at the 1e-16 level
+            np.testing.assert_allclose(x, y, rtol=1e-12)
+        else:                # count, min, max: exact
+            np.testing.assert_array_equal(x, y)
+    comm.destroy()

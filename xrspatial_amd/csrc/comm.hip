@@ -90,13 +90,26 @@ int xrs_halo_exchange_f32(void *comm, float *shard_dev, int64_t rows, int64_t co
     return 0;
 }
 
+/* Loop-back check of the RCCL point-to-point plumbing on ONE GPU: a grouped ncclSend/ncclRecv of `count`
+ * floats from src_dev to dst_dev addressed to this rank itself.  Used by the single-GPU test-suite (the
+ * real halo exchange needs >= 2 GPUs); not part of the data path. */
+int xrs_comm_selftest_f32(void *comm, const float *src_dev, float *dst_dev, int64_t count, void *stream) {
+    if (!comm || !src_dev || !dst_dev || count < 0) return fail("xrs_comm_selftest_f32: bad argument");
+    Comm *c = static_cast<Comm *>(comm);
+    hipStream_t s = as_stream(stream);
+    XRS_NCCL(ncclGroupStart());
+    XRS_NCCL(ncclSend(src_dev, (size_t)count, ncclFloat32, c->rank, c->nccl, s));
+    XRS_NCCL(ncclRecv(dst_dev, (size_t)count, ncclFloat32, c->rank, c->nccl, s));
+    XRS_NCCL(ncclGroupEnd());
+    return 0;
+}
+
 int xrs_zonal_allreduce(void *comm, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, void *min_dev,
                         void *max_dev, int minmax_f64, int n_zones, void *stream) {
     if (!comm) return fail("xrs_zonal_allreduce: null communicator");
     if (n_zones <= 0) return 0;
     Comm *c = static_cast<Comm *>(comm);
-    if (c->nranks == 1) return 0;
-    hipStream_t s = as_stream(stream);
+    hipStream_t s = as_stream(stream);     // (a 1-rank communicator still goes through RCCL: in-place no-op reduce)
     XRS_NCCL(ncclGroupStart());
     XRS_NCCL(ncclAllReduce(count_dev, count_dev, n_zones, ncclUint64, ncclSum, c->nccl, s));
     XRS_NCCL(ncclAllReduce(sum_dev, sum_dev, n_zones, ncclFloat64, ncclSum, c->nccl, s));

@@ -530,6 +530,107 @@ __global__ void __launch_bounds__(256) focal_mean3_kernel(const Mean3Args a) {
     a.out[y * a.ld_out + x] = res;
 }
 
+// Strip version of focal.mean for 16-byte friendly rasters: a wave owns 256 columns x 4 rows, each lane
+// keeps its 6 x 6 neighbourhood in registers (float32 or float64 input), interior waves sum the nine
+// cells in float64 row-major (the reference's nanmean order) and divide by the constant 9; a strip whose
+// sums come out non-finite (a NaN/inf under some window) or that touches a raster edge is redone cell by
+// cell with the counting body.  Excluded centre values are passed through in both paths.
+template <typename InT>
+__device__ __forceinline__ void load6(const InT *p, bool has_l, bool has_r, double (&d)[6]);
+template <>
+__device__ __forceinline__ void load6<float>(const float *p, bool has_l, bool has_r, double (&d)[6]) {
+    const float4 c = *reinterpret_cast<const float4 *>(p);
+    d[1] = c.x; d[2] = c.y; d[3] = c.z; d[4] = c.w;
+    d[0] = has_l ? (double)p[-1] : nan("");
+    d[5] = has_r ? (double)p[4] : nan("");
+}
+template <>
+__device__ __forceinline__ void load6<double>(const double *p, bool has_l, bool has_r, double (&d)[6]) {
+    const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+    d[1] = a.x; d[2] = a.y; d[3] = b.x; d[4] = b.y;
+    d[0] = has_l ? p[-1] : nan("");
+    d[5] = has_r ? p[4] : nan("");
+}
+
+__device__ __forceinline__ bool is_excluded(const Mean3Args &a, double c) {
+    bool ex = false;
+    for (int e = 0; e < a.n_excl; ++e) ex = ex || c == a.excl[e] || (isnan(c) && isnan(a.excl[e]));
+    return ex;
+}
+
+template <typename InT>
+__global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
+    constexpr int RB = 4;
+    const long t = xcd_tile(blockIdx.x, n_tiles);
+    if (t < 0) return;
+    const long ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = tx * TW, y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+    const InT *in = static_cast<const InT *>(a.in);
+    const unsigned loff = (unsigned)lane * 4u;
+    const long x0 = x_tile + loff;
+    const bool interior = x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - 1 >= y_lo && y0 + RB + 1 <= y_hi &&
+                          y0 + RB <= a.rows;
+    if (interior) {
+        double d[RB + 2][6];
+#pragma unroll
+        for (int r = 0; r < RB + 2; ++r) load6<InT>(in + (y0 - 1 + r) * a.ld_in + x_tile + loff, true, true, d[r]);
+        double res[RB][4];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                double s = 0.0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) s += d[r + ky][o + kx];
+                bad |= !isfinite(s);
+                const double c = d[r + 1][o + 1];
+                res[r][o] = is_excluded(a, c) ? c : s / 9.0;
+            }
+        if (!__any(bad)) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                double2 *q = reinterpret_cast<double2 *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
+                q[0] = make_double2(res[r][0], res[r][1]);
+                q[1] = make_double2(res[r][2], res[r][3]);
+            }
+            return;
+        }
+    }
+    // edge / NaN strip: the reference's loop, cell by cell (clamped window, NaN skipped, 0/0 -> NaN)
+    if (x0 >= a.cols) return;
+    for (int r = 0; r < RB; ++r) {
+        const long y = y0 + r;
+        if (y >= a.rows) break;
+        for (int o = 0; o < 4; ++o) {
+            const long x = x0 + o;
+            if (x >= a.cols) break;
+            const double c = (double)in[y * a.ld_in + x];
+            double resv = c;
+            if (!is_excluded(a, c)) {
+                double s = 0.0;
+                int n = 0;
+                for (long yy = y - 1; yy <= y + 1; ++yy) {
+                    if (yy < y_lo || yy >= y_hi) continue;
+                    for (long xx = x - 1; xx <= x + 1; ++xx) {
+                        if (xx < 0 || xx >= a.cols) continue;
+                        const double v = (double)in[yy * a.ld_in + xx];
+                        if (!isnan(v)) { s += v; ++n; }
+                    }
+                }
+                resv = s / (double)n;
+            }
+            a.out[y * a.ld_out + x] = resv;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- host side
 int plan_tile(KxkArgs &a, size_t *lds_bytes) {
     const int rx = a.kcols / 2;
@@ -718,6 +819,17 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
     a.in = in_dev; a.out = out_dev; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
     a.halo_top = halo_top; a.halo_bot = halo_bot; a.n_excl = n_excludes;
     for (int i = 0; i < n_excludes; ++i) a.excl[i] = excludes[i];
+    const bool vec = (cols % 4 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in_dev) && aligned16(out_dev);
+    if (vec) {
+        const long tiles_x = (cols + TW - 1) / TW, n_tiles = tiles_x * ((rows + 15) / 16);
+        const unsigned g = (unsigned)xcd_grid(n_tiles);
+        if (in_is_f64)
+            hipLaunchKernelGGL(focal_mean3_strip_kernel<double>, dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+        else
+            hipLaunchKernelGGL(focal_mean3_strip_kernel<float>, dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+        XRS_LAUNCH_CHECK();
+        return 0;
+    }
     const long grid = (rows * cols + 255) / 256;
     if (grid > 0x7fffffffL) return fail("xrs_focal_mean3x3: raster too large");
     if (in_is_f64)

@@ -8,6 +8,8 @@
 // with a grid-stride loop, IEEE float32 / float64 division (bit-exact vs the CPU path).
 #include "xrs_common.h"
 
+#include <cstdlib>
+
 // bit-exact vs the CPU path: no FMA contraction (Numba does not contract either)
 #pragma clang fp contract(off)
 
@@ -54,17 +56,32 @@ __global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
     const long stride = (long)gridDim.x * 256;
     if (VEC) {
         const long n4 = q.n >> 2;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-            const float4 a = reinterpret_cast<const float4 *>(q.a)[i];
-            const float4 b = reinterpret_cast<const float4 *>(q.b)[i];
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (K == K_EVI) c = reinterpret_cast<const float4 *>(q.c)[i];
+        // two independent 16-byte slots per lane per trip: twice the loads in flight
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * stride) {
+            const long j = i + stride;
+            const bool two = j < n4;
+            const float4 a0 = reinterpret_cast<const float4 *>(q.a)[i];
+            const float4 b0 = reinterpret_cast<const float4 *>(q.b)[i];
+            float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = c0, b1 = c0, c1 = c0;
+            if (K == K_EVI) c0 = reinterpret_cast<const float4 *>(q.c)[i];
+            if (two) {
+                a1 = reinterpret_cast<const float4 *>(q.a)[j];
+                b1 = reinterpret_cast<const float4 *>(q.b)[j];
+                if (K == K_EVI) c1 = reinterpret_cast<const float4 *>(q.c)[j];
+            }
             float4 o;
-            o.x = cell<K>(q, a.x, b.x, c.x);
-            o.y = cell<K>(q, a.y, b.y, c.y);
-            o.z = cell<K>(q, a.z, b.z, c.z);
-            o.w = cell<K>(q, a.w, b.w, c.w);
+            o.x = cell<K>(q, a0.x, b0.x, c0.x);
+            o.y = cell<K>(q, a0.y, b0.y, c0.y);
+            o.z = cell<K>(q, a0.z, b0.z, c0.z);
+            o.w = cell<K>(q, a0.w, b0.w, c0.w);
             reinterpret_cast<float4 *>(q.out)[i] = o;
+            if (two) {
+                o.x = cell<K>(q, a1.x, b1.x, c1.x);
+                o.y = cell<K>(q, a1.y, b1.y, c1.y);
+                o.z = cell<K>(q, a1.z, b1.z, c1.z);
+                o.w = cell<K>(q, a1.w, b1.w, c1.w);
+                reinterpret_cast<float4 *>(q.out)[j] = o;
+            }
         }
         // tail (n % 4 cells)
         const long t = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x;
@@ -75,10 +92,57 @@ __global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
     }
 }
 
+// One-shot streaming variant for 16-byte aligned planes: workgroup b owns one contiguous 16 KiB chunk
+// (256 lanes x 4 float4) of every plane, chunks are dealt to the XCDs in contiguous runs
+// (xrs::xcd_tile), and a lane's four slots are a wave-interleaved 1 KiB apart so every load/store
+// instruction of a wave covers 1 KiB of consecutive addresses.  All loads are issued before the first use.
+template <int K>
+__global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, const long n_chunks) {
+    const long chunk = xcd_tile(blockIdx.x, n_chunks);
+    if (chunk < 0) return;
+    const long n4 = q.n >> 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long base = chunk * 1024 + wave * 256 + lane;       // in float4 slots; +64 per unrolled slot
+    float4 a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = base + 64 * u;
+        a[u] = b[u] = c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            a[u] = reinterpret_cast<const float4 *>(q.a)[i];
+            b[u] = reinterpret_cast<const float4 *>(q.b)[i];
+            if (K == K_EVI) c[u] = reinterpret_cast<const float4 *>(q.c)[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = base + 64 * u;
+        if (i < n4) {
+            float4 o;
+            o.x = cell<K>(q, a[u].x, b[u].x, c[u].x);
+            o.y = cell<K>(q, a[u].y, b[u].y, c[u].y);
+            o.z = cell<K>(q, a[u].z, b[u].z, c[u].z);
+            o.w = cell<K>(q, a[u].w, b[u].w, c[u].w);
+            reinterpret_cast<float4 *>(q.out)[i] = o;
+        }
+    }
+    if (chunk == 0) {                                          // n % 4 trailing cells
+        const long t = (n4 << 2) + threadIdx.x;
+        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], K == K_EVI ? q.c[t] : 0.f);
+    }
+}
+
 template <int K>
 int launch(const CellArgs &q, hipStream_t s) {
     if (q.n <= 0) return 0;
     const bool vec = aligned16(q.a) && aligned16(q.b) && aligned16(q.out) && (K != K_EVI || aligned16(q.c));
+    const char *variant = getenv("XRS_PERCELL_VARIANT");
+    if (vec && !(variant && variant[0] == 'g')) {              // default: one-shot chunks ('g' = grid-stride, for A/B)
+        const long n_chunks = ((q.n >> 2) + 1023) / 1024 > 0 ? ((q.n >> 2) + 1023) / 1024 : 1;
+        hipLaunchKernelGGL((percell_chunk_kernel<K>), dim3((unsigned)xcd_grid(n_chunks)), dim3(256), 0, s, q, n_chunks);
+        XRS_LAUNCH_CHECK();
+        return 0;
+    }
     const long work = vec ? ((q.n + 3) >> 2) : q.n;
     long grid = (work + 255) / 256;
     const long cap = 256L * 16;            // 256 CUs x 16 workgroups, grid-stride beyond

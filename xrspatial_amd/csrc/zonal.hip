@@ -19,6 +19,8 @@
 // at the 1e-16 level.
 #include "xrs_common.h"
 
+#include <rocprim/warp/warp_reduce.hpp>
+
 using namespace xrs;
 
 namespace {
@@ -130,27 +132,43 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
 
     const long n4 = VEC ? (a.n >> 2) : 0;
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4 + (stride - n4 % stride) % stride; i += stride) {
-        // (loop bound padded to a multiple of the stride so whole waves stay converged for the shuffles)
-        int z[4] = {-1, -1, -1, -1};
-        VT v[4] = {0, 0, 0, 0};
-        if (i < n4) {
-            const int4 zi = reinterpret_cast<const int4 *>(a.zidx)[i];
-            z[0] = zi.x; z[1] = zi.y; z[2] = zi.z; z[3] = zi.w;
-            if constexpr (sizeof(VT) == 4) {
-                const float4 vf = reinterpret_cast<const float4 *>(a.vals)[i];
-                v[0] = vf.x; v[1] = vf.y; v[2] = vf.z; v[3] = vf.w;
-            } else {
-                const double2 va = reinterpret_cast<const double2 *>(a.vals)[2 * i];
-                const double2 vb = reinterpret_cast<const double2 *>(a.vals)[2 * i + 1];
-                v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[3] = vb.y;
+    // Each workgroup streams ONE contiguous chunk of the raster (chunks dealt to XCDs in contiguous runs),
+    // not a grid-strided comb: contiguous chunks measured 1.3x faster on the per-cell kernels, and a chunk
+    // of a real zone raster touches few zones, so the LDS flush at the end is short.
+    const long n_chunks = gridDim.x;                                           // a multiple of 8
+    const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
+    const long per_chunk = ((n4 + n_chunks - 1) / n_chunks + 1023) & ~1023L;    // multiple of one workgroup trip
+    const long c_begin = my_chunk * per_chunk;
+    const long c_end = (my_chunk < n_chunks && c_begin < n4) ? (c_begin + per_chunk < n4 ? c_begin + per_chunk : n4) : c_begin;
+    constexpr int U = 4;                    // 16-byte slots per lane per trip, 64 slots apart: a wave covers 1024
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // consecutive cells per load instruction
+    for (long i0 = c_begin; i0 < c_end; i0 += 256 * U) {
+        // (whole waves stay converged for the reductions: the loop bound is wave-uniform)
+        int z[4 * U];
+        VT v[4 * U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + wave * (64 * U) + lane + 64 * u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { z[4 * u + k] = -1; v[4 * u + k] = 0; }
+            if (i < c_end) {
+                const int4 zi = reinterpret_cast<const int4 *>(a.zidx)[i];
+                z[4 * u] = zi.x; z[4 * u + 1] = zi.y; z[4 * u + 2] = zi.z; z[4 * u + 3] = zi.w;
+                if constexpr (sizeof(VT) == 4) {
+                    const float4 vf = reinterpret_cast<const float4 *>(a.vals)[i];
+                    v[4 * u] = vf.x; v[4 * u + 1] = vf.y; v[4 * u + 2] = vf.z; v[4 * u + 3] = vf.w;
+                } else {
+                    const double2 va = reinterpret_cast<const double2 *>(a.vals)[2 * i];
+                    const double2 vb = reinterpret_cast<const double2 *>(a.vals)[2 * i + 1];
+                    v[4 * u] = va.x; v[4 * u + 1] = va.y; v[4 * u + 2] = vb.x; v[4 * u + 3] = vb.y;
+                }
             }
         }
-        // fold the lane's 4 cells while they stay in one zone; spill the partial when the zone changes
+        // fold the lane's 16 cells while they stay in one zone; spill the partial when the zone changes
         Part<VT> p; p.z = -1; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
         bool lane_single = true;       // all valid cells of this lane fell into p.z
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4 * U; ++k) {
             if (!cell_ok(a, z[k], v[k])) continue;
             if (p.z >= 0 && p.z != z[k]) {
                 acc.add(p);
@@ -169,15 +187,15 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
         const int z0 = __shfl(p.z, first);
         const bool uniform = __all((p.z < 0 || p.z == z0) && lane_single);
         if (uniform) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                p.c += __shfl_down(p.c, off);
-                p.s += __shfl_down(p.s, off);
-                p.q += __shfl_down(p.q, off);
-                const VT omn = __shfl_down(p.mn, off), omx = __shfl_down(p.mx, off);
-                p.mn = omn < p.mn ? omn : p.mn;
-                p.mx = omx > p.mx ? omx : p.mx;
-            }
+            // wave64 reductions with DPP cross-lane moves (VALU only: the LDS pipe stays free for the atomics)
+            rocprim::warp_reduce<unsigned, 64>::storage_type su;
+            rocprim::warp_reduce<double, 64>::storage_type sd;
+            typename rocprim::warp_reduce<VT, 64>::storage_type sv;
+            rocprim::warp_reduce<unsigned, 64>().reduce(p.c, p.c, su);
+            rocprim::warp_reduce<double, 64>().reduce(p.s, p.s, sd);
+            rocprim::warp_reduce<double, 64>().reduce(p.q, p.q, sd);
+            rocprim::warp_reduce<VT, 64>().reduce(p.mn, p.mn, sv, rocprim::minimum<VT>());
+            rocprim::warp_reduce<VT, 64>().reduce(p.mx, p.mx, sv, rocprim::maximum<VT>());
             if ((threadIdx.x & 63) == 0) { p.z = z0; acc.add(p); }
         } else if (p.z >= 0) {
             acc.add(p);
@@ -248,9 +266,10 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     const size_t smem = lds ? (size_t)n_zones * per_zone : 0;
     // a u32 per-workgroup count cannot overflow: cap the cells one workgroup can see below 2^32
     long grid = ((vec ? (n + 3) / 4 : n) + 255) / 256;
-    const long cap = 256L * 8;                  // 256 CUs x 8 workgroups, grid-stride beyond
+    const long cap = 256L * 8;                                   // 8 chunks per CU
     if (grid > cap) grid = cap;
     if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;
+    grid = xcd_grid(grid);                                       // multiple of 8: chunk <-> XCD mapping is a bijection
     hipStream_t s = as_stream(stream);
 #define XRS_ZL(L, V) hipLaunchKernelGGL((zonal_kernel<VT, L, V>), dim3((unsigned)grid), dim3(256), smem, s, a)
     if (lds && vec) XRS_ZL(true, true);

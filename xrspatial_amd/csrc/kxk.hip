@@ -339,16 +339,16 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
 // Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
 // row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
 // sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
+// Strip loader shared by the register-resident kernels: v[r][0..NV) = columns x0-RX .. x0+3+RX of input
+// row y0 - RY + r (NaN outside the raster / the shard's halo rows).  INTERIOR: no predicates at all.
 template <int KH, int KW, int RB, bool INTERIOR>
-__device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
+__device__ __forceinline__ void load_strip(const KxkArgs &a, long x_tile, long y0, int lane,
+                                           float (&v)[RB + KH - 1][4 + 2 * (KW / 2)]) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const long x0 = x_tile + lane * 4;
     const unsigned loff = (unsigned)lane * 4u;
     const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
     const float qnan = nan_f32();
-
-    // v[r][0..NV) = columns x0-RX .. x0+3+RX of input row y0 - RY + r
-    float v[NR][NV];
     const bool has_l = INTERIOR || x0 >= 4;          // x0 is a multiple of 4 and RX <= 3
     const bool has_r = INTERIOR || x0 + 8 <= a.cols;
 #pragma unroll
@@ -375,6 +375,20 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
             }
         }
     }
+}
+
+template <int KH, int KW, int RB>
+__device__ __forceinline__ bool strip_is_interior(const KxkArgs &a, long x_tile, long y0) {
+    return x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - KH / 2 >= -(long)a.halo_top &&
+           y0 + RB + KH / 2 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
+}
+
+template <int KH, int KW, int RB, bool INTERIOR>
+__device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
+    constexpr int RX = KW / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
+    const unsigned loff = (unsigned)lane * 4u;
+    float v[NR][NV];
+    load_strip<KH, KW, RB, INTERIOR>(a, x_tile, y0, lane, v);
 
     float *out = a.out[XRS_STAT_MEAN] + y0 * a.ld_out + x_tile;      // scalar
     if (INTERIOR) {
@@ -452,11 +466,170 @@ __global__ void __launch_bounds__(256, 4) focal_mean_direct_kernel(const KxkArgs
     const long x_tile = tx * TW;
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
-    const bool interior = x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - KH / 2 >= -(long)a.halo_top &&
-                          y0 + RB + KH / 2 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
-    if (interior && focal_mean_direct_body<KH, KW, RB, true>(a, x_tile, y0, lane)) return;
+    if (strip_is_interior<KH, KW, RB>(a, x_tile, y0) && focal_mean_direct_body<KH, KW, RB, true>(a, x_tile, y0, lane)) return;
     if (x_tile + lane * 4 >= a.cols) return;
     focal_mean_direct_body<KH, KW, RB, false>(a, x_tile, y0, lane);
+}
+
+// All seven statistics, compile-time 3x3 / 5x5 shape, register-resident strip (same layout as the mean
+// kernel).  Per output row the window is walked row-major straight out of the lane's registers: float64
+// sum, float32 row-major sum, min, max in pass 1, squared deviations from the float64 mean in pass 2 (the
+// reference's two-pass nanvar).  CAREFUL = the strip touches a raster edge or holds a non-finite cell:
+// NaN cells are skipped and counted; otherwise the count is the constant number of taps.
+template <int KH, int KW, int RB, bool INTERIOR, bool CAREFUL>
+__device__ __forceinline__ void focal_stats_direct_rows(const KxkArgs &a, long x_tile, long y0, int lane,
+                                                        const float (&v)[RB + KH - 1][4 + 2 * (KW / 2)]) {
+    const unsigned loff = (unsigned)lane * 4u;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (!INTERIOR && y0 + r >= a.rows) break;
+        double sum64[4] = {0, 0, 0, 0}, ssd[4] = {0, 0, 0, 0}, mean[4];
+        int cnt[4] = {0, 0, 0, 0};
+        float sum32[4] = {0, 0, 0, 0};
+        float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+                if (bits >> kx & 1u) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float x = v[r + ky][kx + o];
+                        if (CAREFUL) {
+                            const bool ok = !isnan(x);
+                            sum64[o] += ok ? (double)x : 0.0;
+                            cnt[o] += ok ? 1 : 0;
+                            sum32[o] = ok ? sum32[o] + x : sum32[o];
+                        } else {
+                            sum64[o] += (double)x;
+                            sum32[o] += x;
+                        }
+                        mn[o] = fminf(mn[o], x);
+                        mx[o] = fmaxf(mx[o], x);
+                    }
+                }
+        }
+        double inv[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            inv[o] = CAREFUL ? rcp_count(cnt[o]) : a.inv_ntaps;
+            mean[o] = sum64[o] * inv[o];
+        }
+        if (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR]) {
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const float x = v[r + ky][kx + o];
+                            const double d = (double)x - mean[o];
+                            ssd[o] += (CAREFUL && isnan(x)) ? 0.0 : d * d;
+                        }
+                    }
+            }
+        }
+        const long off = (y0 + r) * a.ld_out + x_tile + loff;
+        const bool none[4] = {CAREFUL && !cnt[0], CAREFUL && !cnt[1], CAREFUL && !cnt[2], CAREFUL && !cnt[3]};
+        const float qn = nan_f32();
+        auto put = [&](int stat, float x0, float x1, float x2, float x3) {
+            if (a.out[stat]) *reinterpret_cast<float4 *>(a.out[stat] + off) = make_float4(x0, x1, x2, x3);
+        };
+        put(XRS_STAT_MEAN, (float)mean[0], (float)mean[1], (float)mean[2], (float)mean[3]);
+        put(XRS_STAT_MAX, none[0] ? qn : mx[0], none[1] ? qn : mx[1], none[2] ? qn : mx[2], none[3] ? qn : mx[3]);
+        put(XRS_STAT_MIN, none[0] ? qn : mn[0], none[1] ? qn : mn[1], none[2] ? qn : mn[2], none[3] ? qn : mn[3]);
+        put(XRS_STAT_RANGE, none[0] ? qn : mx[0] - mn[0], none[1] ? qn : mx[1] - mn[1], none[2] ? qn : mx[2] - mn[2],
+            none[3] ? qn : mx[3] - mn[3]);
+        put(XRS_STAT_SUM, sum32[0], sum32[1], sum32[2], sum32[3]);
+        double var[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) var[o] = ssd[o] * inv[o];
+        put(XRS_STAT_VAR, (float)var[0], (float)var[1], (float)var[2], (float)var[3]);
+        put(XRS_STAT_STD, (float)sqrt(var[0]), (float)sqrt(var[1]), (float)sqrt(var[2]), (float)sqrt(var[3]));
+    }
+}
+
+template <int KH, int KW, int RB>
+__global__ void __launch_bounds__(256) focal_stats_direct_kernel(const KxkArgs a) {
+    constexpr int NV = 4 + 2 * (KW / 2), NR = RB + KH - 1;
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = tx * TW;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    float v[NR][NV];
+    if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
+        load_strip<KH, KW, RB, true>(a, x_tile, y0, lane, v);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) bad |= !isfinite(v[r][i]);
+        if (!__any(bad)) focal_stats_direct_rows<KH, KW, RB, true, false>(a, x_tile, y0, lane, v);
+        else focal_stats_direct_rows<KH, KW, RB, true, true>(a, x_tile, y0, lane, v);
+    } else {
+        if (x_tile + lane * 4 >= a.cols) return;
+        load_strip<KH, KW, RB, false>(a, x_tile, y0, lane, v);
+        focal_stats_direct_rows<KH, KW, RB, false, true>(a, x_tile, y0, lane, v);
+    }
+}
+
+// convolve_2d, compile-time 3x3 / 5x5 shape, register-resident strip.  NaN (and the out-of-raster NaN
+// fill of edge strips) propagates through the float64 multiply-adds by itself: no special cases.
+template <int KH, int KW, int RB>
+__global__ void __launch_bounds__(256) convolve_direct_kernel(const KxkArgs a) {
+    constexpr int NV = 4 + 2 * (KW / 2), NR = RB + KH - 1;
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = tx * TW;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    float v[NR][NV];
+    const bool interior = strip_is_interior<KH, KW, RB>(a, x_tile, y0);
+    if (interior) {
+        load_strip<KH, KW, RB, true>(a, x_tile, y0, lane, v);
+    } else {
+        if (x_tile + lane * 4 >= a.cols) return;
+        load_strip<KH, KW, RB, false>(a, x_tile, y0, lane, v);
+    }
+    double acc[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+#pragma unroll
+    for (int ir = 0; ir < NR; ++ir) {
+        double d[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int orow = ir - ky;
+            if (orow < 0 || orow >= RB) continue;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const double wt = a.weights[ky * KW + kx];           // wave-uniform: scalar load
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[orow][o] += wt * d[kx + o];
+            }
+        }
+    }
+    const unsigned loff = (unsigned)lane * 4u;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (!interior && y0 + r >= a.rows) break;
+        *reinterpret_cast<float4 *>(a.out[0] + (y0 + r) * a.ld_out + x_tile + loff) =
+            make_float4((float)acc[r][0], (float)acc[r][1], (float)acc[r][2], (float)acc[r][3]);
+    }
 }
 
 // ------------------------------------------------------------------------ convolve_2d
@@ -692,6 +865,25 @@ int launch_mean_direct(KxkArgs a, hipStream_t s) {
     return 0;
 }
 
+template <int KH, int KW>
+int launch_stats_direct(KxkArgs a, hipStream_t s) {
+    constexpr int RB = KH >= 5 ? 1 : 2;          // few rows per wave: the 7 output streams dominate traffic, and
+                                                 // registers (12 per output + the window) set the occupancy
+    a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
+    hipLaunchKernelGGL((focal_stats_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KH, int KW>
+int launch_convolve_direct(KxkArgs a, hipStream_t s) {
+    constexpr int RB = 4;
+    a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
+    hipLaunchKernelGGL((convolve_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
 // XRS_FOCAL_VARIANT=lds forces the LDS-tile kernels for small masks (A/B measurements; default: direct)
 bool prefer_lds() {
     const char *e = getenv("XRS_FOCAL_VARIANT");
@@ -709,6 +901,10 @@ int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
         if (a.krows == 3 && a.kcols == 3) return launch_mean_fast<3, 3>(a, lds, s);
         if (a.krows == 5 && a.kcols == 5) return launch_mean_fast<5, 5>(a, lds, s);
         if (a.krows == 7 && a.kcols == 7) return launch_mean_fast<7, 7>(a, lds, s);
+    }
+    if (!MEAN_ONLY && vec && !prefer_lds()) {
+        if (a.krows == 3 && a.kcols == 3) return launch_stats_direct<3, 3>(a, s);
+        if (a.krows == 5 && a.kcols == 5) return launch_stats_direct<5, 5>(a, s);
     }
     // (the unrolled all-statistics bodies need > 170 VGPRs beyond 3x3; the runtime walk needs ~72)
     if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY>(a, vec, lds, s);
@@ -750,6 +946,8 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
         if (vec) hipLaunchKernelGGL((convolve_kernel<KH, KW, true>), dim3(grid), dim3(256), lds, s, a);  \
         else hipLaunchKernelGGL((convolve_kernel<KH, KW, false>), dim3(grid), dim3(256), lds, s, a);     \
     } while (0)
+    if (vec && !prefer_lds() && krows == 3 && kcols == 3) return launch_convolve_direct<3, 3>(a, s);
+    if (vec && !prefer_lds() && krows == 5 && kcols == 5) return launch_convolve_direct<5, 5>(a, s);
     if (krows == 3 && kcols == 3) XRS_CONV(3, 3);
     else if (krows == 5 && kcols == 5) XRS_CONV(5, 5);
     else XRS_CONV(0, 0);

@@ -102,6 +102,15 @@ int xrs_evi_f32(const float *nir_dev, const float *red_dev, const float *blue_de
                 int64_t n, double c1, double c2, double soil_factor, double gain, void *stream);
 int xrs_savi_f32(const float *nir_dev, const float *red_dev, float *out_dev, int64_t n,
                  double soil_factor, void *stream);
+/*   arvi  xrspatial/multispectral.py:29-43     gci   :350-361
+ *   sipi  xrspatial/multispectral.py:1017-1031 ebbi  :1160-1174 */
+int xrs_arvi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev,
+                 int64_t n, void *stream);
+int xrs_gci_f32(const float *nir_dev, const float *green_dev, float *out_dev, int64_t n, void *stream);
+int xrs_sipi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev,
+                 int64_t n, void *stream);
+int xrs_ebbi_f32(const float *red_dev, const float *swir_dev, const float *tir_dev, float *out_dev,
+                 int64_t n, void *stream);
 
 /* ------------------------------------------------------------- k x k kernels
  * convolve2d: correlation with a float64 weight matrix given on the HOST

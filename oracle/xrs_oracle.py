@@ -197,6 +197,52 @@ def savi(nir, red, soil_factor=1.0):
     return out
 
 
+def arvi(nir, red, blue):
+    """Reference: xrspatial/multispectral.py:29-43 (`_arvi_cpu`): `2.0 * red` promotes to float64."""
+    n, r, b = (np.asarray(x).astype(F32).astype(F64) for x in (nir, red, blue))
+    out = _nan_like(n.shape)
+    with np.errstate(all="ignore"):
+        num = n - 2.0 * r + b
+        den = n + 2.0 * r + b
+        ok = den != 0.0
+        out[ok] = (num / den)[ok].astype(F32)
+    return out
+
+
+def gci(nir, green):
+    """Reference: xrspatial/multispectral.py:350-361 (`_gci_cpu`): float32 quotient, `- 1` in float64."""
+    n, g = np.asarray(nir).astype(F32), np.asarray(green).astype(F32)
+    out = _nan_like(n.shape)
+    with np.errstate(all="ignore"):
+        ok = g != 0
+        q = np.divide(n, g, out=np.zeros_like(n), where=ok)
+        out[ok] = (q.astype(F64) - 1)[ok].astype(F32)
+    return out
+
+
+def sipi(nir, red, blue):
+    """Reference: xrspatial/multispectral.py:1017-1031 (`_sipi_cpu`): pure float32."""
+    n, r, b = (np.asarray(x).astype(F32) for x in (nir, red, blue))
+    out = _nan_like(n.shape)
+    with np.errstate(all="ignore"):
+        num, den = n - b, n - r
+        ok = ~(den == 0.0)
+        np.divide(num, den, out=out, where=ok)
+    return out
+
+
+def ebbi(red, swir, tir):
+    """Reference: xrspatial/multispectral.py:1160-1174 (`_ebbi_cpu`): float32 sqrt, `10 *` in float64."""
+    r, s, t = (np.asarray(x).astype(F32) for x in (red, swir, tir))
+    out = _nan_like(r.shape)
+    with np.errstate(all="ignore"):
+        num = (s - r).astype(F64)
+        den = 10 * np.sqrt(s + t).astype(F64)
+        ok = den != 0.0                      # NaN != 0 is True: NaN denominators store NaN, like the reference
+        out[ok] = (num / den)[ok].astype(F32)
+    return out
+
+
 # --------------------------------------------------------------------------
 # k x k kernels
 # --------------------------------------------------------------------------

@@ -172,6 +172,23 @@ def test_multispectral_qgis(golden):
                                rtol=1e-6, equal_nan=True)
 
 
+def test_multispectral_other_indices_qgis(golden):
+    # xrspatial/tests/test_multispectral.py:114-128, 235-283, 429-590 (arvi, gci, sipi, ebbi)
+    nir, red, blue, green = golden["ms_nir"], golden["ms_red"], golden["ms_blue"], golden["ms_green"]
+    np.testing.assert_allclose(orc.arvi(nir, red, blue), golden["qgis_arvi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.gci(nir, green), golden["qgis_gci"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.sipi(nir, red, blue), golden["qgis_sipi"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(orc.ebbi(red, golden["ms_swir1"], golden["ms_tir"]), golden["qgis_ebbi"],
+                               rtol=1e-6, equal_nan=True)
+    for dtype in ("uint8", "uint16"):
+        n, r, b, exp = (golden["uint_arvi__%d" % i] for i in range(4))
+        np.testing.assert_allclose(orc.arvi(n.astype(dtype), r.astype(dtype), b.astype(dtype)), exp, rtol=1e-6)
+        n, r, b, exp = (golden["uint_sipi__%d" % i] for i in range(4))
+        np.testing.assert_allclose(orc.sipi(n.astype(dtype), r.astype(dtype), b.astype(dtype)), exp, rtol=1e-6)
+        r, sw, t, exp = (golden["uint_ebbi__%d" % i] for i in range(4))
+        np.testing.assert_allclose(orc.ebbi(r.astype(dtype), sw.astype(dtype), t.astype(dtype)), exp, rtol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", ["uint8", "uint16"])
 def test_multispectral_uint(golden, dtype):
     # xrspatial/tests/test_multispectral.py:286-336

@@ -18,7 +18,7 @@ from .aspect import aspect  # noqa: F401
 from .curvature import curvature  # noqa: F401
 from .focal import mean  # noqa: F401
 from .hillshade import hillshade  # noqa: F401
-from .multispectral import evi, nbr, ndvi, savi  # noqa: F401
+from .multispectral import arvi, evi, nbr, ndvi, savi, sipi  # noqa: F401
 from .slope import slope  # noqa: F401
 from .zonal import stats as zonal_stats  # noqa: F401
 

@@ -63,6 +63,10 @@ _PROTOTYPES = {
     "xrs_evi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double,
                     c_void_p],
     "xrs_savi_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_double, c_void_p],
+    "xrs_arvi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "xrs_gci_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "xrs_sipi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "xrs_ebbi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrs_kxk_workspace_bytes": [c_int, c_int],
     "xrs_convolve2d_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
                            c_void_p, c_int, c_int, c_void_p],

@@ -1,9 +1,10 @@
-// Per-cell multispectral indices: ndvi (normalized ratio), evi, savi.
+// Per-cell multispectral indices: ndvi (normalized ratio; also nbr, nbr2, ndmi), evi, savi, arvi, gci, sipi, ebbi.
 //
 // Reference runners replaced:
 //   _normalized_ratio_cpu  xrspatial/multispectral.py:825-841  (pure float32)
 //   _evi_cpu               xrspatial/multispectral.py:175-188  (float64 denominator)
 //   _savi_cpu              xrspatial/multispectral.py:876-890  (float64 once L enters)
+//   _arvi_cpu :29-43, _gci_cpu :350-361, _sipi_cpu :1017-1031, _ebbi_cpu :1160-1174
 // Streaming kernels, 12-16 B/cell, no reuse: 16-byte loads/stores, a capped grid
 // with a grid-stride loop, IEEE float32 / float64 division (bit-exact vs the CPU path).
 #include "xrs_common.h"
@@ -42,12 +43,44 @@ struct CellArgs {
     double p0, p1, p2, p3;
 };
 
-enum : int { K_NRATIO = 0, K_EVI = 1, K_SAVI = 2 };
+enum : int { K_NRATIO = 0, K_EVI = 1, K_SAVI = 2, K_ARVI = 3, K_GCI = 4, K_SIPI = 5, K_EBBI = 6 };
+
+// number of input planes of each index
+template <int K> struct Bands { static constexpr int n = (K == K_EVI || K == K_ARVI || K == K_SIPI || K == K_EBBI) ? 3 : 2; };
+
+__device__ __forceinline__ float arvi1(float nir, float red, float blue) {
+    // multispectral.py:39-42: 2.0 * red promotes to float64
+    const double num = (double)nir - 2.0 * (double)red + (double)blue;
+    const double den = (double)nir + 2.0 * (double)red + (double)blue;
+    return den != 0.0 ? (float)(num / den) : nan_f32();
+}
+
+__device__ __forceinline__ float gci1(float nir, float green) {
+    // multispectral.py:358-359: float32 quotient, then `- 1` (int literal) in float64
+    return green != 0.0f ? (float)((double)(nir / green) - 1.0) : nan_f32();
+}
+
+__device__ __forceinline__ float sipi1(float nir, float red, float blue) {
+    // multispectral.py:1027-1030: pure float32
+    const float num = nir - blue, den = nir - red;
+    return den != 0.0f ? num / den : nan_f32();
+}
+
+__device__ __forceinline__ float ebbi1(float red, float swir, float tir) {
+    // multispectral.py:1170-1173: float32 sqrt of the float32 sum, then 10 * (int literal) in float64
+    const float num = swir - red;
+    const double den = 10.0 * (double)sqrtf(swir + tir);
+    return den != 0.0 ? (float)((double)num / den) : nan_f32();
+}
 
 template <int K>
 __device__ __forceinline__ float cell(const CellArgs &q, float a, float b, float c) {
     if (K == K_NRATIO) return nratio(a, b);
     if (K == K_EVI) return evi1(a, b, c, q.p0, q.p1, q.p2, q.p3);
+    if (K == K_ARVI) return arvi1(a, b, c);
+    if (K == K_GCI) return gci1(a, b);
+    if (K == K_SIPI) return sipi1(a, b, c);
+    if (K == K_EBBI) return ebbi1(a, b, c);
     return savi1(a, b, q.p0, q.p1);
 }
 
@@ -63,11 +96,11 @@ __global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
             const float4 a0 = reinterpret_cast<const float4 *>(q.a)[i];
             const float4 b0 = reinterpret_cast<const float4 *>(q.b)[i];
             float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = c0, b1 = c0, c1 = c0;
-            if (K == K_EVI) c0 = reinterpret_cast<const float4 *>(q.c)[i];
+            if (Bands<K>::n == 3) c0 = reinterpret_cast<const float4 *>(q.c)[i];
             if (two) {
                 a1 = reinterpret_cast<const float4 *>(q.a)[j];
                 b1 = reinterpret_cast<const float4 *>(q.b)[j];
-                if (K == K_EVI) c1 = reinterpret_cast<const float4 *>(q.c)[j];
+                if (Bands<K>::n == 3) c1 = reinterpret_cast<const float4 *>(q.c)[j];
             }
             float4 o;
             o.x = cell<K>(q, a0.x, b0.x, c0.x);
@@ -85,10 +118,10 @@ __global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
         }
         // tail (n % 4 cells)
         const long t = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x;
-        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], K == K_EVI ? q.c[t] : 0.f);
+        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], Bands<K>::n == 3 ? q.c[t] : 0.f);
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < q.n; i += stride)
-            q.out[i] = cell<K>(q, q.a[i], q.b[i], K == K_EVI ? q.c[i] : 0.f);
+            q.out[i] = cell<K>(q, q.a[i], q.b[i], Bands<K>::n == 3 ? q.c[i] : 0.f);
     }
 }
 
@@ -111,7 +144,7 @@ __global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, co
         if (i < n4) {
             a[u] = reinterpret_cast<const float4 *>(q.a)[i];
             b[u] = reinterpret_cast<const float4 *>(q.b)[i];
-            if (K == K_EVI) c[u] = reinterpret_cast<const float4 *>(q.c)[i];
+            if (Bands<K>::n == 3) c[u] = reinterpret_cast<const float4 *>(q.c)[i];
         }
     }
 #pragma unroll
@@ -128,14 +161,14 @@ __global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, co
     }
     if (chunk == 0) {                                          // n % 4 trailing cells
         const long t = (n4 << 2) + threadIdx.x;
-        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], K == K_EVI ? q.c[t] : 0.f);
+        if (t < q.n) q.out[t] = cell<K>(q, q.a[t], q.b[t], Bands<K>::n == 3 ? q.c[t] : 0.f);
     }
 }
 
 template <int K>
 int launch(const CellArgs &q, hipStream_t s) {
     if (q.n <= 0) return 0;
-    const bool vec = aligned16(q.a) && aligned16(q.b) && aligned16(q.out) && (K != K_EVI || aligned16(q.c));
+    const bool vec = aligned16(q.a) && aligned16(q.b) && aligned16(q.out) && (Bands<K>::n != 3 || aligned16(q.c));
     const char *variant = getenv("XRS_PERCELL_VARIANT");
     if (vec && !(variant && variant[0] == 'g')) {              // default: one-shot chunks ('g' = grid-stride, for A/B)
         const long n_chunks = ((q.n >> 2) + 1023) / 1024 > 0 ? ((q.n >> 2) + 1023) / 1024 : 1;
@@ -178,6 +211,33 @@ int xrs_savi_f32(const float *nir_dev, const float *red_dev, float *out_dev, int
     if (n > 0 && (!nir_dev || !red_dev || !out_dev)) return fail("xrs_savi_f32: null pointer");
     CellArgs q{nir_dev, red_dev, nullptr, out_dev, n, soil_factor, 1.0 + soil_factor, 0, 0};
     return launch<K_SAVI>(q, as_stream(stream));
+}
+
+int xrs_arvi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev, int64_t n,
+                 void *stream) {
+    if (n > 0 && (!nir_dev || !red_dev || !blue_dev || !out_dev)) return fail("xrs_arvi_f32: null pointer");
+    CellArgs q{nir_dev, red_dev, blue_dev, out_dev, n, 0, 0, 0, 0};
+    return launch<K_ARVI>(q, as_stream(stream));
+}
+
+int xrs_gci_f32(const float *nir_dev, const float *green_dev, float *out_dev, int64_t n, void *stream) {
+    if (n > 0 && (!nir_dev || !green_dev || !out_dev)) return fail("xrs_gci_f32: null pointer");
+    CellArgs q{nir_dev, green_dev, nullptr, out_dev, n, 0, 0, 0, 0};
+    return launch<K_GCI>(q, as_stream(stream));
+}
+
+int xrs_sipi_f32(const float *nir_dev, const float *red_dev, const float *blue_dev, float *out_dev, int64_t n,
+                 void *stream) {
+    if (n > 0 && (!nir_dev || !red_dev || !blue_dev || !out_dev)) return fail("xrs_sipi_f32: null pointer");
+    CellArgs q{nir_dev, red_dev, blue_dev, out_dev, n, 0, 0, 0, 0};
+    return launch<K_SIPI>(q, as_stream(stream));
+}
+
+int xrs_ebbi_f32(const float *red_dev, const float *swir_dev, const float *tir_dev, float *out_dev, int64_t n,
+                 void *stream) {
+    if (n > 0 && (!red_dev || !swir_dev || !tir_dev || !out_dev)) return fail("xrs_ebbi_f32: null pointer");
+    CellArgs q{red_dev, swir_dev, tir_dev, out_dev, n, 0, 0, 0, 0};
+    return launch<K_EBBI>(q, as_stream(stream));
 }
 
 }  // extern "C"

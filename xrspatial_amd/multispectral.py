@@ -1,5 +1,6 @@
-"""Per-cell multispectral indices: ndvi, evi, savi (and the other normalized-ratio
-indices that share ndvi's kernel: nbr, nbr2, ndmi).  Reference: xrspatial/multispectral.py.
+"""Per-cell multispectral indices: ndvi, evi, savi, the other normalized-ratio indices that share
+ndvi's kernel (nbr, nbr2, ndmi) and arvi, gci, sipi, ebbi.  Reference: xrspatial/multispectral.py.
+(`true_color` is an RGBA image composer, not a raster index: out of scope.)
 """
 from __future__ import annotations
 
@@ -100,3 +101,41 @@ def savi(nir_agg, red_agg, soil_factor=1.0, name='savi'):
 
     mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
     return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data), name, nir_agg)
+
+
+def _simple_index(fn_name, like, bands, name, order=None):
+    """validate, run a parameter-free per-cell kernel on `bands`, wrap with `like`'s metadata."""
+    validate_arrays(*(order or bands))
+
+    def run(*arrays):
+        return _percell(fn_name, arrays, ())
+
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    return _wrap(mapper(like)(*[b.data for b in bands]), name, like)
+
+
+@supports_dataset_bands(nir='nir_agg', red='red_agg', blue='blue_agg')
+def arvi(nir_agg, red_agg, blue_agg, name='arvi'):
+    """Atmospherically Resistant Vegetation Index (nir - 2*red + blue) / (nir + 2*red + blue).
+    Same signature and float32 results as `xrspatial.multispectral.arvi` (:79-171)."""
+    return _simple_index("xrs_arvi_f32", nir_agg, (nir_agg, red_agg, blue_agg), name,
+                         order=(red_agg, nir_agg, blue_agg))
+
+
+@supports_dataset_bands(nir='nir_agg', green='green_agg')
+def gci(nir_agg, green_agg, name='gci'):
+    """Green Chlorophyll Index nir / green - 1; NaN where green == 0  (multispectral.py:392-472)."""
+    return _simple_index("xrs_gci_f32", nir_agg, (nir_agg, green_agg), name)
+
+
+@supports_dataset_bands(nir='nir_agg', red='red_agg', blue='blue_agg')
+def sipi(nir_agg, red_agg, blue_agg, name='sipi'):
+    """Structure Insensitive Pigment Index (nir - blue) / (nir - red)  (multispectral.py:1066-1156)."""
+    return _simple_index("xrs_sipi_f32", nir_agg, (nir_agg, red_agg, blue_agg), name,
+                         order=(red_agg, nir_agg, blue_agg))
+
+
+@supports_dataset_bands(red='red_agg', swir='swir_agg', tir='tir_agg')
+def ebbi(red_agg, swir_agg, tir_agg, name='ebbi'):
+    """Enhanced Built-Up and Bareness Index (swir - red) / (10 * sqrt(swir + tir))  (multispectral.py:1209-1332)."""
+    return _simple_index("xrs_ebbi_f32", red_agg, (red_agg, swir_agg, tir_agg), name)

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="experiment: do not record per-kernel HIP events inside the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +135,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(None if args.no_kernel_events else events[k])
     L("xrs_stream_sync", stream)
     L("xrs_device_sync")
     if dist is not None:
@@ -149,12 +151,45 @@ def main():
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     ms = ctypes.c_float()
     hill_ms, focal_ms = [], []
-    for e in events:
+    for e in ([] if args.no_kernel_events else events):
         L("xrs_event_elapsed_ms", e[0], e[1], ctypes.byref(ms))
         hill_ms.append(ms.value)
         L("xrs_event_elapsed_ms", e[1], e[2], ctypes.byref(ms))
         focal_ms.append(ms.value)
-    hill_avg, focal_avg = float(np.mean(hill_ms)), float(np.mean(focal_ms))
+    hill_avg, focal_avg = (float(np.mean(hill_ms)), float(np.mean(focal_ms))) if hill_ms else (float("nan"), float("nan"))
+
+    # Informational, OUTSIDE the timed region (rank 0, N=1): the other kernels of BASELINE configs[1]/[2] on the
+    # same resident raster, and one numpy-in/numpy-out call to quote the PCIe-inclusive rate of the drop-in path.
+    extra = {}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        def timed(fn, reps=5):
+            fn()
+            e0, e1 = make_event(), make_event()
+            L("xrs_stream_sync", stream)
+            L("xrs_event_record", e0, stream)
+            for _ in range(reps):
+                fn()
+            L("xrs_event_record", e1, stream)
+            L("xrs_event_sync", e1)
+            L("xrs_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+            return ms.value / reps
+
+        k25 = np.ascontiguousarray(circle_kernel(1, 1, 12), dtype=np.float64)
+        extra["other_kernels_ms"] = {
+            "slope": round(timed(lambda: L("xrs_slope_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0, 0, 0, stream)), 4),
+            "aspect": round(timed(lambda: L("xrs_aspect_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 0, 0, stream)), 4),
+            "curvature": round(timed(lambda: L("xrs_curvature_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 0, 0, stream)), 4),
+            "focal_mean_25x25_circle": round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols,
+                                                             k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=2), 4),
+        }
+        host_rows = min(rows, 4096)
+        host_dem = synth.asv_dem(host_rows, cols, y0=0, total_rows=total_rows)
+        agg = xs.DataArray(host_dem, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+        xs.hillshade(agg)
+        t_h = time.perf_counter()
+        xs.hillshade(agg)
+        t_h = time.perf_counter() - t_h
+        extra["numpy_in_numpy_out_hillshade_mcells_s"] = round(host_rows * cols / t_h / 1e6, 1)
 
     if rank != 0:
         if dist is not None:
@@ -195,6 +230,7 @@ def main():
             "sharding": "rows" if world > 1 else "none",
             "halo_exchange": f"RCCL send/recv, {HALO} rows per neighbour per step" if world > 1 else None,
             "kernel_ms": {"hillshade": round(hill_avg, 4), "focal_mean_5x5": round(focal_avg, 4)},
+            **extra,
         },
         "roofline": {
             "bound": "hbm",

@@ -126,6 +126,7 @@ def main():
         "focal3_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 8),
         "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
         "focal25_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),
+        "focal25_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 32),
         "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
@@ -137,7 +138,7 @@ def main():
     for name_, (fn, bpc) in cases.items():
         if only and name_ not in only:
             continue
-        reps = 3 if name_ == "focal25_mean" else args.reps
+        reps = 2 if name_.startswith("focal25") else args.reps
         med, mn = timer.time(fn, reps, warmup=2)
         gbs = cells * bpc / (med * 1e-3) / 1e9
         results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs}

@@ -168,6 +168,17 @@ int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev
                            uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                            double *min_dev, double *max_dev, void *stream);
 
+/* Dense zone indexing on the device (replaces the host-side np.unique of xrspatial/zonal.py:290 for
+ * integral zone ids): zone_dtype 0 = int32, 1 = int64, 2 = float32, 3 = float64.
+ *   xrs_zonal_scan      -> result32_dev = { double zmin, zmax; uint64 n_finite; int32 all_integral, pad }
+ *   xrs_zonal_presence  -> present_dev[id - zmin] = 1 for every finite id in [zmin, zmin + range)
+ *   xrs_zonal_index     -> idx_dev[cell] = lut_dev[id - zmin], -1 for non-finite / out-of-range ids */
+int xrs_zonal_scan(const void *zones_dev, int zone_dtype, int64_t n, void *result32_dev, void *stream);
+int xrs_zonal_presence(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
+                       unsigned char *present_dev, void *stream);
+int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
+                    const int32_t *lut_dev, int32_t *idx_dev, void *stream);
+
 /* majority (most frequent valid value per zone, ties -> smallest; NaN for zones without a valid
  * cell), computed by two device radix sorts + run voting; replaces _stats_majority applied per zone
  * (xrspatial/zonal.py:56-68, 144-163).  `work_dev` must hold

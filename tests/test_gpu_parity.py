@@ -348,6 +348,33 @@ def test_zonal_majority_and_dataarray(golden, golden_tables):
         xs.zonal_stats(zones, values, stats_funcs={'double_sum': lambda a: a.sum() * 2})
 
 
+@pytest.mark.parametrize("zdtype", [np.int32, np.int64, np.float32, np.float64])
+def test_zonal_device_resident_zone_indexing(zdtype):
+    """zones already in HBM: ids are mapped to dense indices on the device (scan / presence / index)."""
+    rng = np.random.default_rng(3)
+    zones = (rng.integers(-7, 40, size=(257, 300)) * 3).astype(zdtype)        # gaps in the id range, negative ids
+    if np.issubdtype(zdtype, np.floating):
+        zones[rng.random(zones.shape) < 0.02] = np.nan
+        zones[5, 5] = np.inf
+    vals = synth.asv_dem(257, 300)
+    names = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count', 'majority']
+    got = xs.zonal_stats(raster(zones, backend='hip'), raster(vals, backend='hip'), stats_funcs=names)
+    want = orc.zonal_stats(zones, vals, stats_funcs=names)
+    np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'])
+    assert got['zone'].dtype == zones.dtype
+    for col in ('count', 'max', 'min', 'majority'):
+        np.testing.assert_array_equal(got[col].to_numpy(), want[col], err_msg=col)
+    for col in ('mean', 'sum', 'std', 'var'):
+        np.testing.assert_allclose(got[col].to_numpy(), want[col], rtol=RTOL, err_msg=col)
+    # non-integral ids fall back to the host mapping and still agree
+    if np.issubdtype(zdtype, np.floating):
+        zf = zones + zdtype(0.5)
+        got = xs.zonal_stats(raster(zf, backend='hip'), raster(vals, backend='hip'), stats_funcs=['count'])
+        want = orc.zonal_stats(zf, vals, stats_funcs=['count'])
+        np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'])
+        np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+
+
 def test_zonal_run_to_run_counts_and_many_zones():
     rows, cols = 512, 512
     zones = np.random.default_rng(1).integers(0, 5000, size=(rows, cols)).astype(np.int32)   # > LDS-privatised limit

@@ -1,0 +1,186 @@
+// Dense zone indexing on the device: raw zone rasters (int32 / int64 / float32 / float64, NaN or any
+// non-finite value = "no zone") -> int32 dense indices in [0, n_zones) / -1, without the host ever
+// touching the n-cell raster.
+//
+// The reference obtains the zone list with np.unique(zones[np.isfinite(zones)]) (xrspatial/zonal.py:290),
+// a full host sort.  Zone ids of real rasters are integral and span a small range, so here:
+//   pass 1  xrs_zonal_scan_*      min / max of the finite ids + "all integral" flag (wave reduce + atomics);
+//   pass 2  xrs_zonal_presence_*  byte map present[id - min] = 1 over that range;
+//   host    compacts the (range-sized, not raster-sized) map into the ascending id list and a LUT;
+//   pass 3  xrs_zonal_index_*     idx[cell] = lut[id - min]  (or -1).
+// Non-integral ids or ranges above the caller's limit make the host layer fall back to its own path.
+#include "xrs_common.h"
+
+#include <rocprim/warp/warp_reduce.hpp>
+
+using namespace xrs;
+
+namespace {
+
+struct ScanResult {          // device-resident, 32 bytes
+    double zmin, zmax;
+    unsigned long long n_finite;
+    int all_integral, pad;
+};
+
+template <typename T> __device__ __forceinline__ bool finite_id(T v) { return true; }
+template <> __device__ __forceinline__ bool finite_id<float>(float v) { return isfinite(v); }
+template <> __device__ __forceinline__ bool finite_id<double>(double v) { return isfinite(v); }
+template <typename T> __device__ __forceinline__ bool integral_id(T v) { return true; }
+template <> __device__ __forceinline__ bool integral_id<float>(float v) { return v == floorf(v); }
+template <> __device__ __forceinline__ bool integral_id<double>(double v) { return v == floor(v); }
+
+__device__ __forceinline__ void atomic_min_f64(double *addr, double v) {
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v < __longlong_as_double((long long)old)) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+__device__ __forceinline__ void atomic_max_f64(double *addr, double v) {
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v > __longlong_as_double((long long)old)) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+
+__global__ void scan_init_kernel(ScanResult *r) {
+    r->zmin = INFINITY; r->zmax = -INFINITY; r->n_finite = 0ull; r->all_integral = 1; r->pad = 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResult *res) {
+    double mn = INFINITY, mx = -INFINITY;
+    unsigned cnt = 0;
+    bool integral = true;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const T v = z[i];
+        if (finite_id(v)) {
+            const double d = (double)v;
+            mn = d < mn ? d : mn;
+            mx = d > mx ? d : mx;
+            integral = integral && integral_id(v);
+            ++cnt;
+        }
+    }
+    rocprim::warp_reduce<double, 64>::storage_type sd;
+    rocprim::warp_reduce<unsigned, 64>::storage_type su;
+    rocprim::warp_reduce<double, 64>().reduce(mn, mn, sd, rocprim::minimum<double>());
+    rocprim::warp_reduce<double, 64>().reduce(mx, mx, sd, rocprim::maximum<double>());
+    rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
+    const bool wave_integral = __all(integral);
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) {
+            atomic_min_f64(&res->zmin, mn);
+            atomic_max_f64(&res->zmax, mx);
+            atomicAdd(&res->n_finite, (unsigned long long)cnt);
+        }
+        if (!wave_integral) atomicAnd(&res->all_integral, 0);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) presence_kernel(const T *z, long n, double zmin, long range,
+                                                       unsigned char *present) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const T v = z[i];
+        if (finite_id(v)) {
+            const long off = (long)((double)v - zmin);
+            if (off >= 0 && off < range) present[off] = 1;      // benign race: every writer stores 1
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) index_kernel(const T *z, long n, double zmin, long range,
+                                                    const int32_t *lut, int32_t *idx) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const T v = z[i];
+        int32_t out = -1;
+        if (finite_id(v)) {
+            const long off = (long)((double)v - zmin);
+            if (off >= 0 && off < range) out = lut[off];
+        }
+        idx[i] = out;
+    }
+}
+
+inline unsigned grid_for(long n) {
+    long g = (n + 255) / 256;
+    const long cap = 256L * 16;
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+int scan_impl(const void *zones, long n, void *result32, hipStream_t s) {
+    if (n < 0) return fail("xrs_zonal_scan: negative size");
+    if (!result32 || (n && !zones)) return fail("xrs_zonal_scan: null pointer");
+    ScanResult *r = static_cast<ScanResult *>(result32);
+    hipLaunchKernelGGL(scan_init_kernel, dim3(1), dim3(1), 0, s, r);
+    if (n) hipLaunchKernelGGL(scan_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, r);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int presence_impl(const void *zones, long n, double zmin, long range, unsigned char *present, hipStream_t s) {
+    if (n < 0 || range <= 0) return fail("xrs_zonal_presence: bad size");
+    if (!present || (n && !zones)) return fail("xrs_zonal_presence: null pointer");
+    XRS_HIP(hipMemsetAsync(present, 0, (size_t)range, s));
+    if (n) hipLaunchKernelGGL(presence_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, present);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int index_impl(const void *zones, long n, double zmin, long range, const int32_t *lut, int32_t *idx, hipStream_t s) {
+    if (n < 0 || range <= 0) return fail("xrs_zonal_index: bad size");
+    if (n == 0) return 0;
+    if (!zones || !lut || !idx) return fail("xrs_zonal_index: null pointer");
+    hipLaunchKernelGGL(index_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, lut, idx);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+#define XRS_DISPATCH_ZTYPE(code, CALL)                                        \
+    switch (code) {                                                           \
+        case 0: return CALL(int32_t);                                         \
+        case 1: return CALL(int64_t);                                         \
+        case 2: return CALL(float);                                           \
+        case 3: return CALL(double);                                          \
+        default: return fail("unknown zone dtype code %d (0 i32, 1 i64, 2 f32, 3 f64)", code); \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int xrs_zonal_scan(const void *zones_dev, int zone_dtype, int64_t n, void *result32_dev, void *stream) {
+#define CALL(T) scan_impl<T>(zones_dev, n, result32_dev, as_stream(stream))
+    XRS_DISPATCH_ZTYPE(zone_dtype, CALL)
+#undef CALL
+}
+
+int xrs_zonal_presence(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
+                       unsigned char *present_dev, void *stream) {
+#define CALL(T) presence_impl<T>(zones_dev, n, zmin, range, present_dev, as_stream(stream))
+    XRS_DISPATCH_ZTYPE(zone_dtype, CALL)
+#undef CALL
+}
+
+int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
+                    const int32_t *lut_dev, int32_t *idx_dev, void *stream) {
+#define CALL(T) index_impl<T>(zones_dev, n, zmin, range, lut_dev, idx_dev, as_stream(stream))
+    XRS_DISPATCH_ZTYPE(zone_dtype, CALL)
+#undef CALL
+}
+
+}  // extern "C"

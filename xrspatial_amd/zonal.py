@@ -58,6 +58,41 @@ def _dense_zone_index(zones: np.ndarray):
     return uniq, idx.reshape(zones.shape)
 
 
+_ZONE_DTYPE_CODE = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+
+
+def _dense_zone_index_device(zones_dev: DeviceArray):
+    """Device-side counterpart of `_dense_zone_index` for zone rasters already in HBM: returns
+    (unique ids as a host array of the zones dtype, int32 DeviceArray of dense indices), or None when
+    the ids are not integral / span too wide a range (the caller then takes the host path)."""
+    code = _ZONE_DTYPE_CODE.get(zones_dev.dtype)
+    if code is None:
+        return None
+    stream = get_stream()
+    n = zones_dev.size
+    res = DeviceArray((4,), np.float64)
+    _lib.call("xrs_zonal_scan", zones_dev.ptr, code, n, res.ptr, stream)
+    raw = res.get(stream)
+    zmin, zmax = raw[0], raw[1]
+    n_finite = int(raw[2:3].view(np.uint64)[0])
+    all_integral = int(raw[3:4].view(np.int32)[0])
+    if n_finite == 0:
+        return zones_dev.get()[:0].ravel(), DeviceArray.from_numpy(np.full(zones_dev.shape, -1, np.int32))
+    if not all_integral or zmax - zmin >= _DENSE_RANGE_LIMIT:
+        return None
+    rng = int(zmax - zmin) + 1
+    present = DeviceArray((rng,), np.uint8)
+    _lib.call("xrs_zonal_presence", zones_dev.ptr, code, n, float(zmin), rng, present.ptr, stream)
+    mask = present.get(stream).astype(bool)
+    lut = (np.cumsum(mask, dtype=np.int64) - 1).astype(np.int32)
+    uniq = (np.flatnonzero(mask).astype(np.float64) + zmin).astype(zones_dev.dtype)
+    lut_dev = DeviceArray.from_numpy(lut)
+    idx = DeviceArray(zones_dev.shape, np.int32)
+    _lib.call("xrs_zonal_index", zones_dev.ptr, code, n, float(zmin), rng, lut_dev.ptr, idx.ptr, stream)
+    _lib.call("xrs_stream_sync", stream)
+    return uniq, idx
+
+
 def _stage(zone_idx, values):
     zdev = zone_idx if isinstance(zone_idx, DeviceArray) else DeviceArray.from_numpy(
         np.ascontiguousarray(zone_idx, dtype=np.int32))
@@ -133,15 +168,25 @@ def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None):
 
 def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, return_type, comm=None):
     like_numpy = not isinstance(values_data, DeviceArray)
-    zones_host = zones_data.get() if isinstance(zones_data, DeviceArray) else np.asarray(zones_data)
-    unique_zones, idx = _dense_zone_index(zones_host)
+    mapped = None
+    if isinstance(zones_data, DeviceArray):
+        _lib.require_device()
+        mapped = _dense_zone_index_device(zones_data)           # stays in HBM when ids are integral
+    if mapped is None:
+        zones_host = zones_data.get() if isinstance(zones_data, DeviceArray) else np.asarray(zones_data)
+        unique_zones, idx = _dense_zone_index(zones_host)
+        idx_dev = None
+    else:
+        unique_zones, idx_dev = mapped
+        idx = idx_dev                                           # only .shape / .size are used below
     if zone_ids is None:
         selected = unique_zones
     else:
         wanted = np.unique(zone_ids)
         selected = [z for z in wanted if z in unique_zones]
     nz = len(unique_zones)
-    idx_dev = DeviceArray.from_numpy(idx)
+    if idx_dev is None:
+        idx_dev = DeviceArray.from_numpy(idx)
     _, vdev = _stage(idx_dev, values_data)
     count, s1, s2, mn, mx = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
     majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in stat_names else None

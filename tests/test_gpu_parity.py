@@ -538,3 +538,54 @@ def test_rccl_plumbing_single_gpu():
         else:                # count, min, max: exact
             np.testing.assert_array_equal(x, y)
     comm.destroy()
+
+
+def test_degenerate_shapes_and_layouts():
+    """Empty rasters, single cells, non-contiguous and Fortran-ordered inputs behave like the reference."""
+    for shape in [(0, 5), (5, 0), (1, 1), (1, 9), (9, 1)]:
+        z = np.zeros(shape, np.float32)
+        agg = raster(z) if 0 not in shape else xs.DataArray(z, dims=['y', 'x'], attrs={'res': (1, 1)})
+        for fn in (xs.slope, xs.aspect, xs.curvature, xs.hillshade):
+            out = fn(agg).data
+            assert out.shape == shape and (out.size == 0 or np.isnan(out).all())
+        assert xs.ndvi(agg, agg).data.shape == shape
+        if 0 not in shape:
+            np.testing.assert_array_equal(apply(agg, circle_kernel(1, 1, 2)).data, orc.focal_apply(z, circle_kernel(1, 1, 2)))
+            np.testing.assert_array_equal(xs.focal.mean(agg).data, orc.focal_mean3x3(z))
+    big = synth.smooth_dem((70, 120), nan_frac=0.01)
+    view = big[3:67:2, 5:117:3]                       # strided view
+    fort = np.asfortranarray(big)
+    for data in (view, fort):
+        agg = raster(data, res=(30.0, 30.0))
+        np.testing.assert_allclose(xs.slope(agg).data, orc.slope(np.ascontiguousarray(data), 30.0, 30.0),
+                                   rtol=RTOL, equal_nan=True)
+        np.testing.assert_array_equal(xs.ndvi(agg, agg).data, orc.normalized_ratio(data, data))
+    assert big[3, 5] == view[0, 0]                     # inputs untouched
+
+
+def test_thread_safety():
+    """The library is re-entrant (per-thread error text, no global state): concurrent callers, like dask's
+    threaded scheduler over the reference's nogil kernels, get the right answers."""
+    import threading
+    rasters = [synth.smooth_dem((96 + 8 * i, 256), seed=i, nan_frac=0.01) for i in range(6)]
+    want = [(orc.slope(z, 30.0, 30.0), orc.focal_apply(z, circle_kernel(1, 1, 2)), orc.normalized_ratio(z, z + 1))
+            for z in rasters]
+    errors = []
+
+    def worker(i):
+        try:
+            z = rasters[i]
+            for _ in range(5):
+                agg = raster(z, res=(30.0, 30.0))
+                np.testing.assert_allclose(xs.slope(agg).data, want[i][0], rtol=RTOL, equal_nan=True)
+                np.testing.assert_allclose(apply(agg, circle_kernel(1, 1, 2)).data, want[i][1], rtol=1e-6, equal_nan=True)
+                np.testing.assert_array_equal(xs.ndvi(agg, raster(z + 1)).data, want[i][2])
+        except Exception as e:       # noqa: BLE001
+            errors.append((i, repr(e)[:300]))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(rasters))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -144,6 +144,13 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
                       int64_t ld_in, int64_t ld_out, const double *excludes, int n_excludes,
                       int halo_top, int halo_bot, void *stream);
 
+/* focal.hotspots support (xrspatial/focal.py:881-934): global NaN-skipping moments of a float32 plane
+ * -> moments32_dev = { uint64 count; double sum, ssd (sum of squared deviations from the mean), mean },
+ * and the z-score classifier  z = (mean_array - global_mean) / global_std  ->  {0, +-90, +-95, +-99} int8. */
+int xrs_nan_moments_f32(const float *in_dev, int64_t n, void *moments32_dev, void *stream);
+int xrs_hotspots_classify_f32(const float *mean_array_dev, signed char *out_dev, int64_t n,
+                              float global_mean, float global_std, void *stream);
+
 /* -------------------------------------------------------------------- zonal
  * Per-zone partial reductions of one streaming pass over (zone index, value):
  * count (integer-exact), sum and sum of squares (float64), min, max.  Cells with

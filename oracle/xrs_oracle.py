@@ -392,6 +392,26 @@ def focal_stats(data, kernel, stats_funcs=FOCAL_STATS):
     return np.stack([focal_apply(data, kernel, s) for s in stats_funcs])
 
 
+def hotspots(data, kernel):
+    """Getis-Ord Gi* classes.  Reference: xrspatial/focal.py:881-934 (`_calc_hotspots_numpy`,
+    `_hotspots_numpy`): float32 data, convolve_2d with kernel / kernel.sum(), z-score against
+    np.nanmean / np.nanstd of the float32 raster (float32 results), thresholds as written."""
+    z32 = np.asarray(data).astype(F32)
+    k = np.asarray(kernel)
+    mean_array = convolve_2d(z32, k / k.sum())
+    gmean, gstd = np.nanmean(z32), np.nanstd(z32)
+    if gstd == 0:
+        raise ZeroDivisionError("Standard deviation of the input raster values is 0.")
+    with np.errstate(all="ignore"):
+        z = (mean_array - gmean) / gstd
+        a = np.abs(z)
+        p = np.where(a >= 2.33, 0.0099, np.where(a >= 1.65, 0.0495, np.where(a >= 1.29, 0.0985, 1.0)))
+        conf = np.where((a > 2.58) & (p < 0.01), 99, np.where((a > 1.96) & (p < 0.05), 95,
+                        np.where((a > 1.65) & (p < 0.1), 90, 0)))
+        hot = np.where(z > 0, 1, np.where(z < 0, -1, 0))
+    return (hot * conf).astype(np.int8), z
+
+
 # --------------------------------------------------------------------------
 # kernels (host-side helpers; reference: xrspatial/convolution.py:137-282)
 # --------------------------------------------------------------------------

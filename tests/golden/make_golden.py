@@ -82,6 +82,7 @@ WANTED = [
     ("test_focal.py", "convolution_custom_kernel", (), "conv_custom"),
     ("test_focal.py", "data_apply", (), "focal_apply"),
     ("test_focal.py", "data_focal_stats", (), "focal_stats"),
+    ("test_focal.py", "data_hotspots", (), "hotspots"),
     ("test_multispectral.py", "blue_data", ("numpy",), "ms_blue"),
     ("test_multispectral.py", "green_data", ("numpy",), "ms_green"),
     ("test_multispectral.py", "red_data", ("numpy",), "ms_red"),

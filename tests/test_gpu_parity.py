@@ -589,3 +589,26 @@ def test_thread_safety():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_hotspots(golden):
+    from xrspatial_amd.focal import hotspots
+    agg = raster(golden["hotspots__0"])
+    out = hotspots(agg, golden["hotspots__1"])
+    assert out.data.dtype == np.int8 and out.attrs['unit'] == '%' and 'unit' not in agg.attrs
+    np.testing.assert_array_equal(out.data, golden["hotspots__2"])
+    with pytest.raises(ZeroDivisionError, match="Standard deviation of the input raster values is 0."):
+        hotspots(raster(np.zeros((10, 20))), np.ones((3, 3)))
+    # seeded: identical classes except where |z| sits within 1e-5 of a threshold (the reference's own
+    # float32 nanmean / nanstd carry ~1e-6 relative error)
+    z = synth.asv_dem(300, 512)
+    z[np.random.default_rng(2).random(z.shape) < 0.01] = np.nan
+    k = circle_kernel(1, 1, 3)
+    want, zs = orc.hotspots(z, k)
+    for backend in ('numpy', 'hip'):
+        got = host(hotspots(raster(z, backend=backend), k).data)
+        near = np.zeros(z.shape, bool)
+        for t in (1.29, 1.65, 1.96, 2.33, 2.58):
+            near |= np.abs(np.abs(zs) - t) < 1e-5
+        assert near.sum() < 100
+        np.testing.assert_array_equal(got[~near], want[~near])

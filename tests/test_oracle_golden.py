@@ -252,3 +252,15 @@ def test_zonal_qgis(golden, golden_tables):
                           stats_funcs=[k for k in exp if k != 'zone'])
     _check_table(res, exp, atol=1e-5)
     assert res['count'].tolist() == exp['count']
+
+
+def test_hotspots(golden):
+    # xrspatial/tests/test_focal.py:426-470 and the docstring example focal.py:1058-1072
+    got, _ = orc.hotspots(golden["hotspots__0"], golden["hotspots__1"])
+    np.testing.assert_array_equal(got, golden["hotspots__2"])
+    assert got.dtype == np.int8
+    data = np.array([[0, 1000, 1000, 0, 0, 0], [0, 0, 0, -1000, -1000, 0], [0, -900, -900, 0, 0, 0], [0, 100, 1000, 0, 0, 0]])
+    got, _ = orc.hotspots(data, np.array([[1, 1, 0]]))
+    np.testing.assert_array_equal(got, [[0, 0, 95, 0, 0, 0], [0, 0, 0, 0, -90, 0], [0, 0, -90, 0, 0, 0], [0, 0, 0, 0, 0, 0]])
+    with pytest.raises(ZeroDivisionError):
+        orc.hotspots(np.zeros((10, 20)), np.ones((3, 3)))

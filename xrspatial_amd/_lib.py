@@ -74,6 +74,8 @@ _PROTOTYPES = {
                             c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "xrs_focal_mean3x3": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
                           c_int, c_int, c_void_p],
+    "xrs_nan_moments_f32": [c_void_p, c_int64, c_void_p, c_void_p],
+    "xrs_hotspots_classify_f32": [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p],
     "xrs_zonal_init": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "xrs_zonal_partials_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],

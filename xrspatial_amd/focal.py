@@ -1,7 +1,8 @@
 """Focal statistics.  Reference: xrspatial/focal.py (mean :162-265, apply :343-473,
-focal_stats :800-878).  `hotspots` is not part of this backend yet."""
+focal_stats :800-878, hotspots :881-1125)."""
 from __future__ import annotations
 
+import copy
 import ctypes
 
 import numpy as np
@@ -164,3 +165,46 @@ def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 
     coords = dict(agg.coords.items())
     coords['stats'] = np.array(stats_funcs, dtype=object)
     return DataArray(stacked, dims=('stats',) + tuple(agg.dims), coords=coords, attrs=agg.attrs)
+
+
+def _hotspots_hip(data, kernel):
+    # replaces _hotspots_numpy (focal.py:914-934)
+    from .convolution import _convolve_2d_hip
+    like_numpy = not isinstance(data, DeviceArray)
+    if not (issubclass(data.dtype.type, np.integer) or issubclass(data.dtype.type, np.floating)):
+        raise ValueError("data type must be integer or float")
+    _lib.require_device()
+    src = to_device_f32(data)
+    k = np.asarray(kernel, dtype=np.float64)
+    mean_array = _convolve_2d_hip(src, k / k.sum())
+    stream = get_stream()
+    mom = DeviceArray((4,), np.float64)
+    _lib.call("xrs_nan_moments_f32", src.ptr, src.size, mom.ptr, stream)
+    raw = mom.get(stream)
+    count = int(raw[0:1].view(np.uint64)[0])
+    with np.errstate(all="ignore"):
+        global_mean = np.float32(raw[3])
+        global_std = np.float32(np.sqrt(raw[2] / count)) if count else np.float32(np.nan)
+    if global_std == 0:
+        raise ZeroDivisionError("Standard deviation of the input raster values is 0.")
+    out = DeviceArray(src.shape, np.int8)
+    _lib.call("xrs_hotspots_classify_f32", mean_array.ptr, out.ptr, out.size, float(global_mean), float(global_std),
+              stream)
+    return finish(out, like_numpy)
+
+
+def hotspots(raster, kernel):
+    """Getis-Ord Gi* hot / cold spots: int8 raster of {0, +-90, +-95, +-99} confidence levels.
+
+    Same signature and behaviour as `xrspatial.focal.hotspots`: neighbourhood mean by `convolve_2d` with the
+    normalised kernel, z-score against the raster's global nanmean / nanstd, ZeroDivisionError for a constant
+    raster, `attrs['unit'] = '%'`."""
+    if not isinstance(raster, DataArray):
+        raise TypeError("`raster` must be instance of DataArray")
+    if raster.ndim != 2:
+        raise ValueError("`raster` must be 2D")
+    mapper = ArrayTypeFunctionMapping(numpy_func=_hotspots_hip, hip_func=_hotspots_hip)
+    out = mapper(raster)(raster.data, kernel)
+    attrs = copy.deepcopy(raster.attrs)
+    attrs['unit'] = '%'
+    return DataArray(out, coords=raster.coords, dims=raster.dims, attrs=attrs)

@@ -92,6 +92,21 @@ int xrs_terrain_fused_f32(const float *in_dev, float *slope_dev, float *aspect_d
                           double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
                           int halo_top, int halo_bot, void *stream);
 
+/* Geodesic slope / aspect (method='geodesic'): WGS-84 ECEF -> local ENU plane fit per 3x3 window, float64
+ * arithmetic, float32 out, NaN border, NaN if any of the nine elevations is NaN.  Replaces
+ * _cpu_geodesic_slope / _cpu_geodesic_aspect (xrspatial/geodesic.py:181-229) behind slope.py:167-174 and
+ * aspect.py:172-179.  elev_is_f64 selects the elevation element type (the reference widens to float64;
+ * float32 rasters are widened in registers).  latlon_2d = 0: lat_dev[row] / lon_dev[col] are 1-D degree
+ * coordinates (lat_dev points at the first OWNED row; halo rows' latitudes precede / follow it) and
+ * `work_dev` must hold xrs_geodesic_workspace_bytes(rows + halo_top + halo_bot, cols) bytes for the
+ * per-row / per-column trigonometry tables.  latlon_2d = 1: 2-D planes with pitch ld_latlon, no workspace.
+ * aspect = 0 -> slope in degrees; 1 -> compass aspect, -1 where the fitted gradient is below 1e-7. */
+size_t xrs_geodesic_workspace_bytes(int64_t rows_with_halos, int64_t cols);
+int xrs_geodesic_f32(const void *elev_dev, int elev_is_f64, const double *lat_dev, const double *lon_dev,
+                     int latlon_2d, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                     int64_t ld_latlon, double a2, double b2, double z_factor, int aspect, void *work_dev,
+                     int halo_top, int halo_bot, void *stream);
+
 /* ----------------------------------------------------------- per-cell indices
  * Flat arrays of n float32 cells, NaN where the denominator is exactly 0.
  *   normalized_ratio  xrspatial/multispectral.py:825-841 (_normalized_ratio_cpu: ndvi/nbr/nbr2/ndmi)

@@ -140,6 +140,96 @@ def hillshade(data, azimuth=225, angle_altitude=25):
 
 
 # --------------------------------------------------------------------------
+# geodesic slope / aspect (method='geodesic')
+# --------------------------------------------------------------------------
+WGS84_A2 = 6378137.0 * 6378137.0
+WGS84_B2 = 6356752.314245 * 6356752.314245
+_INV_2R = 1.0 / (2.0 * 6370994.884953014)        # geodesic.py:187
+
+
+def _ecef(lat_rad, lon_rad, h, a2, b2):
+    """xrspatial/geodesic.py:40-51 (`_geodetic_to_ecef`), float64."""
+    cl, sl, co, so = np.cos(lat_rad), np.sin(lat_rad), np.cos(lon_rad), np.sin(lon_rad)
+    N = a2 / np.sqrt(a2 * cl * cl + b2 * sl * sl)
+    return (N + h) * cl * co, (N + h) * cl * so, (b2 / a2 * N + h) * sl
+
+
+def _geodesic_plane_fit(elev, lat_2d, lon_2d, z_factor, a2=WGS84_A2, b2=WGS84_B2):
+    """(A, B, valid) for the interior cells.  Reference: xrspatial/geodesic.py:54-136
+    (`_local_frame_project_and_fit`): 3x3 ECEF -> local ENU of the centre cell -> curvature
+    correction -> centred least-squares plane u = A e + B n, all float64, neighbours in row-major order."""
+    z = np.asarray(elev).astype(F64)
+    lat = np.asarray(lat_2d, dtype=F64)
+    lon = np.asarray(lon_2d, dtype=F64)
+    d2r = 3.141592653589793 / 180.0
+    c = (slice(1, -1), slice(1, -1))
+    lat_c, lon_c = lat[c] * d2r, lon[c] * d2r
+    Xc, Yc, Zc = _ecef(lat_c, lon_c, z[c] * z_factor, a2, b2)
+    cl, sl, co, so = np.cos(lat_c), np.sin(lat_c), np.cos(lon_c), np.sin(lon_c)
+    ex, ey = -so, co
+    nx, ny, nz = -sl * co, -sl * so, cl
+    ux, uy, uz = cl * co, cl * so, sl
+    H, W = z.shape
+    e9, n9, u9 = [], [], []
+    valid = np.ones((H - 2, W - 2), dtype=bool)
+    for dy in range(3):
+        for dx in range(3):
+            sub = (slice(dy, H - 2 + dy), slice(dx, W - 2 + dx))
+            valid &= ~np.isnan(z[sub])
+            Xk, Yk, Zk = _ecef(lat[sub] * d2r, lon[sub] * d2r, z[sub] * z_factor, a2, b2)
+            ddx, ddy, ddz = Xk - Xc, Yk - Yc, Zk - Zc
+            ek = ddx * ex + ddy * ey + ddz * 0.0
+            nk = ddx * nx + ddy * ny + ddz * nz
+            uk = ddx * ux + ddy * uy + ddz * uz
+            uk = uk + (ek * ek + nk * nk) * _INV_2R
+            e9.append(ek); n9.append(nk); u9.append(uk)
+    me = mn = mu = 0.0
+    for k in range(9):
+        me = me + e9[k]; mn = mn + n9[k]; mu = mu + u9[k]
+    inv9 = 1.0 / 9.0
+    me, mn, mu = me * inv9, mn * inv9, mu * inv9
+    See = Snn = Sen = Seu = Snu = 0.0
+    for k in range(9):
+        de, dn, du = e9[k] - me, n9[k] - mn, u9[k] - mu
+        See = See + de * de; Snn = Snn + dn * dn; Sen = Sen + de * dn
+        Seu = Seu + de * du; Snu = Snu + dn * du
+    det = See * Snn - Sen * Sen
+    degenerate = np.abs(det) < 1e-30
+    with np.errstate(all="ignore"):
+        A = np.where(degenerate, 0.0, (Seu * Snn - Snu * Sen) / det)
+        B = np.where(degenerate, 0.0, (Snu * See - Seu * Sen) / det)
+    return A, B, valid
+
+
+def geodesic_slope(elev, lat_2d, lon_2d, z_factor=1.0):
+    """Reference: xrspatial/geodesic.py:139-149, 181-204 (`_geodesic_slope_at_point`, `_cpu_geodesic_slope`)."""
+    out = _nan_like(np.shape(elev))
+    if out.shape[0] < 3 or out.shape[1] < 3:
+        return out
+    with np.errstate(all="ignore"):
+        A, B, valid = _geodesic_plane_fit(elev, lat_2d, lon_2d, z_factor)
+        deg = np.arctan(np.sqrt(A * A + B * B)) * (180.0 / 3.141592653589793)
+        out[1:-1, 1:-1] = np.where(valid, deg, np.nan).astype(F32)
+    return out
+
+
+def geodesic_aspect(elev, lat_2d, lon_2d, z_factor=1.0):
+    """Reference: xrspatial/geodesic.py:152-173, 207-229 (`_geodesic_aspect_at_point`, `_cpu_geodesic_aspect`)."""
+    out = _nan_like(np.shape(elev))
+    if out.shape[0] < 3 or out.shape[1] < 3:
+        return out
+    with np.errstate(all="ignore"):
+        A, B, valid = _geodesic_plane_fit(elev, lat_2d, lon_2d, z_factor)
+        mag = np.sqrt(A * A + B * B)
+        deg = np.arctan2(-A, -B) * (180.0 / 3.141592653589793)
+        deg = np.where(deg < 0, deg + 360.0, deg)
+        deg = np.where(deg >= 360.0, deg - 360.0, deg)
+        res = np.where(mag < 1e-7, -1.0, deg)
+        out[1:-1, 1:-1] = np.where(valid, res, np.nan).astype(F32)
+    return out
+
+
+# --------------------------------------------------------------------------
 # per-cell multispectral indices
 # --------------------------------------------------------------------------
 

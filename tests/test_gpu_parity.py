@@ -612,3 +612,68 @@ def test_hotspots(golden):
             near |= np.abs(np.abs(zs) - t) < 1e-5
         assert near.sum() < 100
         np.testing.assert_array_equal(got[~near], want[~near])
+
+
+def _geo_raster(elev, lat0, lat1, lon0, lon1, backend='numpy'):
+    H, W = elev.shape
+    agg = xs.DataArray(elev, dims=['lat', 'lon'], coords={'lat': np.linspace(lat0, lat1, H), 'lon': np.linspace(lon0, lon1, W)})
+    if backend == 'hip':
+        agg.data = xs.DeviceArray.from_numpy(elev)
+    return agg
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("backend", ["numpy", "hip"])
+def test_geodesic_slope_aspect(dtype, backend):
+    """method='geodesic' vs the float64 restatement of xrspatial/geodesic.py, plus the reference's own
+    property tests (test_geodesic_slope.py / test_geodesic_aspect.py)."""
+    H, W = 48, 70
+    lat, lon = np.linspace(40.0, 41.0, H), np.linspace(10.0, 11.0, W)
+    LAT, LON = np.meshgrid(lat, lon, indexing='ij')
+    rng = np.random.default_rng(4)
+    elev = (500 + 300 * np.sin(LON * 40) * np.cos(LAT * 30) + rng.normal(0, 2, (H, W))).astype(dtype)
+    elev[20, 30] = np.nan
+    agg = _geo_raster(elev, 40.0, 41.0, 10.0, 11.0, backend)
+    for fn, orc_fn in ((xs.slope, orc.geodesic_slope), (xs.aspect, orc.geodesic_aspect)):
+        got = host(fn(agg, method='geodesic').data)
+        want = orc_fn(elev, LAT, LON)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6, equal_nan=True)
+        assert np.isnan(got[19:22, 29:32]).all() and np.isnan(got[0]).all() and np.isnan(got[:, -1]).all()
+        # z_unit: the same surface given in feet
+        got_ft = host(fn(_geo_raster((elev / 0.3048).astype(np.float64), 40.0, 41.0, 10.0, 11.0, backend),
+                         method='geodesic', z_unit='foot').data)
+        np.testing.assert_allclose(got_ft, want, rtol=1e-4, atol=1e-4, equal_nan=True)
+    # 2-D (curvilinear) coordinates take the per-cell trigonometry path and agree with the 1-D path
+    agg2 = xs.DataArray(agg.data, dims=['y', 'x'], coords={'lat': xs.DataArray(LAT, dims=['y', 'x']),
+                                                           'lon': xs.DataArray(LON, dims=['y', 'x'])})
+    np.testing.assert_allclose(host(xs.slope(agg2, method='geodesic').data), orc.geodesic_slope(elev, LAT, LON),
+                               rtol=RTOL, atol=1e-6, equal_nan=True)
+
+
+def test_geodesic_properties_and_validation():
+    flat = np.full((6, 8), 500.0)
+    for lat_c in (0.0, 30.0, 60.0, -45.0):
+        s = xs.slope(_geo_raster(flat, lat_c - 0.5, lat_c + 0.5, 10.0, 11.0), method='geodesic').data[1:-1, 1:-1]
+        assert np.isfinite(s).all() and np.abs(s).max() < 0.1
+    assert (xs.aspect(_geo_raster(flat, 40.0, 41.0, 10.0, 11.0), method='geodesic').data[1:-1, 1:-1] == -1).all()
+    lon = np.linspace(10.0, 11.0, 8)
+    east = np.broadcast_to(500.0 + 50.0 * (lon - 10.0), (6, 8)).copy()
+    s_eq = xs.slope(_geo_raster(east, -0.5, 0.5, 10.0, 11.0), method='geodesic').data[2, 4]
+    s_60 = xs.slope(_geo_raster(east, 59.5, 60.5, 10.0, 11.0), method='geodesic').data[2, 4]
+    assert s_eq > 0 and 1.5 < s_60 / s_eq < 2.5
+    a = xs.aspect(_geo_raster(east, 40.0, 41.0, 10.0, 11.0), method='geodesic').data[2, 4]
+    assert abs(a - 270.0) < 1.0                       # rises to the east -> faces west
+    pole = np.broadcast_to((500.0 + 50.0 * np.linspace(0, 1, 6))[:, None], (6, 6)).copy()
+    sp = xs.slope(_geo_raster(pole, 88.0, 89.0, 10.0, 11.0), method='geodesic').data[1:-1, 1:-1]
+    assert np.isfinite(sp).all() and (sp > 0).all()
+    with pytest.raises(ValueError, match="method"):
+        xs.slope(_geo_raster(flat, 40, 41, 10, 11), method='invalid')
+    with pytest.raises(ValueError, match="z_unit"):
+        xs.slope(_geo_raster(flat, 40, 41, 10, 11), method='geodesic', z_unit='cubit')
+    with pytest.raises(ValueError, match="coordinates"):
+        xs.slope(xs.DataArray(np.ones((5, 5)), dims=['dim_0', 'dim_1']), method='geodesic')
+    with pytest.raises(ValueError):
+        xs.slope(xs.DataArray(np.ones((5, 5)), dims=['y', 'x'],
+                              coords={'y': np.linspace(4000000, 4100000, 5), 'x': np.linspace(500000, 600000, 5)}),
+                 method='geodesic')

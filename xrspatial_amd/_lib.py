@@ -59,6 +59,9 @@ _PROTOTYPES = {
                           c_int, c_int, c_void_p],
     "xrs_terrain_fused_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                               c_int64, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p],
+    "xrs_geodesic_workspace_bytes": [c_int64, c_int64],
+    "xrs_geodesic_f32": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                         c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int, c_int, c_void_p],
     "xrs_normalized_ratio_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrs_evi_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double,
                     c_void_p],
@@ -98,7 +101,8 @@ _PROTOTYPES = {
     "xrs_halo_exchange_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
     "xrs_zonal_allreduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
-_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t}
+_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t,
+             "xrs_geodesic_workspace_bytes": c_size_t}
 
 EXPORTED = tuple(_PROTOTYPES)
 

@@ -8,6 +8,8 @@ import numpy as np
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
+from .device import DeviceArray
+from .geodesic import extract_latlon, run_geodesic, z_factor_of
 from .utils import ArrayTypeFunctionMapping
 
 
@@ -29,7 +31,12 @@ def aspect(agg: DataArray,
     if method not in ('planar', 'geodesic'):
         raise ValueError(f"method must be 'planar' or 'geodesic', got {method!r}")
     if method == 'geodesic':
-        raise NotImplementedError("geodesic aspect is not implemented by the MI355X backend yet")
+        z_factor = z_factor_of(z_unit)
+        lat, lon, is_2d = extract_latlon(agg)
+        if not isinstance(agg.data, (np.ndarray, DeviceArray)):
+            raise TypeError("Unsupported Array Type: {}".format(type(agg)))
+        out = run_geodesic(agg.data, lat, lon, is_2d, z_factor, aspect=1)
+        return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)
     mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
     out = mapper(agg)(agg.data)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

@@ -8,6 +8,8 @@ import numpy as np
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
+from .device import DeviceArray
+from .geodesic import extract_latlon, run_geodesic, z_factor_of
 from .utils import ArrayTypeFunctionMapping, get_dataarray_resolution
 
 
@@ -25,12 +27,17 @@ def slope(agg: DataArray,
 
     Same signature and results as `xrspatial.slope` (planar Horn method,
     cell size from `attrs['res']` or the coordinates); runs on the MI355X.
-    `method='geodesic'` is not part of this backend yet.
+    `method='geodesic'` fits a plane in the local ENU frame on the WGS-84 ellipsoid (needs lat/lon coordinates).
     """
     if method not in ('planar', 'geodesic'):
         raise ValueError(f"method must be 'planar' or 'geodesic', got {method!r}")
     if method == 'geodesic':
-        raise NotImplementedError("geodesic slope is not implemented by the MI355X backend yet")
+        z_factor = z_factor_of(z_unit)
+        lat, lon, is_2d = extract_latlon(agg)
+        if not isinstance(agg.data, (np.ndarray, DeviceArray)):
+            raise TypeError("Unsupported Array Type: {}".format(type(agg)))
+        out = run_geodesic(agg.data, lat, lon, is_2d, z_factor, aspect=0)
+        return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)
     cellsize_x, cellsize_y = get_dataarray_resolution(agg)
     mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
     out = mapper(agg)(agg.data, cellsize_x, cellsize_y)

@@ -201,6 +201,12 @@ int xrs_zonal_presence(const void *zones_dev, int zone_dtype, int64_t n, double 
 int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
                     const int32_t *lut_dev, int32_t *idx_dev, void *stream);
 
+/* zonal.crosstab, 2-D values (xrspatial/zonal.py:699-800): counts_dev[zone * n_cats + cat] += number of cells
+ * with that (dense zone index, dense category index) pair; negative / out-of-range indices are skipped.
+ * counts_dev (n_zones * n_cats uint64) is accumulated into: zero it with xrs_memset first. */
+int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *cat_idx_dev, int64_t n, int n_zones,
+                        int n_cats, uint64_t *counts_dev, void *stream);
+
 /* majority (most frequent valid value per zone, ties -> smallest; NaN for zones without a valid
  * cell), computed by two device radix sorts + run voting; replaces _stats_majority applied per zone
  * (xrspatial/zonal.py:56-68, 144-163).  `work_dev` must hold

@@ -604,3 +604,34 @@ def zonal_stats(zones, values, zone_ids=None, stats_funcs=None, nodata_values=No
             lo = 0 if iz == 0 else breaks[iz - 1]
             result[sid][order[lo:breaks[iz]]] = res[iz]
     return result.reshape(len(stats_funcs), *values.shape)
+
+
+def crosstab_2d(zones, values, zone_ids=None, cat_ids=None, nodata_values=None, agg='count'):
+    """2-D zonal.crosstab.  Reference: xrspatial/zonal.py:670-800 (`_find_cats`, `_crosstab_numpy`,
+    `_single_zone_crosstab_2d`): per zone, the valid (finite, != nodata) values are sorted and strided over
+    the category list; TOTAL_COUNT is float32; percentage = count / total * 100 with total 0 -> NaN."""
+    zones, values = np.asarray(zones), np.asarray(values)
+    unique_cats = np.unique(values[np.isfinite(values) & (values != nodata_values)])
+    cat_sel = unique_cats if cat_ids is None else [c for c in cat_ids if c in unique_cats]
+    unique_zones = np.unique(zones[np.isfinite(zones)])
+    zone_sel = unique_zones if zone_ids is None else [z for z in zone_ids if z in unique_zones]
+    out = {'zone': list(zone_sel)}
+    for c in cat_sel:
+        out[c] = []
+    total = []
+    for z in unique_zones:
+        if z not in zone_sel:
+            continue
+        zv = values[zones == z]
+        zv = zv[np.isfinite(zv) & (zv != nodata_values)]
+        total.append(zv.shape[0])
+        for c in cat_sel:
+            out[c].append(int((zv == c).sum()))
+    total = np.array(total, dtype=F32)
+    for c in cat_sel:
+        out[c] = np.array(out[c])
+    if agg == 'percentage':
+        total[total == 0] = np.nan
+        for c in cat_sel:
+            out[c] = out[c] / total * 100
+    return out

@@ -677,3 +677,36 @@ def test_geodesic_properties_and_validation():
         xs.slope(xs.DataArray(np.ones((5, 5)), dims=['y', 'x'],
                               coords={'y': np.linspace(4000000, 4100000, 5), 'x': np.linspace(500000, 600000, 5)}),
                  method='geodesic')
+
+
+def test_zonal_crosstab(golden):
+    """zonal.crosstab: reference goldens (test_zonal.py:240-264, 786-822) + seeded rasters vs the oracle."""
+    from xrspatial_amd.zonal import crosstab
+    zones, values = raster(golden["zonal_zones"]), raster(golden["zonal_values"])
+    df = crosstab(zones, values, zone_ids=[1, 2, 3], cat_ids=[0, 1, 2])
+    assert list(df.columns) == ['zone', 0, 1, 2] and df['zone'].tolist() == [1, 2, 3]
+    assert df[0].tolist() == [0, 0, 1] and df[1].tolist() == [6, 0, 0] and df[2].tolist() == [0, 4, 0]
+    df = crosstab(zones, values, zone_ids=[1, 2], cat_ids=[1, 2], nodata_values=3, agg='percentage')
+    assert df[1].tolist() == [100, 0] and df[2].tolist() == [0, 100]
+    rng = np.random.default_rng(8)
+    zz = rng.integers(0, 9, size=(150, 260)).astype(np.float64)
+    zz[rng.random(zz.shape) < 0.02] = np.nan
+    vv = rng.integers(-3, 12, size=zz.shape).astype(np.float32)
+    vv[rng.random(zz.shape) < 0.02] = np.nan
+    for backend in ('numpy', 'hip'):
+        for agg in ('count', 'percentage'):
+            got = crosstab(raster(zz, backend=backend), raster(vv, backend=backend), nodata_values=5, agg=agg)
+            want = orc.crosstab_2d(zz, vv, nodata_values=5, agg=agg)
+            assert list(got.columns) == list(want)
+            for col in want:
+                np.testing.assert_allclose(got[col].to_numpy(), want[col], rtol=1e-6, equal_nan=True, err_msg=str(col))
+    # 3-D values: a layer per category (test_zonal.py:50-59, 266-336, 825-880)
+    data3 = np.ones((3, 8, 4))
+    v3 = xs.DataArray(data3, dims=['lat', 'lon', 'race'], coords={'race': np.array(['cat1', 'cat2', 'cat3', 'cat4'], dtype=object)})
+    for agg, exp in (('count', [6, 5, 6]), ('sum', [6., 5., 6.]), ('mean', [1., 1., 1.]), ('std', [0., 0., 0.])):
+        df = crosstab(zones, v3, zone_ids=[1, 2, 3], layer=-1, agg=agg)
+        assert list(df.columns) == ['zone', 'cat1', 'cat2', 'cat3', 'cat4']
+        for c in ('cat1', 'cat4'):
+            np.testing.assert_allclose(df[c].to_numpy(), exp)
+    with pytest.raises(ValueError):
+        crosstab(zones, values, agg='mean')

@@ -20,6 +20,7 @@ from .focal import mean  # noqa: F401
 from .hillshade import hillshade  # noqa: F401
 from .multispectral import arvi, evi, nbr, ndvi, savi, sipi  # noqa: F401
 from .slope import slope  # noqa: F401
+from .zonal import crosstab as zonal_crosstab  # noqa: F401
 from .zonal import stats as zonal_stats  # noqa: F401
 
 from . import convolution, focal, multispectral, zonal  # noqa: F401

@@ -88,6 +88,7 @@ _PROTOTYPES = {
     "xrs_zonal_scan": [c_void_p, c_int, c_int64, c_void_p, c_void_p],
     "xrs_zonal_presence": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p],
     "xrs_zonal_index": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p, c_void_p],
+    "xrs_crosstab_counts": [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
     "xrs_zonal_majority_workspace_bytes": [c_int64, c_int, c_int],
     "xrs_zonal_majority_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p,
                                c_void_p],

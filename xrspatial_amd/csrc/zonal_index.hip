@@ -184,3 +184,64 @@ int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmi
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// zonal.crosstab (2-D values): counts of (zone, category) pairs.  Reference: _single_zone_crosstab_2d /
+// _crosstab_numpy (xrspatial/zonal.py:699-800): per zone, sort the zone's values and stride over the
+// categories.  Here: one streaming pass over two dense index planes (8 B/cell), counters privatised per
+// workgroup in LDS when the zone x category table fits (<= 16384 cells), flushed once with device atomics.
+namespace {
+
+template <bool LDS>
+__global__ void __launch_bounds__(256) crosstab_kernel(const int32_t *zidx, const int32_t *cidx, long n, int nz, int nc,
+                                                       unsigned long long *counts) {
+    extern __shared__ unsigned local[];
+    const int cells = nz * nc;
+    if (LDS) {
+        for (int i = threadIdx.x; i < cells; i += 256) local[i] = 0u;
+        __syncthreads();
+    }
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * 256;
+    auto bump = [&](int z, int c) {
+        if (z >= 0 && z < nz && c >= 0 && c < nc) {
+            if (LDS) atomicAdd(&local[z * nc + c], 1u);
+            else atomicAdd(&counts[(long)z * nc + c], 1ull);
+        }
+    };
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int4 z = reinterpret_cast<const int4 *>(zidx)[i];
+        const int4 c = reinterpret_cast<const int4 *>(cidx)[i];
+        bump(z.x, c.x); bump(z.y, c.y); bump(z.z, c.z); bump(z.w, c.w);
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bump(zidx[i], cidx[i]);
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < cells; i += 256)
+            if (local[i]) atomicAdd(&counts[i], (unsigned long long)local[i]);
+    }
+}
+
+}  // namespace
+
+extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *cat_idx_dev, int64_t n, int n_zones,
+                                   int n_cats, uint64_t *counts_dev, void *stream) {
+    if (n < 0 || n_zones < 0 || n_cats < 0) return fail("xrs_crosstab_counts: negative size");
+    if (n == 0 || n_zones == 0 || n_cats == 0) return 0;
+    if (!zone_idx_dev || !cat_idx_dev || !counts_dev) return fail("xrs_crosstab_counts: null pointer");
+    if (!aligned16(zone_idx_dev) || !aligned16(cat_idx_dev)) return fail("xrs_crosstab_counts: index planes must be 16-byte aligned");
+    const long cells = (long)n_zones * n_cats;
+    long grid = (n / 4 + 255) / 256;
+    if (grid > 2048) grid = 2048;                   // per-workgroup u32 counters: n / grid < 2^32
+    if (grid < 1) grid = 1;
+    if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(counts_dev);
+    if (cells <= 16384)
+        hipLaunchKernelGGL(crosstab_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)cells * 4, as_stream(stream),
+                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts);
+    else
+        hipLaunchKernelGGL(crosstab_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}

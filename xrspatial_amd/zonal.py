@@ -270,3 +270,119 @@ def stats(
         coords['stats'] = names
         return DataArray(result, coords=coords, dims=('stats',) + tuple(values.dims), attrs=values.attrs)
     return result
+
+
+def _dense_index_any(data):
+    """(unique finite values, int32 DeviceArray of dense indices) for a host or device raster."""
+    if isinstance(data, DeviceArray):
+        _lib.require_device()
+        mapped = _dense_zone_index_device(data)
+        if mapped is not None:
+            return mapped
+        data = data.get()
+    uniq, idx = _dense_zone_index(np.asarray(data))
+    return uniq, DeviceArray.from_numpy(idx)
+
+
+def _crosstab_2d(zones_data, values_data, zone_ids, cat_ids, nodata_values, agg):
+    # replaces _crosstab_numpy / _single_zone_crosstab_2d (zonal.py:699-800) for 2-D values
+    _lib.require_device()
+    stream = get_stream()
+    unique_zones, zidx = _dense_index_any(zones_data)
+    all_cats, cidx = _dense_index_any(values_data)
+    nz, nc = len(unique_zones), len(all_cats)
+    counts = np.zeros((nz, nc), dtype=np.uint64)
+    if nz and nc:
+        cdev = DeviceArray((nz * nc,), np.uint64)
+        _lib.call("xrs_memset", cdev.ptr, 0, cdev.nbytes, stream)
+        _lib.call("xrs_crosstab_counts", zidx.ptr, cidx.ptr, zidx.size, nz, nc, cdev.ptr, stream)
+        counts = cdev.get(stream).reshape(nz, nc)
+    valid_cat = np.ones(nc, dtype=bool) if nodata_values is None else (all_cats != nodata_values)
+    unique_cats = all_cats[valid_cat]
+    counts = counts[:, valid_cat].astype(np.int64)
+    if zone_ids is None:
+        sel_zones = unique_zones
+    else:
+        sel_zones = [z for z in zone_ids if z in unique_zones]
+    if cat_ids is None:
+        sel_cats = unique_cats
+    else:
+        sel_cats = [c for c in cat_ids if c in unique_cats]
+    zrows = [i for i, z in enumerate(unique_zones) if z in sel_zones]
+    total = counts[zrows].sum(axis=1).astype(np.float32)                 # all valid cells of the zone (zonal.py:708-709)
+    frame = {'zone': sel_zones}
+    for c in sel_cats:
+        j = int(np.flatnonzero(unique_cats == c)[0])
+        frame[c] = counts[zrows, j]
+    if agg == 'percentage':
+        total[total == 0] = np.nan
+        for c in sel_cats:
+            frame[c] = frame[c] / total * 100
+    return pd.DataFrame(frame)[['zone'] + list(sel_cats)]
+
+
+def _crosstab_3d(zones_data, values_data, cat_labels, zone_ids, cat_ids, nodata_values, agg):
+    # 3-D values: one layer per category, `agg` of the layer's values per zone (zonal.py:724-739)
+    unique_zones, zidx = _dense_index_any(zones_data)
+    nz = len(unique_zones)
+    sel_zones = unique_zones if zone_ids is None else [z for z in zone_ids if z in unique_zones]
+    sel_cats = list(cat_labels) if cat_ids is None else [c for c in cat_ids if c in cat_labels]
+    zrows = [i for i, z in enumerate(unique_zones) if z in sel_zones]
+    frame = {'zone': sel_zones}
+    for j, cat in enumerate(cat_labels):
+        if cat not in sel_cats:
+            continue
+        layer = values_data.rows(j, j + 1) if isinstance(values_data, DeviceArray) else values_data[j]
+        if isinstance(layer, DeviceArray):
+            layer = DeviceArray(layer.shape[1:], layer.dtype, _ptr=layer.ptr, _base=layer)
+        count, s1, s2, mn, mx = zonal_partials(zidx, layer, nz, nodata_values)
+        majority = zonal_majority(zidx, layer, nz, nodata_values) if agg == 'majority' else None
+        col = finalize_stats([agg], count, s1, s2, mn, mx, majority)[agg]
+        if agg == 'count':
+            col = count.astype(np.int64)
+        frame[cat] = col[zrows]
+    return pd.DataFrame(frame)[['zone'] + sel_cats]
+
+
+def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count", nodata_values=None):
+    """Cross-tabulated (categorical) statistics of `values` per zone.
+
+    Same signature as `xrspatial.zonal.crosstab`.  2-D `values`: count / percentage of every category
+    (distinct value) per zone, counted on the MI355X in one pass.  3-D `values`: one layer per category
+    along dimension `layer`, `agg` of each layer per zone (the zonal.stats partials per layer)."""
+    if not isinstance(zones, DataArray):
+        raise TypeError("zones must be instance of DataArray")
+    if not isinstance(values, DataArray):
+        raise TypeError("values must be instance of DataArray")
+    if zones.ndim != 2:
+        raise ValueError("zones must be 2D")
+    if not (issubclass(zones.data.dtype.type, np.integer) or issubclass(zones.data.dtype.type, np.floating)):
+        raise ValueError("`zones` must be an xarray of integers or floats")
+    if not (issubclass(values.data.dtype.type, np.integer) or issubclass(values.data.dtype.type, np.floating)):
+        raise ValueError("`values` must be an xarray of integers or floats")
+    if values.ndim not in [2, 3]:
+        raise ValueError("`values` must use either 2D or 3D coordinates.")
+    if values.ndim == 2:
+        validate_arrays(zones, values)
+        if agg not in ("percentage", "count"):
+            raise ValueError("`agg` method for 2D data array must be one of following ['percentage', 'count']")
+        return _crosstab_2d(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
+    if agg not in _DEFAULT_STATS:
+        raise ValueError(f"`agg` method for 3D numpy backed data array must be one of following {list(_DEFAULT_STATS)}")
+    if layer is None:
+        layer = 0
+    try:
+        cat_dim = values.dims[layer]
+    except IndexError:
+        raise ValueError("Invalid `layer`")
+    data = values.data
+    axis = list(values.dims).index(cat_dim)
+    if axis != 0:
+        if isinstance(data, DeviceArray):
+            data = DeviceArray.from_numpy(np.ascontiguousarray(np.moveaxis(data.get(), axis, 0)))
+        else:
+            data = np.ascontiguousarray(np.moveaxis(np.asarray(data), axis, 0))
+    if tuple(zones.shape) != tuple(data.shape[1:]):
+        raise ValueError("Incompatible shapes")
+    labels = np.asarray(values[cat_dim].values).tolist()
+    return _crosstab_3d(zones.data, data, labels, zone_ids, cat_ids, nodata_values, agg)

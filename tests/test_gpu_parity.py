@@ -710,3 +710,24 @@ def test_zonal_crosstab(golden):
             np.testing.assert_allclose(df[c].to_numpy(), exp)
     with pytest.raises(ValueError):
         crosstab(zones, values, agg='mean')
+
+
+def test_large_mask_stats_conditioning():
+    """Large masks take the prefix-sum mean/var/std kernel: flat patches inside high-relief tiles (lakes),
+    NaN holes and +-inf must still match the reference's two-pass float64 variance."""
+    rng = np.random.default_rng(12)
+    y, x = np.mgrid[0:120, 0:300]
+    z = (3000 + 2500 * np.sin(x / 9.0) * np.cos(y / 7.0) + rng.normal(0, 0.5, x.shape)).astype(np.float32)
+    z[30:80, 100:190] = 1234.5                          # a lake: exactly constant, var must be exactly 0 inside
+    z[rng.random(z.shape) < 0.01] = np.nan
+    z[10, 250] = np.inf
+    k = circle_kernel(1, 1, 12)
+    got = focal_stats(raster(z), k, stats_funcs=['mean', 'var', 'std', 'min', 'max', 'sum'])
+    for i, stat in enumerate(['mean', 'var', 'std', 'min', 'max', 'sum']):
+        want = corc.focal_apply(z, k, stat, nthreads=8)
+        if stat in ('min', 'max', 'sum'):
+            np.testing.assert_array_equal(got.data[i], want, err_msg=stat)
+        else:
+            np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=0, equal_nan=True, err_msg=stat)
+    lake_var = got.data[1][45:65, 115:175]
+    assert (lake_var[np.isfinite(lake_var)] >= 0).all()

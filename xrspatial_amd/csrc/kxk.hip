@@ -121,18 +121,22 @@ __device__ __forceinline__ void store_row(float *out, long ld, long y, long x0, 
     }
 }
 
-// Visit every tap of the kernel for the 4 adjacent outputs a lane owns:
+// Visit every selected tap of the kernel for the 4 adjacent outputs a lane owns:
 //   f(ky, kx, v0, v1, v2, v3)  with v_o = input cell under tap (ky, kx) of output column o.
-// KH/KW > 0: compile-time shape, fully unrolled, register-indexed.  0: runtime shape, an
-// 8-register sliding view advanced one 16-byte slot per 4 taps (the slot after the last needed
-// one is read and ignored; the tile allocation carries 64 bytes of slack for it).
+// `rowmask` (bit kx of entry ky selects tap (ky, kx); wave-uniform) or nullptr for "every tap" (convolution).
+// KH/KW > 0: compile-time shape, fully unrolled, register-indexed.  0: runtime shape, an 8-register sliding
+// view advanced one 16-byte slot per 4 taps; a slot whose 4 mask bits are all set runs without per-tap
+// tests, an empty one is skipped (the slot after the last needed one is read and ignored; the tile
+// allocation carries 64 bytes of slack for it).
 template <int KH, int KW, typename F>
-__device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile, int orow, int lane, F &&f) {
+__device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile, int orow, int lane,
+                                            const unsigned long long *rowmask, F &&f) {
     if constexpr (KH > 0) {
         constexpr int NS = (4 + 2 * (KW / 2) + 3) / 4;     // 16-byte slots per lane per row
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
             const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.pitch) + lane;
+            const unsigned long long bits = rowmask ? rowmask[ky] : ~0ull;
             float w[4 * NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -140,23 +144,39 @@ __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile,
                 w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
             }
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) f(ky, kx, w[kx], w[kx + 1], w[kx + 2], w[kx + 3]);
+            for (int kx = 0; kx < KW; ++kx)
+                if (bits >> kx & 1ull) f(ky, kx, w[kx], w[kx + 1], w[kx + 2], w[kx + 3]);
         }
     } else {
         const int kh = a.krows, kw = a.kcols;
         const int nchunks = (kw + 3) >> 2;
         for (int ky = 0; ky < kh; ++ky) {
+            unsigned long long bits = rowmask ? rowmask[ky] : ~0ull;
+            if (kw < 64) bits &= (1ull << kw) - 1;
+            if (!bits) continue;
             const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.pitch) + lane;
-            float4 cur = r4[0];
-            for (int jc = 0; jc < nchunks; ++jc) {
-                const float4 nx = r4[jc + 1];
-                const float w[8] = {cur.x, cur.y, cur.z, cur.w, nx.x, nx.y, nx.z, nx.w};
+            // slots are fetched four at a time (ds_read_b128 x4 in flight) and consumed from registers
+            float4 slot[5];
+            slot[0] = r4[0];
+            for (int jg = 0; jg < nchunks; jg += 4) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int kx = jc * 4 + jj;
-                    if (kx < kw) f(ky, kx, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
+                for (int c = 0; c < 4; ++c) slot[c + 1] = r4[jg + c + 1];      // (reads past the row's last slot land in
+#pragma unroll                                                                //  the next row / the allocation's slack)
+                for (int c = 0; c < 4; ++c) {
+                    const int jc = jg + c;
+                    const unsigned b4 = jc < nchunks ? (unsigned)(bits >> (4 * jc)) & 15u : 0u;
+                    const float w[8] = {slot[c].x, slot[c].y, slot[c].z, slot[c].w,
+                                        slot[c + 1].x, slot[c + 1].y, slot[c + 1].z, slot[c + 1].w};
+                    if (b4 == 15u) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) f(ky, jc * 4 + jj, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
+                    } else if (b4) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            if (b4 >> jj & 1u) f(ky, jc * 4 + jj, w[jj], w[jj + 1], w[jj + 2], w[jj + 3]);
+                    }
                 }
-                cur = nx;
+                slot[0] = slot[4];
             }
         }
     }
@@ -174,8 +194,12 @@ __device__ __forceinline__ double rcp_count(int n) {
 // ------------------------------------------------------------------ focal statistics
 // All statistics / any kernel shape.  Per output row: pass 1 walks the window row-major (the order the
 // reference's reducers visit their scratch array), pass 2 (std / var only) accumulates squared deviations.
-template <int KH, int KW, bool MEAN_ONLY, bool VEC>
-__device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float *tile, long X0, long Y0) {
+// MODE 0: mean only.  1: every requested statistic.  2: the float32 statistics only (sum, max, min, range) --
+// used for large masks whose mean / var / std come from the prefix-sum kernel of kxk_runs.hip.
+template <int KH, int KW, int MODE, bool VEC>
+__device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float *tile, long X0, long Y0,
+                                                   bool nan_free = false) {
+    constexpr bool MEAN_ONLY = MODE == 0;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const long x0 = X0 + lane * 4;
     if (x0 >= a.cols) return;
@@ -192,21 +216,35 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
         float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-        walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
-            if (!(a.mask_rows[ky] >> kx & 1ull)) return;      // wave-uniform
-            const float v[4] = {v0, v1, v2, v3};
+        if (MODE == 2 && nan_free) {
+            // float32 statistics of a tile without NaN / out-of-raster cells: three VALU ops per tap
+            walk_window<KH, KW>(a, tile, orow, lane, a.mask_rows, [&](int, int, float v0, float v1, float v2, float v3) {
+                const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const bool ok = !isnan(v[o]);
-                sum64[o] += ok ? (double)v[o] : 0.0;
-                cnt[o] += ok ? 1 : 0;
-                if (!MEAN_ONLY) {
-                    sum32[o] = ok ? sum32[o] + v[o] : sum32[o];
+                for (int o = 0; o < 4; ++o) {
+                    sum32[o] += v[o];
                     mn[o] = fminf(mn[o], v[o]);
                     mx[o] = fmaxf(mx[o], v[o]);
                 }
-            }
-        });
+            });
+#pragma unroll
+            for (int o = 0; o < 4; ++o) cnt[o] = a.ntaps;
+        } else {
+            walk_window<KH, KW>(a, tile, orow, lane, a.mask_rows, [&](int, int, float v0, float v1, float v2, float v3) {
+                const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const bool ok = !isnan(v[o]);
+                    if (MODE != 2) sum64[o] += ok ? (double)v[o] : 0.0;
+                    cnt[o] += ok ? 1 : 0;
+                    if (!MEAN_ONLY) {
+                        sum32[o] = ok ? sum32[o] + v[o] : sum32[o];
+                        mn[o] = fminf(mn[o], v[o]);
+                        mx[o] = fmaxf(mx[o], v[o]);
+                    }
+                }
+            });
+        }
 
         double mean[4];
         float o_tmp[4];
@@ -215,7 +253,7 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
             mean[o] = sum64[o] * rcp_count(cnt[o]);
             o_tmp[o] = (float)mean[o];
         }
-        store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
+        if (MODE != 2) store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
         if (MEAN_ONLY) continue;
 
         if (a.out[XRS_STAT_MAX]) {
@@ -235,10 +273,9 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
         }
         store_row<VEC>(a.out[XRS_STAT_SUM], a.ld_out, y, x0, a.cols, sum32);
 
-        if (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR]) {
+        if (MODE != 2 && (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR])) {
             double ssd[4] = {0, 0, 0, 0};
-            walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
-                if (!(a.mask_rows[ky] >> kx & 1ull)) return;
+            walk_window<KH, KW>(a, tile, orow, lane, a.mask_rows, [&](int, int, float v0, float v1, float v2, float v3) {
                 const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
@@ -259,16 +296,16 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
     }
 }
 
-template <int KH, int KW, bool MEAN_ONLY, bool VEC>
+template <int KH, int KW, int MODE, bool VEC>
 __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const long t = xcd_tile(blockIdx.x, a.n_tiles);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * TW, Y0 = ty * a.th;
-    load_tile<VEC>(a, tile, X0, Y0);
-    __syncthreads();
-    focal_rows_general<KH, KW, MEAN_ONLY, VEC>(a, tile, X0, Y0);
+    const bool bad = load_tile<VEC>(a, tile, X0, Y0);
+    const bool nan_free = !__syncthreads_or(bad);           // (also the barrier between staging and the walk)
+    focal_rows_general<KH, KW, MODE, VEC>(a, tile, X0, Y0, nan_free);
 }
 
 // Mean only, compile-time kernel shape, 16-byte friendly raster: the headline kernel.
@@ -287,7 +324,7 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
     const long X0 = tx * TW, Y0 = ty * TH_FAST;
     const bool bad = load_tile<true>(a, tile, X0, Y0);
     if (__syncthreads_or(bad)) {
-        focal_rows_general<KH, KW, true, true>(a, tile, X0, Y0);
+        focal_rows_general<KH, KW, 0, true>(a, tile, X0, Y0);
         return;
     }
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
@@ -653,7 +690,7 @@ __global__ void __launch_bounds__(256) convolve_kernel(const KxkArgs a) {
         const long y = Y0 + orow;
         if (y >= a.rows) break;
         double acc[4] = {0, 0, 0, 0};
-        walk_window<KH, KW>(a, tile, orow, lane, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
+        walk_window<KH, KW>(a, tile, orow, lane, nullptr, [&](int ky, int kx, float v0, float v1, float v2, float v3) {
             const double wt = a.weights[ky * kw + kx];     // wave-uniform address: scalar load
             acc[0] += wt * (double)v0;
             acc[1] += wt * (double)v1;
@@ -810,7 +847,7 @@ int plan_tile(KxkArgs &a, size_t *lds_bytes) {
     a.lpad = (rx + 3) & ~3;
     a.pitch = TW + ((2 * rx + 3) & ~3);
     for (int th = 16; th >= 4; th >>= 1) {
-        const size_t bytes = ((size_t)(th + a.krows - 1) * a.pitch + 16) * sizeof(float);   // + one slot of read slack
+        const size_t bytes = ((size_t)(th + a.krows - 1) * a.pitch + 32) * sizeof(float);   // + read slack (<= 5 slots past the last row)
         if (bytes <= 64 * 1024) {
             a.th = th;
             *lds_bytes = bytes;
@@ -838,13 +875,13 @@ bool vec_ok(const KxkArgs &a, unsigned out_mask) {
     return v;
 }
 
-template <int KH, int KW, bool MEAN_ONLY>
+template <int KH, int KW, int MODE>
 int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
     const unsigned grid = (unsigned)xcd_grid(a.n_tiles);
     if (vec)
-        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MEAN_ONLY, true>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MODE, true>), dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MEAN_ONLY, false>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MODE, false>), dim3(grid), dim3(256), lds, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -856,13 +893,19 @@ int launch_mean_fast(const KxkArgs &a, size_t lds, hipStream_t s) {
     return 0;
 }
 
-template <int KH, int KW>
-int launch_mean_direct(KxkArgs a, hipStream_t s) {
-    constexpr int RB = 4;
+template <int KH, int KW, int RB>
+int launch_mean_direct_rb(KxkArgs a, hipStream_t s) {
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
     hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KH, int KW>
+int launch_mean_direct(const KxkArgs &a, hipStream_t s) {
+    const char *e = getenv("XRS_FOCAL_RB");          // A/B knob: rows per wave (default 4)
+    if (e && e[0] == '2') return launch_mean_direct_rb<KH, KW, 2>(a, s);
+    return launch_mean_direct_rb<KH, KW, 4>(a, s);
 }
 
 template <int KH, int KW>
@@ -907,8 +950,8 @@ int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
         if (a.krows == 5 && a.kcols == 5) return launch_stats_direct<5, 5>(a, s);
     }
     // (the unrolled all-statistics bodies need > 170 VGPRs beyond 3x3; the runtime walk needs ~72)
-    if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY>(a, vec, lds, s);
-    return launch_focal<0, 0, MEAN_ONLY>(a, vec, lds, s);
+    if (a.krows == 3 && a.kcols == 3) return launch_focal<3, 3, MEAN_ONLY ? 0 : 1>(a, vec, lds, s);
+    return launch_focal<0, 0, MEAN_ONLY ? 0 : 1>(a, vec, lds, s);
 }
 
 }  // namespace
@@ -1000,6 +1043,20 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     a.tiles_x = (cols + TW - 1) / TW;
     a.n_tiles = a.tiles_x * ((rows + a.th - 1) / a.th);
     const bool vec = vec_ok(a, stat_mask);
+    if (stat_mask != (1u << XRS_STAT_MEAN) && krows * kcols > 49) {
+        // large run-structured masks, several statistics: mean / var / std from prefix sums (kxk_runs.hip),
+        // the float32 statistics (row-major sum, min, max, range) from one tap walk over the LDS tile
+        const unsigned f64_stats = (1u << XRS_STAT_MEAN) | (1u << XRS_STAT_VAR) | (1u << XRS_STAT_STD);
+        int rc = 0;
+        if (stat_mask & f64_stats)
+            rc = try_launch_focal_meanvar_runs(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows,
+                                               cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            if (!(stat_mask & ~f64_stats)) return 0;
+            return launch_focal<0, 0, 2>(a, vec, lds, s);
+        }
+    }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
     // the all-statistics kernel always produces the mean internally; give it somewhere to go
     return dispatch_focal<false>(a, vec, lds, s);

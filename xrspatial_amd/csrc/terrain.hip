@@ -23,6 +23,8 @@
 // base address are not multiples of 16 bytes.
 #include "xrs_common.h"
 
+#include <cstdlib>
+
 using namespace xrs;
 
 namespace {
@@ -206,11 +208,19 @@ __global__ void __launch_bounds__(256) terrain_cell_kernel(const TerrainArgs a, 
     if ((ops & OP_HILL) && a.out[3]) static_cast<HillT *>(a.out[3])[off] = (HillT)r_hill;
 }
 
-constexpr int RB_DEFAULT = 4;
+template <int OPS, typename HillT, int RB>
+int launch_strip_rb(TerrainArgs &a, hipStream_t s);
 
 template <int OPS, typename HillT>
 int launch_strip(TerrainArgs &a, hipStream_t s) {
-    constexpr int RB = RB_DEFAULT;
+    const char *e = getenv("XRS_TERRAIN_RB");        // A/B knob: rows per wave (default 4)
+    if (e && e[0] == '2') return launch_strip_rb<OPS, HillT, 2>(a, s);
+    if (e && e[0] == '8') return launch_strip_rb<OPS, HillT, 8>(a, s);
+    return launch_strip_rb<OPS, HillT, 4>(a, s);
+}
+
+template <int OPS, typename HillT, int RB>
+int launch_strip_rb(TerrainArgs &a, hipStream_t s) {
     a.tiles_x = (a.cols + 255) / 256;
     const long tiles_y = (a.rows + 4 * RB - 1) / (4 * RB);
     a.n_tiles = a.tiles_x * tiles_y;

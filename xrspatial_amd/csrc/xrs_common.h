@@ -64,5 +64,9 @@ __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); 
 int try_launch_focal_mean_runs(const float *in, float *out, long rows, long cols, long ld_in, long ld_out,
                                const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
                                hipStream_t s);
+// same tiles, plus variance / standard deviation from a second prefix array (any output may be null)
+int try_launch_focal_meanvar_runs(const float *in, float *out_mean, float *out_var, float *out_std, long rows,
+                                  long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols,
+                                  int halo_top, int halo_bot, hipStream_t s);
 
 }  // namespace xrs

@@ -109,6 +109,13 @@ def main():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
         L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
 
+    lat1 = xs.DeviceArray.from_numpy(np.linspace(40.0, 41.0, n))
+    lon1 = xs.DeviceArray.from_numpy(np.linspace(10.0, 11.0, n))
+    geo_work = xs.DeviceArray((int(_lib.load().xrs_geodesic_workspace_bytes(n, n)),), np.uint8)
+    A2, B2 = 6378137.0 ** 2, 6356752.314245 ** 2
+    mom = xs.DeviceArray((4,), np.float64)
+    out8 = xs.DeviceArray((n, n), np.int8)
+
     # name -> (callable, algorithmic bytes per cell)
     cases = {
         "copy_d2d": (lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, S), 8),
@@ -130,6 +137,12 @@ def main():
         "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
+        "geodesic_slope": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
+                                     A2, B2, 1.0, 0, geo_work.ptr, 0, 0, S), 8),
+        "geodesic_aspect": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
+                                      A2, B2, 1.0, 1, geo_work.ptr, 0, 0, S), 8),
+        "nan_moments": (lambda: L("xrs_nan_moments_f32", dem.ptr, cells, mom.ptr, S), 8),
+        "hotspots_classify": (lambda: L("xrs_hotspots_classify_f32", dem.ptr, out8.ptr, cells, 50.0, 20.0, S), 5),
     }
     only = [s for s in args.only.split(",") if s]
     timer = Timer()

@@ -7,8 +7,6 @@ back either a NumPy array (numpy-backed input: strict drop-in) or the DeviceArra
 """
 from __future__ import annotations
 
-import ctypes
-
 import numpy as np
 
 from . import _lib
@@ -44,7 +42,7 @@ def stencil(fn_name, data, out_dtype, extra, halo=(0, 0)):
     """Run a (in, out, rows, cols, ld_in, ld_out, *extra, halo_top, halo_bot, stream) entry point."""
     _lib.require_device()
     like_numpy = not isinstance(data, DeviceArray)
-    if np.ndim(data) != 2 if like_numpy else data.ndim != 2:
+    if len(data.shape) != 2:
         raise ValueError("expected a 2D raster")
     src = to_device_f32(data)
     rows, cols, ld = plane_args(src)

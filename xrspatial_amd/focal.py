@@ -84,8 +84,7 @@ def _mean_hip(data, excludes, passes):
     rows, cols = cur.shape
     ex = np.asarray(list(excludes), dtype=np.float64)
     stream = get_stream()
-    if passes <= 0:
-        out = DeviceArray.from_numpy(cur.get().astype(np.float64))
+    out = cur if cur.dtype == np.float64 else cur.astype(np.float64)      # passes == 0: `agg.data.astype(float)` only
     for _ in range(int(passes)):
         out = DeviceArray((rows, cols), np.float64)
         _lib.call("xrs_focal_mean3x3", cur.ptr, int(cur.dtype == np.float64), out.ptr, rows, cols, cols, cols,

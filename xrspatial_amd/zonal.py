@@ -174,19 +174,16 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
         mapped = _dense_zone_index_device(zones_data)           # stays in HBM when ids are integral
     if mapped is None:
         zones_host = zones_data.get() if isinstance(zones_data, DeviceArray) else np.asarray(zones_data)
-        unique_zones, idx = _dense_zone_index(zones_host)
-        idx_dev = None
+        unique_zones, idx_host = _dense_zone_index(zones_host)
+        idx_dev = DeviceArray.from_numpy(idx_host)
     else:
         unique_zones, idx_dev = mapped
-        idx = idx_dev                                           # only .shape / .size are used below
     if zone_ids is None:
         selected = unique_zones
     else:
         wanted = np.unique(zone_ids)
         selected = [z for z in wanted if z in unique_zones]
     nz = len(unique_zones)
-    if idx_dev is None:
-        idx_dev = DeviceArray.from_numpy(idx)
     _, vdev = _stage(idx_dev, values_data)
     count, s1, s2, mn, mx = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
     majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in stat_names else None
@@ -202,8 +199,8 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
     for i, name in enumerate(stat_names):
         table[i, keep] = cols[name][keep]
     tdev = DeviceArray.from_numpy(table)
-    out = DeviceArray((len(stat_names),) + tuple(idx.shape), np.float64)
-    _lib.call("xrs_zonal_backproject_f64", idx_dev.ptr, idx.size, tdev.ptr, len(stat_names), max(nz, 1), out.ptr,
+    out = DeviceArray((len(stat_names),) + tuple(idx_dev.shape), np.float64)
+    _lib.call("xrs_zonal_backproject_f64", idx_dev.ptr, idx_dev.size, tdev.ptr, len(stat_names), max(nz, 1), out.ptr,
               get_stream())
     return out.get(get_stream()) if like_numpy else out
 

@@ -729,3 +729,25 @@ def test_large_mask_stats_conditioning():
             np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=0, equal_nan=True, err_msg=stat)
     lake_var = got.data[1][45:65, 115:175]
     assert (lake_var[np.isfinite(lake_var)] >= 0).all()
+
+
+def test_zonal_stats_dataset_timeseries(golden):
+    """values as a Dataset (3-D time series split per variable): test_zonal.py:625-698."""
+    zones = xs.DataArray(golden["zonal_zones"], dims=['y', 'x'])
+    v = golden["zonal_values"]
+    v3 = xs.DataArray(np.stack([v, v * 2], axis=0), dims=['time', 'y', 'x'], coords={'time': np.array(['t0', 't1'], dtype=object)})
+    df = xs.zonal_stats(zones=zones, values=v3.to_dataset(dim='time'))
+    assert df['zone'].tolist() == [0, 1, 2, 3]
+    exp = {'t0_mean': [0, 1, 2, 2.4], 't0_max': [0, 1, 2, 3], 't0_sum': [0, 6, 8, 12], 't0_var': [0, 0, 0, 1.44],
+           't0_count': [5, 6, 4, 5], 't0_majority': [0, 1, 2, 3], 't1_mean': [0, 2, 4, 4.8], 't1_min': [0, 2, 4, 0],
+           't1_std': [0, 0, 0, 2.4], 't1_count': [5, 6, 4, 5], 't1_majority': [0, 2, 4, 6]}
+    assert len(df.columns) == 17
+    for col, want in exp.items():
+        np.testing.assert_allclose(df[col], want, rtol=1e-5, atol=1e-7, err_msg=col)
+    # Dataset in -> Dataset out for the single-input functions (test_dataset_support.py:74-140)
+    z = synth.smooth_dem((20, 40))
+    ds = xs.Dataset({'dem': raster(z), 'dem2': raster(z + 5)})
+    for fn in (xs.hillshade, xs.curvature, xs.focal.mean):
+        out = fn(ds)
+        assert set(out.data_vars) == {'dem', 'dem2'}
+        np.testing.assert_array_equal(out['dem2'].data, fn(raster(z + 5)).data)

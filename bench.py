@@ -59,6 +59,8 @@ def main():
         args.gpus = world
     os.environ.setdefault("XRS_DEVICE", str(local_rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # single node: RCCL bootstrap over loopback
 
     # Load the HIP library (and with it /opt/rocm's runtime) BEFORE torch is imported.
     if not os.path.exists(os.path.join(ROOT, "xrspatial_amd", "libxrs_hip.so")):

@@ -160,6 +160,21 @@ def main():
         focal_ms.append(ms.value)
     hill_avg, focal_avg = (float(np.mean(hill_ms)), float(np.mean(focal_ms))) if hill_ms else (float("nan"), float("nan"))
 
+    # Calibration, outside the timed region: the streaming-copy bandwidth this GPU sustains in the library's own
+    # access pattern (xrs_copy_f32, 4 B read + 4 B written per cell like the bench kernels).
+    copy_gbs = None
+    if rank == 0:
+        for _ in range(2):
+            L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
+        c0, c1 = make_event(), make_event()
+        L("xrs_event_record", c0, stream)
+        for _ in range(10):
+            L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
+        L("xrs_event_record", c1, stream)
+        L("xrs_event_sync", c1)
+        L("xrs_event_elapsed_ms", c0, c1, ctypes.byref(ms))
+        copy_gbs = 8.0 * rows * cols / (ms.value / 10 * 1e-3) / 1e9
+
     # Informational, OUTSIDE the timed region (rank 0, N=1): the other kernels of BASELINE configs[1]/[2] on the
     # same resident raster, and one numpy-in/numpy-out call to quote the PCIe-inclusive rate of the drop-in path.
     extra = {}
@@ -244,6 +259,8 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL * cells_rank,
             "launch_ms": round(dom_ms, 4),
+            "measured_copy_gbs": round(copy_gbs, 1),
+            "frac_of_measured_copy": round(achieved / copy_gbs, 4),
         },
     }
     if world == 1 and not args.no_cpu_baseline:

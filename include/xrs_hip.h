@@ -51,6 +51,8 @@ int xrs_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int xrs_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int xrs_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int xrs_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
+/* streaming plane copy in the library's own access pattern: the measured-copy-bandwidth calibration point */
+int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream);
 int xrs_stream_create(void **stream);
 int xrs_stream_destroy(void *stream);
 int xrs_stream_sync(void *stream);

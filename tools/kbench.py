@@ -119,6 +119,7 @@ def main():
     # name -> (callable, algorithmic bytes per cell)
     cases = {
         "copy_d2d": (lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, S), 8),
+        "copy_kernel": (lambda: L("xrs_copy_f32", dem.ptr, outs[0].ptr, cells, S), 8),
         "hillshade": (lambda: L("xrs_hillshade_f32", dem.ptr, outs[0].ptr, 0, n, n, n, n, 225.0, 25.0, 0, 0, S), 8),
         "hillshade_f64out": (lambda: L("xrs_hillshade_f32", dem.ptr, out64.ptr, 1, n, n, n, n, 225.0, 25.0, 0, 0, S), 12),
         "slope": (lambda: L("xrs_slope_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 1.0, 0, 0, S), 8),

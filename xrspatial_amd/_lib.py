@@ -41,6 +41,7 @@ _PROTOTYPES = {
     "xrs_memcpy_d2h": [c_void_p, c_void_p, c_size_t, c_void_p],
     "xrs_memcpy_d2d": [c_void_p, c_void_p, c_size_t, c_void_p],
     "xrs_memset": [c_void_p, c_int, c_size_t, c_void_p],
+    "xrs_copy_f32": [c_void_p, c_void_p, c_int64, c_void_p],
     "xrs_stream_create": [ctypes.POINTER(c_void_p)],
     "xrs_stream_destroy": [c_void_p],
     "xrs_stream_sync": [c_void_p],

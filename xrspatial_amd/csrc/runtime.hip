@@ -3,7 +3,40 @@
 
 using namespace xrs;
 
+namespace {
+
+// Streaming copy in the library's own access pattern (one contiguous 16 KiB chunk per workgroup, four
+// wave-interleaved 16-byte slots per lane, chunks dealt to XCDs in contiguous runs): the "achievable copy
+// bandwidth" calibration point that kernel roofline fractions are compared with (tools/kbench.py).
+__global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, float4 *dst, long n4, long n_chunks) {
+    const long chunk = xcd_tile(blockIdx.x, n_chunks);
+    if (chunk < 0) return;
+    const long base = chunk * 1024 + (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + 64 * u < n4) v[u] = src[base + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + 64 * u < n4) dst[base + 64 * u] = v[u];
+}
+
+}  // namespace
+
 extern "C" {
+
+int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream) {
+    if (n < 0) return fail("xrs_copy_f32: negative size");
+    if (n == 0) return 0;
+    if (!src_dev || !dst_dev) return fail("xrs_copy_f32: null pointer");
+    if (!aligned16(src_dev) || !aligned16(dst_dev) || (n & 3))
+        return fail("xrs_copy_f32: planes must be 16-byte aligned with a multiple of 4 elements");
+    const long n4 = n >> 2, n_chunks = (n4 + 1023) / 1024;
+    hipLaunchKernelGGL(copy_chunk_kernel, dim3((unsigned)xcd_grid(n_chunks)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(src_dev), reinterpret_cast<float4 *>(dst_dev), n4, n_chunks);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
 
 int xrs_version(void) { return 1; }
 

@@ -41,8 +41,8 @@ ALG_BYTES_PER_CELL = 8        # 4 B read + 4 B written per cell, either kernel (
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)     # the clocks settle over the first ~15 launches (profiles/r01)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -751,3 +751,55 @@ def test_zonal_stats_dataset_timeseries(golden):
         out = fn(ds)
         assert set(out.data_vars) == {'dem', 'dem2'}
         np.testing.assert_array_equal(out['dem2'].data, fn(raster(z + 5)).data)
+
+
+def test_row_shard_halo_contract_all_stencils():
+    """Every stencil entry point, called per row shard with halo_top/halo_bot, reproduces the rows of the
+    monolithic result: the contract the multi-GPU path (xrs_halo_exchange_f32 + kernels) relies on."""
+    import ctypes
+    from xrspatial_amd import _lib
+    H, W, HALO = 90, 256, 3
+    z = synth.smooth_dem((H, W), nan_frac=0.01)
+    full = xs.DeviceArray.from_numpy(z)
+    k7 = np.ascontiguousarray(annulus_kernel(1, 1, 3, 1), dtype=np.float64)            # 7x7
+    w7 = np.ascontiguousarray(k7 / k7.sum())
+    work = xs.DeviceArray((4096,), np.uint8)
+    ex = np.array([np.nan])
+    lat, lon = np.linspace(40.0, 41.0, H), np.linspace(10.0, 11.0, W)
+    LAT, LON = np.meshgrid(lat, lon, indexing='ij')
+    lat_dev, lon_dev = xs.DeviceArray.from_numpy(lat), xs.DeviceArray.from_numpy(lon)
+    geo_work = xs.DeviceArray((int(_lib.load().xrs_geodesic_workspace_bytes(H, W)),), np.uint8)
+    want = {
+        'slope': orc.slope(z, 30.0, 30.0), 'aspect': orc.aspect(z), 'curvature': orc.curvature(z, 30.0),
+        'hillshade': orc.hillshade(z), 'convolve': corc.convolve_2d(z, w7),
+        'mean3': orc.focal_mean3x3(z), 'geodesic': orc.geodesic_slope(z, LAT, LON),
+    }
+    want_stats = {s: corc.focal_apply(z, k7, s) for s in orc.FOCAL_STATS}
+    L = _lib.call
+    for (y0, y1) in [(0, 30), (30, 60), (60, 90)]:
+        n = y1 - y0
+        ht, hb = min(HALO, y0), min(HALO, H - y1)
+        h1t, h1b = min(1, y0), min(1, H - y1)
+        shard = full.rows(y0, y1)
+        o32 = xs.DeviceArray((n, W), np.float32)
+        o64 = xs.DeviceArray((n, W), np.float64)
+
+        def check(name, arr, tol=RTOL):
+            np.testing.assert_allclose(arr, want[name][y0:y1], rtol=tol, atol=1e-6, equal_nan=True, err_msg=f"{name} rows {y0}:{y1}")
+
+        L("xrs_slope_f32", shard.ptr, o32.ptr, n, W, W, W, 30.0, 30.0, h1t, h1b, None); check('slope', o32.get())
+        L("xrs_aspect_f32", shard.ptr, o32.ptr, n, W, W, W, h1t, h1b, None); check('aspect', o32.get())
+        L("xrs_curvature_f32", shard.ptr, o32.ptr, n, W, W, W, 30.0, h1t, h1b, None); check('curvature', o32.get())
+        L("xrs_hillshade_f32", shard.ptr, o64.ptr, 1, n, W, W, W, 225.0, 25.0, h1t, h1b, None); check('hillshade', o64.get())
+        L("xrs_convolve2d_f32", shard.ptr, o32.ptr, n, W, W, W, w7.ctypes.data, 7, 7, work.ptr, ht, hb, None)
+        L("xrs_stream_sync", None); check('convolve', o32.get(), 1e-6)
+        L("xrs_focal_mean3x3", shard.ptr, 0, o64.ptr, n, W, W, W, ex.ctypes.data, 1, h1t, h1b, None); check('mean3', o64.get(), 1e-12)
+        L("xrs_geodesic_f32", shard.ptr, 0, lat_dev.ptr + 8 * y0, lon_dev.ptr, 0, o32.ptr, n, W, W, W, W,
+          6378137.0 ** 2, 6356752.314245 ** 2, 1.0, 0, geo_work.ptr, h1t, h1b, None)
+        L("xrs_stream_sync", None); check('geodesic', o32.get())
+        outs = [xs.DeviceArray((n, W), np.float32) for _ in range(7)]
+        ptrs = (ctypes.c_void_p * 7)(*[o.ptr for o in outs])
+        L("xrs_focal_stats_f32", shard.ptr, ptrs, 127, n, W, W, W, k7.ctypes.data, 7, 7, None, ht, hb, None)
+        for i, s in enumerate(orc.FOCAL_STATS):
+            np.testing.assert_allclose(outs[i].get(), want_stats[s][y0:y1], rtol=1e-6, atol=1e-9, equal_nan=True,
+                                       err_msg=f"focal {s} rows {y0}:{y1}")

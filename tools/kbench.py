@@ -85,6 +85,13 @@ def main():
         z = synth.block_zones(min(2048, n - y0), n, y0=y0)
         _lib.call("xrs_memcpy_h2d", zones.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
         _lib.call("xrs_stream_sync", None)
+    zones_sc = xs.DeviceArray((n, n), np.int32)        # scattered: random zone per 8x8-cell block (stresses the atomics)
+    rng = np.random.default_rng(9)
+    for y0 in range(0, n, 2048):
+        blocks = rng.integers(0, 1000, size=(2048 // 8, n // 8)).astype(np.int32)
+        z = np.repeat(np.repeat(blocks, 8, axis=0), 8, axis=1)
+        _lib.call("xrs_memcpy_h2d", zones_sc.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
     print("inputs staged in %.1f s" % (time.time() - t0), flush=True)
 
     outs = [xs.DeviceArray((n, n), np.float32) for _ in range(7)]
@@ -116,6 +123,10 @@ def main():
     mom = xs.DeviceArray((4,), np.float64)
     out8 = xs.DeviceArray((n, n), np.int8)
 
+    def zonal_scatter():
+        L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
+        L("xrs_zonal_partials_f32", zones_sc.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
+
     # name -> (callable, algorithmic bytes per cell)
     cases = {
         "copy_d2d": (lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, S), 8),
@@ -138,6 +149,7 @@ def main():
         "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
+        "zonal_1000_scattered": (zonal_scatter, 8),
         "geodesic_slope": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
                                      A2, B2, 1.0, 0, geo_work.ptr, 0, 0, S), 8),
         "geodesic_aspect": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,

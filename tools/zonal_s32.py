@@ -1,7 +1,6 @@
 """BASELINE config 5 on ONE GPU: zonal.stats over a 32768 x 32768 float32 raster with 1000 int32 zones,
 device-resident inputs.  Prints the partial-sum kernel time (8 B/cell read-only) and the whole
 `zonal.stats` call (zone indexing on the device, partials, majority excluded / included)."""
-import ctypes
 import os
 import sys
 import time

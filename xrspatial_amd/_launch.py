@@ -7,8 +7,6 @@ back either a NumPy array (numpy-backed input: strict drop-in) or the DeviceArra
 """
 from __future__ import annotations
 
-import numpy as np
-
 from . import _lib
 from .device import DeviceArray, to_device_f32
 

@@ -803,3 +803,36 @@ def test_row_shard_halo_contract_all_stencils():
         for i, s in enumerate(orc.FOCAL_STATS):
             np.testing.assert_allclose(outs[i].get(), want_stats[s][y0:y1], rtol=1e-6, atol=1e-9, equal_nan=True,
                                        err_msg=f"focal {s} rows {y0}:{y1}")
+
+
+def test_unaligned_device_views():
+    """Device views whose base address is only 4-byte aligned (e.g. a sub-raster starting at an odd column of a
+    larger allocation) take the scalar / unvectorised kernel paths and still match."""
+    rng = np.random.default_rng(21)
+    H, W = 64, 260
+    pad = 1                                             # shift by one float: base % 16 == 4
+    z = synth.smooth_dem((H, W), nan_frac=0.01)
+    b = (z + rng.normal(0, 1, z.shape)).astype(np.float32)
+    zones = rng.integers(0, 6, size=(H, W)).astype(np.int32)
+
+    def shifted(arr):
+        flat = np.zeros(arr.size + 8, dtype=arr.dtype)
+        flat[pad:pad + arr.size] = arr.ravel()
+        base = xs.DeviceArray.from_numpy(flat)
+        view = xs.DeviceArray(arr.shape, arr.dtype, _ptr=base.ptr + pad * arr.dtype.itemsize, _base=base)
+        assert view.ptr % 16 != 0
+        return view
+
+    zv, bv, zonev = shifted(z), shifted(b), shifted(zones)
+    agg, bagg = xs.DataArray(zv, dims=['y', 'x'], attrs={'res': (30.0, 30.0)}), xs.DataArray(bv, dims=['y', 'x'])
+    np.testing.assert_allclose(xs.slope(agg).data.get(), orc.slope(z, 30.0, 30.0), rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(xs.hillshade(agg).data.get(), orc.hillshade(z), rtol=RTOL, equal_nan=True)
+    np.testing.assert_array_equal(xs.ndvi(agg, bagg).data.get(), orc.normalized_ratio(z, b))
+    k = circle_kernel(1, 1, 2)
+    np.testing.assert_allclose(apply(agg, k).data.get(), orc.focal_apply(z, k), rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(xs.focal.mean(agg).data.get(), orc.focal_mean3x3(z), rtol=1e-12, equal_nan=True)
+    got = xs.zonal_stats(xs.DataArray(zonev, dims=['y', 'x']), agg, stats_funcs=['count', 'sum', 'min'])
+    want = orc.zonal_stats(zones, z, stats_funcs=['count', 'sum', 'min'])
+    np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+    np.testing.assert_array_equal(got['min'].to_numpy(), want['min'])
+    np.testing.assert_allclose(got['sum'].to_numpy(), want['sum'], rtol=RTOL)

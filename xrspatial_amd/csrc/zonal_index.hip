@@ -194,14 +194,14 @@ namespace {
 
 template <bool LDS>
 __global__ void __launch_bounds__(256) crosstab_kernel(const int32_t *zidx, const int32_t *cidx, long n, int nz, int nc,
-                                                       unsigned long long *counts) {
+                                                       unsigned long long *counts, const int vec) {
     extern __shared__ unsigned local[];
     const int cells = nz * nc;
     if (LDS) {
         for (int i = threadIdx.x; i < cells; i += 256) local[i] = 0u;
         __syncthreads();
     }
-    const long n4 = n >> 2;
+    const long n4 = vec ? n >> 2 : 0;
     const long stride = (long)gridDim.x * 256;
     auto bump = [&](int z, int c) {
         if (z >= 0 && z < nz && c >= 0 && c < nc) {
@@ -229,7 +229,7 @@ extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *c
     if (n < 0 || n_zones < 0 || n_cats < 0) return fail("xrs_crosstab_counts: negative size");
     if (n == 0 || n_zones == 0 || n_cats == 0) return 0;
     if (!zone_idx_dev || !cat_idx_dev || !counts_dev) return fail("xrs_crosstab_counts: null pointer");
-    if (!aligned16(zone_idx_dev) || !aligned16(cat_idx_dev)) return fail("xrs_crosstab_counts: index planes must be 16-byte aligned");
+    const int vec = aligned16(zone_idx_dev) && aligned16(cat_idx_dev);
     const long cells = (long)n_zones * n_cats;
     long grid = (n / 4 + 255) / 256;
     if (grid > 2048) grid = 2048;                   // per-workgroup u32 counters: n / grid < 2^32
@@ -238,10 +238,10 @@ extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *c
     unsigned long long *counts = reinterpret_cast<unsigned long long *>(counts_dev);
     if (cells <= 16384)
         hipLaunchKernelGGL(crosstab_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)cells * 4, as_stream(stream),
-                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts);
+                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
     else
         hipLaunchKernelGGL(crosstab_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
-                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts);
+                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
     XRS_LAUNCH_CHECK();
     return 0;
 }

@@ -836,3 +836,24 @@ def test_unaligned_device_views():
     np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
     np.testing.assert_array_equal(got['min'].to_numpy(), want['min'])
     np.testing.assert_allclose(got['sum'].to_numpy(), want['sum'], rtol=RTOL)
+
+
+def test_terrain_with_infinite_cells():
+    """+-inf cells in the DEM: every terrain operator follows the reference's arithmetic through inf / NaN."""
+    z = synth.smooth_dem((40, 256))
+    z[10, 100] = np.inf
+    z[25, 30] = -np.inf
+    z[26, 31] = np.inf
+    agg = raster(z, res=(30.0, 30.0))
+    with np.errstate(all="ignore"):
+        np.testing.assert_allclose(xs.slope(agg).data, orc.slope(z, 30.0, 30.0), rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(xs.aspect(agg).data, orc.aspect(z), rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(xs.curvature(agg).data, orc.curvature(z, 30.0), rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(xs.hillshade(agg).data, orc.hillshade(z), rtol=RTOL, atol=1e-6, equal_nan=True)
+        k = circle_kernel(1, 1, 2)
+        got = focal_stats(agg, k)
+        for i, stat in enumerate(orc.FOCAL_STATS):
+            np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat), rtol=1e-6, equal_nan=True, err_msg=stat)
+        np.testing.assert_allclose(apply(agg, k).data, corc.focal_apply(z, k, 'mean'), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(convolution_2d(agg, k / k.sum()).data, corc.convolve_2d(z, k / k.sum()), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xs.focal.mean(agg).data, orc.focal_mean3x3(z), rtol=1e-12, equal_nan=True)

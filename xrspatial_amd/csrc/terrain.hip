@@ -83,6 +83,16 @@ __device__ __forceinline__ float hillshade_cell(const Nb &q, float sin_alt, floa
     // => shaded = (sin_alt + cos_alt*(cosA*gy - sinA*gx)) / sqrt(1 + gx^2 + gy^2).
     const float gx = (q.s - q.n) * 0.5f;
     const float gy = (q.e - q.w) * 0.5f;
+    if (isinf(gx) || isinf(gy)) {
+        // an infinite gradient (+-inf cell in the DEM): the folded form would give inf * 0; evaluate the
+        // reference's trigonometric chain literally (hillshade.py:25-31), float32 functions, float64 combine
+        const float slope = 1.5707964f - atanf(sqrtf(gx * gx + gy * gy));
+        const float aspect = atan2f(-gx, gy);
+        const float az_off = atan2f(sin_az, cos_az);                    // = azimuth_rad - pi/2
+        const double shaded = (double)sin_alt * (double)sinf(slope) +
+                              (double)cos_alt * (double)cosf(slope) * (double)cosf(az_off - aspect);
+        return (float)((shaded + 1.0) * 0.5);
+    }
     const float num = fmaf(cos_alt, fmaf(cos_az, gy, -sin_az * gx), sin_alt);
     const float shaded = num * rsqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
     return (shaded + 1.0f) * 0.5f;

@@ -1,0 +1,307 @@
+"""Host-side logic of the drop-in layer, exercised without a GPU.
+
+These mirror the reference's own host-level tests (xrspatial/tests/test_focal.py:178-336 kernel builders and
+cell sizes, test_dataset_support.py:111-208 adapter errors, test_multispectral.py argument validation,
+test_zonal.py return-type checks, xrspatial/utils.py:146-277 validation / resolution helpers) and check that
+every entry point validates its arguments BEFORE touching the device, so a bad call fails the same way on a
+box without a GPU as the reference's CPU path does.
+"""
+import numpy as np
+import pytest
+
+import xrspatial_amd as xa
+from xrspatial_amd import convolution, focal, geodesic, multispectral, utils, zonal
+from xrspatial_amd._xr import DataArray, Dataset
+from xrspatial_amd.convolution import annulus_kernel, calc_cellsize, circle_kernel, custom_kernel
+from xrspatial_amd.distributed import combine_zonal_partials, shard_halos, shard_rows
+
+
+def raster(data, res=(0.5, 0.5), attrs=None, dims=('y', 'x')):
+    data = np.asarray(data)
+    h, w = data.shape[-2:]
+    a = {'res': res}
+    a.update(attrs or {})
+    coords = {dims[-1]: np.linspace(0, (w - 1) * res[0], w), dims[-2]: np.linspace((h - 1) * res[1], 0, h)}
+    return DataArray(data, dims=dims, coords=coords, attrs=a)
+
+
+# ---------------------------------------------------------------- kernels (test_focal.py:178-197)
+def test_custom_kernel_rejects_lists_and_even_shapes():
+    with pytest.raises(ValueError):
+        custom_kernel([1, 0, 0])
+    with pytest.raises(ValueError):
+        custom_kernel(np.ones((4, 6)))
+    k = np.ones((3, 5))
+    assert custom_kernel(k) is k
+
+
+def test_circle_and_annulus_kernels():
+    np.testing.assert_array_equal(circle_kernel(1, 1, 1), [[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    np.testing.assert_array_equal(annulus_kernel(2, 2, 2, 1), [[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    k = circle_kernel(1, 1, 12)
+    assert k.shape == (25, 25) and k.dtype == np.float64
+    assert k[12, 0] == 1 and k[0, 12] == 1 and k[0, 0] == 0
+    np.testing.assert_array_equal(k, k[::-1, ::-1])
+    np.testing.assert_array_equal(k, k.T)
+    # anisotropic cells: wider than tall
+    assert circle_kernel(1, 2, 4).shape == (5, 9)
+    # radius as a distance string
+    np.testing.assert_array_equal(circle_kernel(1000, 1000, '3 km'), circle_kernel(1, 1, 3))
+    np.testing.assert_array_equal(circle_kernel(0.3048, 0.3048, '2ft'), circle_kernel(1, 1, 2))
+
+
+@pytest.mark.parametrize("bad", ['-3', '0', 'abc', '3 parsecs', '3 km 2'])
+def test_kernel_distance_validation(bad):
+    with pytest.raises(ValueError):
+        circle_kernel(1, 1, bad)
+
+
+def test_calc_cellsize():          # test_focal.py:303-312
+    data = np.zeros((6, 6))
+    assert calc_cellsize(raster(data, res=(1, 1), attrs={'unit': 'km'})) == (1000, 1000)
+    assert calc_cellsize(raster(data)) == (0.5, 0.5)
+    cx, cy = calc_cellsize(raster(data, res=(2, -3), attrs={'unit': 'ft'}))
+    assert cx == pytest.approx(0.6096) and cy == pytest.approx(0.9144)
+
+
+# ---------------------------------------------------------------- utils (utils.py:146-277)
+def test_validate_arrays():
+    a = np.zeros((3, 4))
+    utils.validate_arrays(a, a.copy())
+    with pytest.raises(ValueError):
+        utils.validate_arrays(a)
+    with pytest.raises(ValueError):
+        utils.validate_arrays(a, np.zeros((4, 3)))
+
+
+def test_resolution_helpers():
+    r = raster(np.zeros((4, 5)), res=(10.0, 20.0))
+    assert utils.get_dataarray_resolution(r) == (10.0, 20.0)
+    # no 'res' attribute: derived from the coordinates
+    bare = DataArray(np.zeros((4, 5)), dims=('y', 'x'),
+                     coords={'x': np.arange(5) * 2.0, 'y': np.arange(4)[::-1] * 3.0})
+    cx, cy = utils.calc_res(bare)
+    assert cx == pytest.approx(2.0) and abs(cy) == pytest.approx(3.0)
+    assert utils.get_dataarray_resolution(bare)[0] == pytest.approx(2.0)
+    # scalar res attribute means square cells
+    sq = DataArray(np.zeros((4, 5)), dims=('y', 'x'), attrs={'res': 7})
+    assert utils.get_dataarray_resolution(sq) == (7, 7)
+
+
+def test_array_type_dispatch_without_a_backend():
+    mapper = utils.ArrayTypeFunctionMapping(numpy_func=lambda x: 'np', hip_func=None)
+    assert mapper(DataArray(np.zeros((2, 2))))(None) == 'np'      # returns the implementation, like upstream
+    with pytest.raises(TypeError):
+        class Holder:            # neither a host nor a device array behind .data
+            data = [[1, 2], [3, 4]]
+        mapper(Holder())
+    with pytest.raises(NotImplementedError):
+        utils.not_implemented_func(None)
+
+
+# ---------------------------------------------------------------- argument validation ahead of the device
+def test_focal_argument_validation():
+    r = raster(np.zeros((5, 5)))
+    k = np.ones((3, 3))
+    with pytest.raises(TypeError):
+        focal.apply(np.zeros((5, 5)), k)
+    with pytest.raises(ValueError):
+        focal.apply(raster(np.zeros((2, 5, 5)), dims=('t', 'y', 'x')), k)
+    with pytest.raises(ValueError):
+        focal.apply(r, np.ones((2, 3)))
+    with pytest.raises(NotImplementedError):
+        focal.apply(r, k, func=lambda w: 0)              # arbitrary callables have no device form
+    with pytest.raises(TypeError):
+        focal.focal_stats(np.zeros((5, 5)), k)
+    with pytest.raises(KeyError):
+        focal.focal_stats(r, k, stats_funcs=['median'])
+    with pytest.raises(ValueError):
+        focal.mean(raster(np.zeros((2, 5, 5)), dims=('t', 'y', 'x')))
+    with pytest.raises(TypeError):
+        focal.hotspots(np.zeros((5, 5)), k)
+    with pytest.raises(ValueError):
+        focal.hotspots(raster(np.zeros((2, 5, 5)), dims=('t', 'y', 'x')), k)
+
+
+def test_builtin_reducer_tokens():
+    # the reference passes numba functions (_calc_mean ... focal.py:226-258); here they are device tokens
+    for stat in ('mean', 'max', 'min', 'range', 'std', 'var', 'sum'):
+        tok = getattr(focal, '_calc_' + stat)
+        assert focal._reducer_name(tok) == stat
+        assert stat in repr(tok)
+
+
+def test_multispectral_argument_validation():
+    a = raster(np.ones((4, 4)))
+    b = raster(np.ones((4, 5)))
+    with pytest.raises(ValueError):
+        multispectral.ndvi(a, b)
+    with pytest.raises(ValueError):
+        multispectral.evi(a, a, b)
+    with pytest.raises(ValueError):
+        multispectral.evi(a, a, a, c1='6')
+    with pytest.raises(ValueError):
+        multispectral.evi(a, a, a, c2=None)
+    with pytest.raises(ValueError):
+        multispectral.evi(a, a, a, soil_factor=1.5)
+    with pytest.raises(ValueError):
+        multispectral.evi(a, a, a, gain=-1)
+    with pytest.raises(ValueError):
+        multispectral.savi(a, a, soil_factor=-2)
+    with pytest.raises(ValueError):
+        multispectral.arvi(a, a, b)
+    with pytest.raises(ValueError):
+        multispectral.ebbi(a, b, a)
+
+
+def test_dataset_adapter_errors():                      # test_dataset_support.py:111-165, 208
+    ds = Dataset({'nir': raster(np.ones((4, 4))), 'red': raster(np.ones((4, 4)))})
+    with pytest.raises(TypeError, match="'red' keyword required"):
+        multispectral.ndvi(ds, nir='nir')
+    with pytest.raises(ValueError, match="not in Dataset"):
+        multispectral.ndvi(ds, nir='nir', red='crimson')
+    zones = raster(np.zeros((4, 4), dtype=np.int32))
+    with pytest.raises(ValueError):
+        zonal.stats(zones, ds, return_type='xarray.DataArray')
+
+
+def test_zonal_argument_validation():
+    zones = raster(np.zeros((4, 4), dtype=np.int32))
+    vals = raster(np.ones((4, 4)))
+    with pytest.raises(ValueError):
+        zonal.stats(zones, raster(np.ones((4, 5))))
+    with pytest.raises(ValueError):
+        zonal.stats(raster(np.zeros((4, 4), dtype=bool)), vals)      # zones must be integers or floats
+    with pytest.raises(ValueError):
+        zonal.stats(zones, raster(np.zeros((4, 4), dtype=bool)))
+    with pytest.raises(ValueError):
+        zonal.stats(zones, vals, return_type='dict')
+    with pytest.raises(NotImplementedError):
+        zonal.stats(zones, vals, stats_funcs={'mine': lambda z: 0})
+    with pytest.raises((KeyError, ValueError)):
+        zonal.stats(zones, vals, stats_funcs=['mode'])
+    with pytest.raises(ValueError):
+        zonal.crosstab(zones, vals, agg='median')
+
+
+def test_geodesic_validation():                          # utils.py:608-713, slope.py:300-330
+    assert geodesic.z_factor_of('meter') == 1.0
+    assert geodesic.z_factor_of('ft') == pytest.approx(0.3048)
+    with pytest.raises(ValueError):
+        geodesic.z_factor_of('cubit')
+    z = np.zeros((4, 5))
+    ok = DataArray(z, dims=('lat', 'lon'), coords={'lat': np.linspace(41, 40, 4), 'lon': np.linspace(-100, -99, 5)})
+    lat, lon, is_2d = geodesic.extract_latlon(ok)
+    assert not is_2d and lat.shape == (4,) and lon.shape == (5,)
+    with pytest.raises(ValueError, match="Latitude"):
+        geodesic.extract_latlon(DataArray(z, dims=('lat', 'lon'), coords={'lat': np.linspace(100, 95, 4),
+                                                                         'lon': np.linspace(0, 1, 5)}))
+    with pytest.raises(ValueError, match="Longitude"):
+        geodesic.extract_latlon(DataArray(z, dims=('lat', 'lon'), coords={'lat': np.linspace(10, 9, 4),
+                                                                         'lon': np.linspace(400, 401, 5)}))
+    with pytest.raises(ValueError):
+        geodesic.extract_latlon(DataArray(z, dims=('row', 'col')))    # no recognisable lat/lon coordinate
+    with pytest.raises(ValueError):
+        xa.slope(ok, method='geodetic')
+    with pytest.raises(ValueError):
+        xa.aspect(ok, method='geodesic', z_unit='cubit')
+
+
+# ---------------------------------------------------------------- zonal host arithmetic
+def test_finalize_stats_from_partials():
+    rng = np.random.default_rng(3)
+    v = rng.normal(50, 20, (40, 30))
+    z = rng.integers(0, 4, v.shape)
+    count = np.array([(z == k).sum() for k in range(4)], dtype=np.int64)
+    s1 = np.array([v[z == k].sum() for k in range(4)])
+    s2 = np.array([(v[z == k] ** 2).sum() for k in range(4)])
+    mn = np.array([v[z == k].min() for k in range(4)])
+    mx = np.array([v[z == k].max() for k in range(4)])
+    out = zonal.finalize_stats(['mean', 'max', 'min', 'sum', 'std', 'var', 'count'], count, s1, s2, mn, mx)
+    for k in range(4):
+        np.testing.assert_allclose(out['mean'][k], v[z == k].mean(), rtol=1e-12)
+        np.testing.assert_allclose(out['var'][k], v[z == k].var(), rtol=1e-9)
+        np.testing.assert_allclose(out['std'][k], v[z == k].std(), rtol=1e-9)
+        assert out['count'][k] == count[k] and out['max'][k] == mx[k] and out['min'][k] == mn[k]
+
+    # the same partials split over two row shards combine to the same moments (row e1 of SURVEY 8e)
+    halves = []
+    for rows in (slice(0, 17), slice(17, 40)):
+        zz, vv = z[rows], v[rows]
+        halves.append((np.array([(zz == k).sum() for k in range(4)], dtype=np.int64),
+                       np.array([vv[zz == k].sum() for k in range(4)]),
+                       np.array([(vv[zz == k] ** 2).sum() for k in range(4)]),
+                       np.array([vv[zz == k].min() for k in range(4)]),
+                       np.array([vv[zz == k].max() for k in range(4)])))
+    c, a1, a2, lo, hi = combine_zonal_partials(halves)
+    np.testing.assert_array_equal(c, count)
+    np.testing.assert_allclose(a1, s1, rtol=1e-13)
+    np.testing.assert_allclose(a2, s2, rtol=1e-13)
+    np.testing.assert_array_equal(lo, mn)
+    np.testing.assert_array_equal(hi, mx)
+
+
+def test_dense_zone_index_host():
+    z = np.array([[7, 7, -3], [1000000, 7, -3]], dtype=np.int64)
+    ids, idx = zonal._dense_zone_index(z)
+    np.testing.assert_array_equal(ids, [-3, 7, 1000000])
+    np.testing.assert_array_equal(idx, [[1, 1, 0], [2, 1, 0]])
+    assert idx.dtype == np.int32 and ids.dtype == z.dtype
+    # float zones: NaN / inf cells belong to no zone, non-integral ids take the sort path
+    zf = np.array([[0.5, np.nan, 2.0], [np.inf, 0.5, -1.0]])
+    ids, idx = zonal._dense_zone_index(zf)
+    np.testing.assert_array_equal(ids, [-1.0, 0.5, 2.0])
+    np.testing.assert_array_equal(idx, [[1, -1, 2], [-1, 1, 0]])
+    # ids too far apart for a lookup table
+    zw = np.array([[-2**40, 5], [2**40, 5]], dtype=np.int64)
+    ids, idx = zonal._dense_zone_index(zw)
+    np.testing.assert_array_equal(ids, [-2**40, 5, 2**40])
+    np.testing.assert_array_equal(idx, [[0, 1], [2, 1]])
+    ids, idx = zonal._dense_zone_index(np.full((2, 2), np.nan))
+    assert ids.size == 0 and (idx == -1).all()
+
+
+def test_shard_geometry():
+    # shards tile the rows exactly, halos stop at the raster edge
+    for rows, n in ((16384, 8), (1001, 3), (7, 7), (5, 8)):
+        cuts = [shard_rows(rows, n, r) for r in range(n)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == rows
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(n - 1))
+        assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+        for r, (a, b) in enumerate(cuts):
+            top, bot = shard_halos(n, r, 12)
+            assert top == (12 if r > 0 else 0) and bot == (12 if r < n - 1 else 0)
+
+
+def test_xarray_stand_in_round_trip():
+    r = raster(np.arange(12.0).reshape(3, 4), attrs={'unit': 'm'})
+    assert r.shape == (3, 4) and r.ndim == 2 and r.dims == ('y', 'x')
+    assert list(r.coords) == ['x', 'y'] or set(r.coords) == {'x', 'y'}
+    np.testing.assert_array_equal(r.values, np.arange(12.0).reshape(3, 4))
+    with pytest.raises(ValueError):
+        DataArray(np.zeros((3, 4)), dims=('y',))
+    ds = Dataset({'a': r, 'b': r})
+    assert list(ds.data_vars) == ['a', 'b']
+    with pytest.raises(KeyError):
+        ds['c']
+
+
+def test_every_device_entry_point_refuses_to_run_without_the_gpu():
+    """No silent CPU path: with arguments that pass validation, each public function must raise the
+    library's own error on a box without a GPU (on a GPU box this test is a no-op)."""
+    if utils.has_hip():
+        pytest.skip("GPU present")
+    r = raster(np.random.default_rng(0).random((16, 16)).astype(np.float32))
+    z = raster(np.zeros((16, 16), dtype=np.int32))
+    k = np.ones((3, 3))
+    calls = [
+        lambda: xa.slope(r), lambda: xa.aspect(r), lambda: xa.curvature(r), lambda: xa.hillshade(r),
+        lambda: focal.mean(r), lambda: focal.apply(r, k), lambda: focal.focal_stats(r, k),
+        lambda: focal.hotspots(r, k), lambda: convolution.convolution_2d(r, k),
+        lambda: convolution.convolve_2d(r.data, k), lambda: multispectral.ndvi(r, r),
+        lambda: multispectral.evi(r, r, r), lambda: multispectral.savi(r, r),
+        lambda: zonal.stats(z, r), lambda: zonal.crosstab(z, z),
+    ]
+    for call in calls:
+        with pytest.raises(xa.XrsError):
+            call()

@@ -2,22 +2,26 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of the hot path over one raster: `hillshade(dem)` followed by the 5x5
-circular focal mean `focal.apply(dem, circle_kernel(1, 1, 2))` (BASELINE.json `metric`:
-"hillshade+focal.mean on 16k^2 f32 DEM"; SURVEY.md fact 4 maps "focal.mean(5x5)" onto focal.apply).
-Both go through the C ABI of libxrs_hip.so on this process's HIP stream.  Inputs are staged in HBM
-before the timed region.
+One "step" = one pass of the hot path over one raster: `hillshade(dem)` and the 5x5 circular focal
+mean `focal.apply(dem, circle_kernel(1, 1, 2))` (BASELINE.json `metric`: "hillshade+focal.mean on
+16k^2 f32 DEM"; SURVEY.md fact 4 maps "focal.mean(5x5)" onto focal.apply).  Both products of the step
+come from ONE launch of the fused raster pass (`xrs_raster_pass_f32`, csrc/pass.hip: the DEM is read
+once, 4 B in + 2 x 4 B out per cell) -- what `with xrspatial_amd.fuse():` around the two reference
+calls runs; results are bit-identical to the two stand-alone kernels (tests/test_gpu_parity.py).
+`--unfused` times the two stand-alone launches instead (16 B per cell), and the default run reports
+that form too (`config.unfused`, outside the timed region).  Everything goes through the C ABI of
+libxrs_hip.so on this process's HIP stream.  Inputs are staged in HBM before the timed region.
 
 N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
 one process per GPU, weak scaling -- every rank owns a 16384 x 16384 row-shard of a
 (16384*N) x 16384 raster; each step starts with ONE RCCL halo exchange (2 rows each way over xGMI,
-enough for both operators) and then runs the same two kernels with halo_top/halo_bot set.
+enough for both operators) and then runs the same pass with halo_top/halo_bot set.
 torch.distributed (gloo) is used only for rendezvous, the barriers and the max-over-ranks of the
 elapsed time; no tensor ever touches the GPU through torch.
 
 Prints ONE JSON line (rank 0): metric/value in Mcells/s (raster cells through the whole step, all
 ranks), `roofline` for the dominant kernel (HIP-event time on the launch stream, algorithmic
-8 B/cell), `cpu_baseline` = the CPU oracle timed on this box on a bounded band of the same raster.
+12 B/cell fused, 8 B/cell for either stand-alone kernel), `cpu_baseline` = the CPU oracle timed on this box on a bounded band of the same raster.
 """
 import argparse
 import ctypes
@@ -35,7 +39,8 @@ ROWS_PER_GPU = 16384
 COLS = 16384
 HALO = 2                      # 5x5 focal window; hillshade needs 1 of them
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
-ALG_BYTES_PER_CELL = 8        # 4 B read + 4 B written per cell, either kernel
+ALG_BYTES_FUSED = 12          # fused pass: 4 B read + 4 B hillshade + 4 B focal mean written per cell
+ALG_BYTES_PER_CELL = 8        # stand-alone kernels: 4 B read + 4 B written per cell
 
 
 def main():
@@ -45,6 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)     # the clocks settle over the first ~15 launches (profiles/r01)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--unfused", action="store_true",
+                    help="time hillshade and the focal mean as two stand-alone launches instead of the fused pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="experiment: do not record per-kernel HIP events inside the timed region")
@@ -142,6 +149,18 @@ def main():
             L("xrs_memcpy_h2d", dem_ptr + rows * cols * 4, small[3 * HALO:4 * HALO].ctypes.data, HALO * cols * 4, stream)
         L("xrs_stream_sync", stream)
 
+    def launch_hillshade():
+        L("xrs_hillshade_f32", dem_ptr, out_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0,
+          min(ht, 1), min(hb, 1), stream)
+
+    def launch_focal():
+        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc, None,
+          ht, hb, stream)
+
+    def launch_fused():
+        L("xrs_raster_pass_f32", dem_ptr, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data, kr, kc,
+          None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, ht, hb, stream)
+
     def step(events=None):
         if comm is not None:
             L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, stream)
@@ -149,12 +168,15 @@ def main():
             halo_exchange_through_host()
         if events:
             L("xrs_event_record", events[0], stream)
-        L("xrs_hillshade_f32", dem_ptr, out_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0,
-          min(ht, 1), min(hb, 1), stream)
-        if events:
-            L("xrs_event_record", events[1], stream)
-        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc, None,
-          ht, hb, stream)
+        if args.unfused:
+            launch_hillshade()
+            if events:
+                L("xrs_event_record", events[1], stream)
+            launch_focal()
+        else:
+            launch_fused()
+            if events:
+                L("xrs_event_record", events[1], stream)
         if events:
             L("xrs_event_record", events[2], stream)
 
@@ -192,6 +214,7 @@ def main():
         L("xrs_event_elapsed_ms", e[1], e[2], ctypes.byref(ms))
         focal_ms.append(ms.value)
     hill_avg, focal_avg = (float(np.mean(hill_ms)), float(np.mean(focal_ms))) if hill_ms else (float("nan"), float("nan"))
+    # (fused: events[0] -> events[1] brackets the single launch; [1] -> [2] is empty)
 
     # Correctness of the sharded run, outside the timed region: the rows either side of every shard boundary
     # (the ones that depend on exchanged halo rows) are compared with the CPU oracle on a regenerated band.
@@ -254,6 +277,12 @@ def main():
             L("xrs_event_elapsed_ms", e0, e1, ctypes.byref(ms))
             return ms.value / reps
 
+        if not args.unfused:
+            # the same step as two stand-alone launches (what two eager reference-style calls run)
+            u_h, u_f = timed(launch_hillshade, reps=10), timed(launch_focal, reps=10)
+            extra["unfused"] = {"hillshade_ms": round(u_h, 4), "focal_mean_5x5_ms": round(u_f, 4),
+                                "ms_per_step": round(u_h + u_f, 4),
+                                "mcells_s": round(rows * cols / ((u_h + u_f) * 1e-3) / 1e6, 1)}
         k25 = np.ascontiguousarray(circle_kernel(1, 1, 12), dtype=np.float64)
         extra["other_kernels_ms"] = {
             "slope": round(timed(lambda: L("xrs_slope_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0, 0, 0, stream)), 4),
@@ -280,9 +309,16 @@ def main():
     cells_rank = rows * cols
     ms_per_step = elapsed / args.steps * 1e3
     value = cells_rank * world / (elapsed / args.steps) / 1e6
-    dom_name, dom_ms = ("focal_mean_direct_kernel<5,5,4>", focal_avg) if focal_avg >= hill_avg else \
-        ("terrain_strip_kernel<hillshade,float,4>", hill_avg)
-    achieved = ALG_BYTES_PER_CELL * cells_rank / (dom_ms * 1e-3) / 1e9
+    if args.unfused:
+        dom_name, dom_ms = ("focal_mean_direct_kernel<5,5,4>", focal_avg) if focal_avg >= hill_avg else \
+            ("terrain_strip_kernel<hillshade,float,4>", hill_avg)
+        alg_bytes = ALG_BYTES_PER_CELL
+        kernel_ms = {"hillshade": round(hill_avg, 4), "focal_mean_5x5": round(focal_avg, 4)}
+    else:
+        dom_name, dom_ms = "raster_pass_kernel<hillshade,5,5,4>", hill_avg
+        alg_bytes = ALG_BYTES_FUSED
+        kernel_ms = {"raster_pass(hillshade + focal_mean_5x5)": round(hill_avg, 4)}
+    achieved = alg_bytes * cells_rank / (dom_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):              # HBM bytes/launch from a separate rocprofv3 --pmc run (see profiles/README.md)
@@ -305,12 +341,15 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"hillshade + focal.apply(mean, circle_kernel r=2 -> 5x5/13 taps) on a "
-                        f"{rows}x{cols} float32 DEM per GPU (BASELINE configs[1]/[2] raster), HBM-resident",
+                        f"{rows}x{cols} float32 DEM per GPU (BASELINE configs[1]/[2] raster), HBM-resident; "
+                        + ("two stand-alone launches per step" if args.unfused else
+                           "both products from one fused pass per step (xrs_raster_pass_f32)"),
+            "fused": not args.unfused,
             "rows_per_gpu": rows, "cols": cols, "global_rows": total_rows,
             "sharding": "rows" if world > 1 else "none",
             "halo_exchange": halo_via,
             "halo_check": halo_check,
-            "kernel_ms": {"hillshade": round(hill_avg, 4), "focal_mean_5x5": round(focal_avg, 4)},
+            "kernel_ms": kernel_ms,
             **extra,
         },
         "roofline": {
@@ -321,10 +360,11 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL * cells_rank,
+            "algorithmic_bytes_per_launch": alg_bytes * cells_rank,
             "launch_ms": round(dom_ms, 4),
             "measured_copy_gbs": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+            "algorithmic_bytes_per_cell": alg_bytes,
         },
     }
     if world == 1 and not args.no_cpu_baseline:

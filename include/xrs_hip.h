@@ -94,6 +94,21 @@ int xrs_terrain_fused_f32(const float *in_dev, float *slope_dev, float *aspect_d
                           double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
                           int halo_top, int halo_bot, void *stream);
 
+/* Fused raster pass: ONE read of the raster, any subset of the four terrain products plus a focal mean
+ * (focal.apply / focal_stats 'mean' with a 0/1 mask).  Replaces a sequence of separate reference passes over
+ * the same DataArray -- hillshade (xrspatial/hillshade.py:20-35), slope (slope.py:56-76), aspect
+ * (aspect.py:56-90), curvature (curvature.py:31-49), focal.apply with _calc_mean (focal.py:226-228, 305-326)
+ * -- and returns bit-identical results to the separate entry points above / xrs_focal_stats_f32.
+ * Any output pointer may be NULL.  3x3 and 5x5 masks on 16-byte-friendly rasters run as one kernel
+ * (4 B read + 4 B written per product per cell); other shapes fall back to the separate launches
+ * (`work_dev`: as for xrs_focal_stats_f32, may be NULL for masks up to 5x5).
+ * Row shards: halo_top / halo_bot must be 0 (true raster edge) or >= max(1, krows/2). */
+int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                        float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                        int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                        double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
+                        int halo_top, int halo_bot, void *stream);
+
 /* Geodesic slope / aspect (method='geodesic'): WGS-84 ECEF -> local ENU plane fit per 3x3 window, float64
  * arithmetic, float32 out, NaN border, NaN if any of the nine elevations is NaN.  Replaces
  * _cpu_geodesic_slope / _cpu_geodesic_aspect (xrspatial/geodesic.py:181-229) behind slope.py:167-174 and

@@ -440,6 +440,124 @@ def test_fused_terrain_equals_separate():
     np.testing.assert_array_equal(outs[3].get().astype(np.float64), xs.hillshade(agg).data)
 
 
+def _raster_pass(z, want, kernel, halo=(0, 0), rows=None, first_row=0, res=(30.0, 20.0), light=(225.0, 25.0)):
+    """xrs_raster_pass_f32 on rows [first_row, first_row+rows) of `z`; returns {product: host array}."""
+    from xrspatial_amd import _lib
+    full = xs.DeviceArray.from_numpy(z)
+    rows = z.shape[0] if rows is None else rows
+    cols = z.shape[1]
+    outs = {s: xs.DeviceArray((rows, cols), np.float32) for s in want}
+    ptr = lambda s: outs[s].ptr if s in outs else None          # noqa: E731
+    k = None if kernel is None else np.ascontiguousarray(kernel, dtype=np.float64)
+    work = None
+    if k is not None and max(k.shape) > 5:
+        work = xs.DeviceArray((max(int(_lib.load().xrs_kxk_workspace_bytes(*k.shape)), 16),), np.uint8)
+    _lib.call("xrs_raster_pass_f32", full.ptr + first_row * cols * 4, ptr('slope'), ptr('aspect'), ptr('curvature'),
+              ptr('hillshade'), ptr('focal_mean'), None if k is None else k.ctypes.data,
+              0 if k is None else k.shape[0], 0 if k is None else k.shape[1], None if work is None else work.ptr,
+              rows, cols, cols, cols, res[0], res[1], light[0], light[1], halo[0], halo[1], None)
+    _lib.call("xrs_stream_sync", None)
+    return {s: a.get() for s, a in outs.items()}
+
+
+def _separate(z, kernel, res=(30.0, 20.0), light=(225.0, 25.0)):
+    agg = raster(z, res=res, backend='hip')
+    out = {'slope': xs.slope(agg), 'aspect': xs.aspect(agg), 'curvature': xs.curvature(agg),
+           'hillshade': xs.hillshade(agg, azimuth=light[0], angle_altitude=light[1])}
+    if kernel is not None:
+        out['focal_mean'] = apply(agg, kernel)
+    return {s: host(v.data) for s, v in out.items()}
+
+
+@pytest.mark.parametrize("shape", [(64, 512), (37, 260), (130, 1024), (3, 8), (16, 256)])
+def test_raster_pass_equals_separate_launches(shape):
+    """The fused pass (one read of the raster) returns bit-identical products to the stand-alone kernels:
+    every product subset the kernel is instantiated for, 3x3 and 5x5 masks, NaN / inf cells, raster edges."""
+    rng = np.random.default_rng(shape[1])
+    z = synth.smooth_dem(shape, nan_frac=0.01)
+    if shape[0] > 8:
+        z[shape[0] // 2, shape[1] // 3] = np.inf
+        z[5, 7] = -np.inf
+    masks = {'circle5': circle_kernel(1, 1, 2), 'box3': np.ones((3, 3)), 'cross3': circle_kernel(1, 1, 1),
+             'ragged5': (rng.random((5, 5)) < 0.6).astype(float)}
+    masks['ragged5'][2, 2] = 1.0
+    subsets = [('hillshade',), ('slope', 'hillshade'), ('slope', 'aspect', 'curvature', 'hillshade'),
+               ('aspect',), ('curvature', 'slope')]
+    for mname, k in masks.items():
+        ref = _separate(z, k)
+        for sub in subsets:
+            got = _raster_pass(z, sub + ('focal_mean',), k)
+            for s in got:
+                np.testing.assert_array_equal(got[s], ref[s], err_msg=f"{mname} {sub} {s}")
+
+
+def test_raster_pass_fallbacks_and_shards():
+    """Shapes outside the fused kernel (unaligned width, 7x7 / 25x25 masks, terrain only, focal only) give the
+    same results through separate launches; row shards with halos reproduce the monolithic pass."""
+    z = synth.smooth_dem((96, 1024), nan_frac=0.005)
+    k5 = circle_kernel(1, 1, 2)
+    ref = _separate(z, k5)
+    # row shards: halo rows live in the same allocation, above / below the owned rows
+    for first, rows, halo in ((0, 40, (0, 2)), (40, 31, (2, 2)), (71, 25, (2, 0)), (40, 31, (5, 7))):
+        got = _raster_pass(z, ('slope', 'hillshade', 'focal_mean'), k5, halo=halo, rows=rows, first_row=first)
+        for s in got:
+            np.testing.assert_array_equal(got[s], ref[s][first:first + rows], err_msg=f"shard {first} {s}")
+    # products only / focal only
+    got = _raster_pass(z, ('slope', 'aspect', 'curvature', 'hillshade'), None)
+    for s in got:
+        np.testing.assert_array_equal(got[s], ref[s])
+    np.testing.assert_array_equal(_raster_pass(z, ('focal_mean',), k5)['focal_mean'], ref['focal_mean'])
+    # larger masks
+    for k in (circle_kernel(1, 1, 3), circle_kernel(1, 1, 12)):
+        r2 = _separate(z, k)
+        got = _raster_pass(z, ('hillshade', 'focal_mean'), k)
+        np.testing.assert_array_equal(got['hillshade'], r2['hillshade'])
+        np.testing.assert_array_equal(got['focal_mean'], r2['focal_mean'])
+    # width not a multiple of 4
+    zu = synth.smooth_dem((33, 301), nan_frac=0.01)
+    r3 = _separate(zu, k5)
+    got = _raster_pass(zu, ('slope', 'hillshade', 'focal_mean'), k5)
+    for s in got:
+        np.testing.assert_array_equal(got[s], r3[s])
+    # against the oracle directly (not only against the stand-alone kernels)
+    np.testing.assert_allclose(ref['focal_mean'], orc.focal_apply(z, k5, 'mean'), rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(ref['hillshade'], orc.hillshade(z), rtol=RTOL, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("backend", ['numpy', 'hip'])
+def test_fuse_scope(backend):
+    """`with xrspatial_amd.fuse():` -- the reference's call sites, one pass per raster."""
+    z = synth.smooth_dem((70, 520), nan_frac=0.01)
+    z2 = synth.smooth_dem((40, 256), seed=5)
+    k5, k3 = circle_kernel(1, 1, 2), np.ones((3, 3))
+    a, b = raster(z, res=(10.0, 10.0), backend=backend), raster(z2, res=(1.0, 2.0), backend=backend)
+    eager = {'h': xs.hillshade(a), 'f': apply(a, k5), 's': xs.slope(a), 'c': xs.curvature(a), 'asp': xs.aspect(a),
+             'h2': xs.hillshade(a, azimuth=90, angle_altitude=45), 'bs': xs.slope(b), 'bf': apply(b, k3),
+             'sum': apply(a, k5, _calc_sum)}
+    with xs.fuse() as scope:
+        got = {'h': xs.hillshade(a), 'f': apply(a, k5, name='smooth'), 's': xs.slope(a), 'c': xs.curvature(a),
+               'asp': xs.aspect(a), 'h2': xs.hillshade(a, azimuth=90, angle_altitude=45), 'bs': xs.slope(b),
+               'bf': apply(b, k3)}
+        got['sum'] = apply(a, k5, _calc_sum)                      # not fusable: runs eagerly inside the scope
+        assert isinstance(got['h'].data, xs.fused.PendingResult) and got['h'].shape == z.shape
+        with pytest.raises(RuntimeError):
+            got['h'].values
+    assert scope.launches == 3                                       # raster a: 2 passes (two hillshades), b: 1
+    assert got['f'].name == 'smooth' and got['h'].name == 'hillshade'
+    for key, want in eager.items():
+        g, w = host(got[key].data), host(want.data)
+        assert g.dtype == w.dtype and type(got[key].data) is type(want.data), key
+        np.testing.assert_array_equal(g, w, err_msg=key)
+        check_meta(a if key[0] != 'b' else b, got[key])
+    # an exception inside the scope discards the recorded calls
+    with pytest.raises(KeyError):
+        with xs.fuse() as scope2:
+            pend = xs.slope(a)
+            raise KeyError('boom')
+    assert scope2.launches == 0 and isinstance(pend.data, xs.fused.PendingResult)
+    assert xs.fused.current() is None
+
+
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
 @pytest.fixture(scope="module")
 def dem16k():

@@ -138,6 +138,28 @@ def main():
         "curvature": (lambda: L("xrs_curvature_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 0, 0, S), 8),
         "terrain_fused4": (lambda: L("xrs_terrain_fused_f32", dem.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr,
                                      outs[3].ptr, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 20),
+        "pass_hill_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, None, None, None, outs[3].ptr, outs[4].ptr,
+                                       k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 12),
+        "pass_hill_slope_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, outs[0].ptr, None, None, outs[3].ptr,
+                                             outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0,
+                                             25.0, 0, 0, S), 16),
+        "pass_all4_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr,
+                                       outs[3].ptr, outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0,
+                                       225.0, 25.0, 0, 0, S), 24),
+        "pass_aspect_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, None, outs[1].ptr, None, None,
+                                         outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0,
+                                         25.0, 0, 0, S), 12),
+        "pass_slope_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, outs[0].ptr, None, None, None,
+                                        outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0,
+                                        25.0, 0, 0, S), 12),
+        "pass_curv_hill_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, None, None, outs[2].ptr, outs[3].ptr,
+                                            outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0,
+                                            25.0, 0, 0, S), 16),
+        "pass_slope_curv_hill_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, outs[0].ptr, None, outs[2].ptr,
+                                                  outs[3].ptr, outs[4].ptr, k5.ctypes.data, 5, 5, None, n, n, n, n,
+                                                  1.0, 1.0, 225.0, 25.0, 0, 0, S), 20),
+        "pass_hill_focal3": (lambda: L("xrs_raster_pass_f32", dem.ptr, None, None, None, outs[3].ptr, outs[4].ptr,
+                                       k3.ctypes.data, 3, 3, None, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 12),
         "ndvi": (lambda: L("xrs_normalized_ratio_f32", dem.ptr, b2.ptr, outs[0].ptr, cells, S), 12),
         "evi": (lambda: L("xrs_evi_f32", dem.ptr, b2.ptr, b3.ptr, outs[0].ptr, cells, 6.0, 7.5, 1.0, 2.5, S), 16),
         "savi": (lambda: L("xrs_savi_f32", dem.ptr, b2.ptr, outs[0].ptr, cells, 1.0, S), 12),
@@ -160,7 +182,7 @@ def main():
     only = [s for s in args.only.split(",") if s]
     timer = Timer()
     results = {}
-    print(f"{'kernel':20s} {'ms(med)':>9s} {'ms(min)':>9s} {'Mcells/s':>11s} {'GB/s(alg)':>10s}")
+    print(f"{'kernel':28s} {'ms(med)':>9s} {'ms(min)':>9s} {'Mcells/s':>11s} {'GB/s(alg)':>10s}")
     for name_, (fn, bpc) in cases.items():
         if only and name_ not in only:
             continue
@@ -168,7 +190,7 @@ def main():
         med, mn = timer.time(fn, reps, warmup=2)
         gbs = cells * bpc / (med * 1e-3) / 1e9
         results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs}
-        print(f"{name_:20s} {med:9.3f} {mn:9.3f} {cells / (med * 1e-3) / 1e6:11.0f} {gbs:10.0f}", flush=True)
+        print(f"{name_:28s} {med:9.3f} {mn:9.3f} {cells / (med * 1e-3) / 1e6:11.0f} {gbs:10.0f}", flush=True)
     if args.json:
         with open(args.json, "w") as fh:
             json.dump({"size": n, "results": results}, fh, indent=1)

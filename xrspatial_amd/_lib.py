@@ -60,6 +60,9 @@ _PROTOTYPES = {
                           c_int, c_int, c_void_p],
     "xrs_terrain_fused_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                               c_int64, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p],
+    "xrs_raster_pass_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                            c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_double, c_double, c_double,
+                            c_int, c_int, c_void_p],
     "xrs_geodesic_workspace_bytes": [c_int64, c_int64],
     "xrs_geodesic_f32": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64,
                          c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int, c_int, c_void_p],

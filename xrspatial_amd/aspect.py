@@ -5,6 +5,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import fused
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
@@ -37,6 +38,9 @@ def aspect(agg: DataArray,
             raise TypeError("Unsupported Array Type: {}".format(type(agg)))
         out = run_geodesic(agg.data, lat, lon, is_2d, z_factor, aspect=1)
         return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)
+    scope = fused.current()
+    if scope is not None:
+        return scope.defer('aspect', agg, name, {})
     mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
     out = mapper(agg)(agg.data)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

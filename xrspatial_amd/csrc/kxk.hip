@@ -16,7 +16,7 @@
 // float64 for mean / var / std / convolution (Numba nanmean / nanvar; `num = 0.0`),
 // float32 row-major for `sum` (Numba nansum keeps the array dtype).
 // No MFMA: 0/1 masks with NaN-skipping are not a dense contraction.
-#include "xrs_common.h"
+#include "strip.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -180,15 +180,6 @@ __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile,
             }
         }
     }
-}
-
-// Fast reciprocal of a small positive count in float64: v_rcp_f64 + one Newton step (error ~1e-16,
-// invisible after the float32 rounding of the result).  0 -> NaN after the multiply, like 0/0.
-__device__ __forceinline__ double rcp_count(int n) {
-    const double c = (double)n;
-    double r = __builtin_amdgcn_rcp(c);
-    r = fma(fma(-c, r, 1.0), r, r);
-    return n ? r : nan("");
 }
 
 // ------------------------------------------------------------------ focal statistics
@@ -376,60 +367,6 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
 // Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
 // row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
 // sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
-struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at dword alignment
-
-// Strip loader shared by the register-resident kernels: v[r][0..NV) = columns x0-RX .. x0+3+RX of input
-// row y0 - RY + r (NaN outside the raster / the shard's halo rows).  INTERIOR: no predicates at all.
-template <int KH, int KW, int RB, bool INTERIOR>
-__device__ __forceinline__ void load_strip(const KxkArgs &a, long x_tile, long y0, int lane,
-                                           float (&v)[RB + KH - 1][4 + 2 * (KW / 2)]) {
-    constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
-    const long x0 = x_tile + lane * 4;
-    const unsigned loff = (unsigned)lane * 4u;
-    const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
-    const float qnan = nan_f32();
-    const bool has_l = INTERIOR || x0 >= 4;          // x0 is a multiple of 4 and RX <= 3
-    const bool has_r = INTERIOR || x0 + 8 <= a.cols;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const long y = y0 - RY + r;
-        const bool ok = INTERIOR || (y >= y_lo && y < y_hi);
-        const float *p = (a.in + y * a.ld_in + x_tile) + loff;       // scalar row base + lane offset
-        if (!INTERIOR) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[r][i] = qnan;
-        }
-        if (ok) {
-            if (!(RX == 2 && INTERIOR)) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(p);
-                v[r][RX] = c4.x; v[r][RX + 1] = c4.y; v[r][RX + 2] = c4.z; v[r][RX + 3] = c4.w;
-            }
-            if (RX == 1) {
-                if (has_l) v[r][0] = p[-1];
-                if (has_r) v[r][NV - 1] = p[4];
-            } else if (RX == 2 && INTERIOR) {
-                // the 8 cells x0-2 .. x0+5 as two 16-byte loads at 8-byte alignment (global loads only need
-                // dword alignment): one instruction fewer per row than float2 + float4 + float2
-                const F4U lo = *reinterpret_cast<const F4U *>(p - 2), hi = *reinterpret_cast<const F4U *>(p + 2);
-                v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w;
-                v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
-            } else if (RX == 2) {
-                if (has_l) { const float2 l2 = *reinterpret_cast<const float2 *>(p - 2); v[r][0] = l2.x; v[r][1] = l2.y; }
-                if (has_r) { const float2 r2 = *reinterpret_cast<const float2 *>(p + 4); v[r][NV - 2] = r2.x; v[r][NV - 1] = r2.y; }
-            } else {                                           // RX == 3 (7-wide): aligned float4 each side, 3 used
-                if (has_l) { const float4 l4 = *reinterpret_cast<const float4 *>(p - 4); v[r][0] = l4.y; v[r][1] = l4.z; v[r][2] = l4.w; }
-                if (has_r) { const float4 r4 = *reinterpret_cast<const float4 *>(p + 4); v[r][NV - 3] = r4.x; v[r][NV - 2] = r4.y; v[r][NV - 1] = r4.z; }
-            }
-        }
-    }
-}
-
-template <int KH, int KW, int RB>
-__device__ __forceinline__ bool strip_is_interior(const KxkArgs &a, long x_tile, long y0) {
-    return x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - KH / 2 >= -(long)a.halo_top &&
-           y0 + RB + KH / 2 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
-}
-
 template <int KH, int KW, int RB, bool INTERIOR>
 __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;

@@ -1,0 +1,270 @@
+// Fused raster pass: any subset of the 3x3 terrain products (slope, aspect, curvature, hillshade) PLUS a
+// focal mean over a 3x3 / 5x5 mask, from ONE read of the raster.
+//
+// The reference runs every product as its own full pass over the DataArray
+//   hillshade(agg)            xrspatial/hillshade.py:20-35
+//   slope(agg) / aspect(agg)  xrspatial/slope.py:56-76, xrspatial/aspect.py:56-90
+//   curvature(agg)            xrspatial/curvature.py:31-49
+//   focal.apply(agg, kernel)  xrspatial/focal.py:305-326 with _calc_mean (:226-228)
+// so a hillshade + focal-mean pipeline moves 16 B per cell (two reads, two writes).  All these products are
+// functions of the same small neighbourhood, the work is HBM-bound, and the register-resident strip layout of
+// the stand-alone kernels (strip.h) already holds a superset of the 3x3 neighbourhood when it holds the 5x5
+// one -- so the fused kernel reads each cell once (4 B) and writes 4 B per product: 12 B per cell for
+// hillshade + focal mean, 16 B for hillshade + slope + focal mean (the 65536^2 target pipeline, 24 B unfused).
+// Arithmetic is the stand-alone kernels' (terrain_cells.h, focal_mean_direct_kernel): results are
+// bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
+//
+// Rasters / kernels outside the fast shape (pitch or width not a multiple of 4, mask larger than 5x5) run as
+// the separate launches -- same results, no fusion.
+#include "strip.h"
+#include "terrain_cells.h"
+
+using namespace xrs;
+
+namespace {
+
+struct PassArgs {
+    const float *in;
+    float *out[4];            // slope, aspect, curvature, hillshade (null = not requested)
+    float *focal;             // focal mean
+    long rows, cols, ld_in, ld_out;
+    int halo_top, halo_bot;
+    double inv8cx, inv8cy, curv_scale;
+    float sin_alt, cos_alt, cos_az, sin_az;
+    unsigned mask_rows[5];    // bit kx of entry ky: tap (ky, kx) selected
+    double inv_ntaps;
+    long tiles_x, n_tiles;
+};
+
+__device__ __forceinline__ void put4(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// OPS: compile-time superset of the terrain products this instantiation can emit (absent ones are skipped by
+// wave-uniform null tests, like terrain.hip's fused kernel).  Returns false when the interior fast path met a
+// non-finite window sum: the caller re-runs the focal part of the strip through the careful body.
+template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool TERRAIN>
+__device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
+    constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
+    const unsigned loff = (unsigned)lane * 4u;
+    const long x0 = x_tile + lane * 4;
+    float v[NR][NV];
+    load_strip<KH, KW, RB, INTERIOR>(a, x_tile, y0, lane, v);
+
+    // ---- terrain products from the 3x3 centre of the registers (first: they need no accumulators, and an
+    // interior strip whose focal sums turn out non-finite keeps them -- the careful re-run skips this part)
+    if (TERRAIN) {
+        const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
+        const float qnan = nan_f32();
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long y = y0 + r;
+            if (!INTERIOR && y >= a.rows) break;
+            const bool row_border = !INTERIOR && ((y - 1 < y_lo) || (y + 1 >= y_hi));
+            float o_slope[4], o_aspect[4], o_curv[4], o_hill[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const long x = x0 + o;
+                const bool border = !INTERIOR && (row_border || x == 0 || x == a.cols - 1);
+                const int c = RX - 1 + o, t = r + RY - 1;
+                Nb q;
+                q.nw = v[t][c];     q.n = v[t][c + 1];     q.ne = v[t][c + 2];
+                q.w = v[t + 1][c];  q.c = v[t + 1][c + 1]; q.e = v[t + 1][c + 2];
+                q.sw = v[t + 2][c]; q.s = v[t + 2][c + 1]; q.se = v[t + 2][c + 2];
+                if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_cell(q, a.inv8cx, a.inv8cy);
+                if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_cell(q);
+                if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
+                if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
+            }
+            const long off = y * a.ld_out + x_tile;
+            if ((OPS & OP_SLOPE) && a.out[0]) put4(a.out[0] + off + loff, o_slope);
+            if ((OPS & OP_ASPECT) && a.out[1]) put4(a.out[1] + off + loff, o_aspect);
+            if ((OPS & OP_CURV) && a.out[2]) put4(a.out[2] + off + loff, o_curv);
+            if ((OPS & OP_HILL) && a.out[3]) put4(a.out[3] + off + loff, o_hill);
+        }
+    }
+
+    // ---- focal mean (float64 accumulation in row-major tap order == numba nanmean over the window)
+    float *fout = a.focal + y0 * a.ld_out + x_tile;
+    if (INTERIOR) {
+        double acc[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+#pragma unroll
+        for (int ir = 0; ir < NR; ++ir) {
+            double d[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
+                    }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
+        if (__any(bad)) return false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float m[4] = {(float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                                (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)};
+            put4(fout + r * a.ld_out + loff, m);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (y0 + r >= a.rows) break;
+            double sum[4] = {0, 0, 0, 0};
+            int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const unsigned bits = a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const float x = v[r + ky][kx + o];
+                            const bool okv = !isnan(x);
+                            sum[o] += okv ? (double)x : 0.0;
+                            cnt[o] += okv ? 1 : 0;
+                        }
+                    }
+            }
+            const float m[4] = {(float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
+                                (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3]))};
+            put4(fout + r * a.ld_out + loff, m);
+        }
+    }
+
+    return true;
+}
+
+template <int OPS, int KH, int KW, int RB>
+__global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) raster_pass_kernel(const PassArgs a) {
+    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    if (t < 0) return;
+    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = tx * 256;
+    const long y0 = ty * (4 * RB) + (long)wy * RB;
+    if (y0 >= a.rows) return;
+    if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
+        if (!pass_body<OPS, KH, KW, RB, true, true>(a, x_tile, y0, lane))
+            pass_body<OPS, KH, KW, RB, false, false>(a, x_tile, y0, lane);      // NaN / inf under a window
+        return;
+    }
+    if (x_tile + lane * 4 >= a.cols) return;
+    pass_body<OPS, KH, KW, RB, false, true>(a, x_tile, y0, lane);
+}
+
+template <int OPS, int K>
+int launch_pass(PassArgs &a, hipStream_t s) {
+    constexpr int RB = 4;
+    a.tiles_x = (a.cols + 255) / 256;
+    a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
+    const long grid = xcd_grid(a.n_tiles);
+    if (grid > 0x7fffffffL) return fail("raster pass: raster too large for one launch");
+    hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Instantiated product sets.  The focal mean fuses well with hillshade / slope / curvature (measured on
+// 16384^2: hillshade+focal 0.61 ms vs 0.82 ms as two launches, hillshade+slope+focal 0.95 vs 1.31); aspect's
+// atan2 on top of the float64 window sums makes the fused kernel VALU-bound, so aspect is left to terrain.hip.
+constexpr int FUSABLE = OP_SLOPE | OP_CURV | OP_HILL;
+
+template <int K>
+int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
+    switch (ops) {
+        case OP_HILL: return launch_pass<OP_HILL, K>(a, s);
+        case OP_SLOPE: return launch_pass<OP_SLOPE, K>(a, s);
+        case OP_CURV: return launch_pass<OP_CURV, K>(a, s);
+        case OP_SLOPE | OP_HILL: return launch_pass<OP_SLOPE | OP_HILL, K>(a, s);
+        case OP_CURV | OP_HILL: return launch_pass<OP_CURV | OP_HILL, K>(a, s);
+        case OP_SLOPE | OP_CURV: return launch_pass<OP_SLOPE | OP_CURV, K>(a, s);
+        case OP_SLOPE | OP_CURV | OP_HILL: return launch_pass<OP_SLOPE | OP_CURV | OP_HILL, K>(a, s);
+        default: return fail("raster pass: internal error, product set %d has no fused kernel", ops);
+    }
+}
+
+}  // namespace
+
+extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                                   float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                                   int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                                   int64_t ld_out, double cellsize_x, double cellsize_y, double azimuth,
+                                   double angle_altitude, int halo_top, int halo_bot, void *stream) {
+    if (!in_dev) return fail("xrs_raster_pass_f32: null input");
+    if (focal_mean_dev && (!kernel || krows <= 0 || kcols <= 0 || !(krows & 1) || !(kcols & 1)))
+        return fail("xrs_raster_pass_f32: a focal mean needs an odd-shaped kernel");
+    int ops = 0;
+    if (slope_dev) ops |= OP_SLOPE;
+    if (aspect_dev) ops |= OP_ASPECT;
+    if (curvature_dev) ops |= OP_CURV;
+    if (hillshade_dev) ops |= OP_HILL;
+    if (rows <= 0 || cols <= 0 || (!ops && !focal_mean_dev)) return 0;
+
+    const int fused_ops = ops & FUSABLE;
+    bool fast = fused_ops && focal_mean_dev && krows == kcols && (krows == 3 || krows == 5) && cols % 4 == 0 &&
+                ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= cols && ld_out >= cols && aligned16(in_dev) &&
+                aligned16(focal_mean_dev) && halo_top >= 0 && halo_bot >= 0;
+    float *outs[4] = {slope_dev, aspect_dev, curvature_dev, hillshade_dev};
+    for (int i = 0; i < 4; ++i)
+        if (fused_ops >> i & 1) fast = fast && aligned16(outs[i]);
+    int ntaps = 0;
+    if (fast) {
+        for (int i = 0; i < krows * kcols; ++i)
+            if (kernel[i] == 1.0) ++ntaps;                    // (cells with any other value are not taps, as in kxk.hip)
+        fast = fast && ntaps > 0;
+    }
+    // products that stay with the stand-alone terrain kernel: all of them without the fused kernel, aspect with it
+    const int rest = fast ? (ops & ~FUSABLE) : ops;
+    if (rest) {
+        const int rc = xrs_terrain_fused_f32(in_dev, (rest & OP_SLOPE) ? slope_dev : nullptr,
+                                             (rest & OP_ASPECT) ? aspect_dev : nullptr,
+                                             (rest & OP_CURV) ? curvature_dev : nullptr,
+                                             (rest & OP_HILL) ? hillshade_dev : nullptr, rows, cols, ld_in, ld_out,
+                                             cellsize_x, cellsize_y, azimuth, angle_altitude, halo_top, halo_bot,
+                                             stream);
+        if (rc) return rc;
+    }
+    if (!fast) {
+        if (!focal_mean_dev) return 0;
+        float *stat_outs[XRS_NUM_STATS] = {nullptr};
+        stat_outs[XRS_STAT_MEAN] = focal_mean_dev;
+        return xrs_focal_stats_f32(in_dev, stat_outs, 1u << XRS_STAT_MEAN, rows, cols, ld_in, ld_out, kernel, krows,
+                                   kcols, work_dev, halo_top, halo_bot, stream);
+    }
+
+    PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev; a.focal = focal_mean_dev;
+    for (int i = 0; i < 4; ++i) a.out[i] = (fused_ops >> i & 1) ? outs[i] : nullptr;
+    a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
+    a.halo_top = halo_top; a.halo_bot = halo_bot;
+    a.inv8cx = 1.0 / (8 * cellsize_x);
+    a.inv8cy = 1.0 / (8 * cellsize_y);
+    const double cs = (cellsize_x + cellsize_y) / 2;       // curvature.py:241
+    a.curv_scale = -200.0 / (cs * cs);
+    hillshade_constants(azimuth, angle_altitude, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
+    for (int ky = 0; ky < krows; ++ky)
+        for (int kx = 0; kx < kcols; ++kx)
+            if (kernel[ky * kcols + kx] == 1.0) a.mask_rows[ky] |= 1u << kx;
+    a.inv_ntaps = 1.0 / ntaps;
+    return krows == 3 ? launch_pass_ops<3>(a, fused_ops, as_stream(stream)) : launch_pass_ops<5>(a, fused_ops, as_stream(stream));
+}

@@ -21,15 +21,13 @@
 //     (xrs::xcd_tile) so vertically adjacent strips share an L2.
 // A scalar one-thread-per-cell kernel handles rasters whose width / pitch /
 // base address are not multiples of 16 bytes.
-#include "xrs_common.h"
+#include "terrain_cells.h"
 
 #include <cstdlib>
 
 using namespace xrs;
 
 namespace {
-
-enum : int { OP_SLOPE = 1, OP_ASPECT = 2, OP_CURV = 4, OP_HILL = 8 };
 
 struct TerrainArgs {
     const float *in;
@@ -41,62 +39,6 @@ struct TerrainArgs {
     float sin_alt, cos_alt, cos_az, sin_az;   // hillshade: az = (360-azimuth) deg - pi/2
     long tiles_x, n_tiles;
 };
-
-// 3x3 neighbourhood, n* = row y-1, s* = row y+1.
-struct Nb { float nw, n, ne, w, c, e, sw, s, se; };
-
-__device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double inv8cy) {
-    // slope.py:64-75: a,b,c = row y+1; g,h,i = row y-1; sums in float64.
-    const double dx = ((((double)q.se + 2.0 * (double)q.e) + (double)q.ne) -
-                       (((double)q.sw + 2.0 * (double)q.w) + (double)q.nw)) * inv8cx;
-    const double dy = ((((double)q.nw + 2.0 * (double)q.n) + (double)q.ne) -
-                       (((double)q.sw + 2.0 * (double)q.s) + (double)q.se)) * inv8cy;
-    const float fx = (float)dx, fy = (float)dy;
-    return atanf(sqrtf(fx * fx + fy * fy)) * 57.29578f;
-}
-
-__device__ __forceinline__ float aspect_cell(const Nb &q) {
-    // aspect.py:66-88: a,b,c = row y-1; g,h,i = row y+1; /8; float64 flat test.
-    const double dx = ((((double)q.ne + 2.0 * (double)q.e) + (double)q.se) -
-                       (((double)q.nw + 2.0 * (double)q.w) + (double)q.sw)) * 0.125;
-    const double dy = ((((double)q.sw + 2.0 * (double)q.s) + (double)q.se) -
-                       (((double)q.nw + 2.0 * (double)q.n) + (double)q.ne)) * 0.125;
-    if (dx == 0.0 && dy == 0.0) return -1.0f;
-    // compass = 90 - atan2(dy, -dx) wrapped to [0, 360)  ==  atan2(-dx, dy) wrapped:
-    // evaluating it this way keeps full relative accuracy near 0 degrees.
-    float deg = atan2f((float)(-dx), (float)dy) * 57.29577951308232f;
-    return deg < 0.0f ? deg + 360.0f : deg;
-}
-
-__device__ __forceinline__ float curvature_cell(const Nb &q, double scale) {
-    // curvature.py:37-39: pair sums float32, the rest float64.
-    const double d = (double)(q.s + q.n) * 0.5 - (double)q.c;
-    const double e = (double)(q.e + q.w) * 0.5 - (double)q.c;
-    return (float)((d + e) * scale);
-}
-
-__device__ __forceinline__ float hillshade_cell(const Nb &q, float sin_alt, float cos_alt,
-                                                float cos_az, float sin_az) {
-    // hillshade.py:24-31 with the trigonometry folded away: for gx = d/drow, gy = d/dcol,
-    //   sin(pi/2 - atan g) = 1/sqrt(1+g^2),  cos(pi/2 - atan g) = g/sqrt(1+g^2),
-    //   cos(A - atan2(-gx, gy)) = (cosA*gy - sinA*gx)/g
-    // => shaded = (sin_alt + cos_alt*(cosA*gy - sinA*gx)) / sqrt(1 + gx^2 + gy^2).
-    const float gx = (q.s - q.n) * 0.5f;
-    const float gy = (q.e - q.w) * 0.5f;
-    if (isinf(gx) || isinf(gy)) {
-        // an infinite gradient (+-inf cell in the DEM): the folded form would give inf * 0; evaluate the
-        // reference's trigonometric chain literally (hillshade.py:25-31), float32 functions, float64 combine
-        const float slope = 1.5707964f - atanf(sqrtf(gx * gx + gy * gy));
-        const float aspect = atan2f(-gx, gy);
-        const float az_off = atan2f(sin_az, cos_az);                    // = azimuth_rad - pi/2
-        const double shaded = (double)sin_alt * (double)sinf(slope) +
-                              (double)cos_alt * (double)cosf(slope) * (double)cosf(az_off - aspect);
-        return (float)((shaded + 1.0) * 0.5);
-    }
-    const float num = fmaf(cos_alt, fmaf(cos_az, gy, -sin_az * gx), sin_alt);
-    const float shaded = num * rsqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
-    return (shaded + 1.0f) * 0.5f;
-}
 
 template <typename OutT>
 __device__ __forceinline__ void store4(OutT *p, const float (&v)[4]);
@@ -279,12 +221,7 @@ TerrainArgs base_args(const float *in, long rows, long cols, long ld_in, long ld
 }
 
 void set_hillshade(TerrainArgs &a, double azimuth, double altitude) {
-    // hillshade.py:23-31: azimuth = 360 - azimuth; A = azimuth*pi/180 - pi/2
-    const double kPi = 3.14159265358979323846;
-    const double az = (360.0 - azimuth) * kPi / 180.0 - kPi / 2.0;
-    const double alt = altitude * kPi / 180.0;
-    a.sin_alt = (float)sin(alt); a.cos_alt = (float)cos(alt);
-    a.cos_az = (float)cos(az);   a.sin_az = (float)sin(az);
+    hillshade_constants(azimuth, altitude, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
 }
 
 }  // namespace

@@ -1,0 +1,88 @@
+// Per-cell arithmetic of the 3x3 terrain family, shared by terrain.hip (one product per launch / the four
+// fused) and pass.hip (terrain products + a focal mean from one read of the raster).
+//
+// Reference runners restated (CPU arithmetic is the contract):
+//   slope      xrspatial/slope.py:56-76       aspect     xrspatial/aspect.py:56-90
+//   curvature  xrspatial/curvature.py:31-49   hillshade  xrspatial/hillshade.py:20-35
+#pragma once
+#include "xrs_common.h"
+
+namespace xrs {
+
+enum : int { OP_SLOPE = 1, OP_ASPECT = 2, OP_CURV = 4, OP_HILL = 8 };
+
+// 3x3 neighbourhood, n* = row y-1, s* = row y+1.
+struct Nb { float nw, n, ne, w, c, e, sw, s, se; };
+
+__device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double inv8cy) {
+#pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically
+    // slope.py:64-75: a,b,c = row y+1; g,h,i = row y-1; sums in float64.
+    const double dx = ((((double)q.se + 2.0 * (double)q.e) + (double)q.ne) -
+                       (((double)q.sw + 2.0 * (double)q.w) + (double)q.nw)) * inv8cx;
+    const double dy = ((((double)q.nw + 2.0 * (double)q.n) + (double)q.ne) -
+                       (((double)q.sw + 2.0 * (double)q.s) + (double)q.se)) * inv8cy;
+    const float fx = (float)dx, fy = (float)dy;
+    return atanf(sqrtf(fx * fx + fy * fy)) * 57.29578f;
+}
+
+__device__ __forceinline__ float aspect_cell(const Nb &q) {
+#pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically
+    // aspect.py:66-88: a,b,c = row y-1; g,h,i = row y+1; /8; float64 flat test.
+    const double dx = ((((double)q.ne + 2.0 * (double)q.e) + (double)q.se) -
+                       (((double)q.nw + 2.0 * (double)q.w) + (double)q.sw)) * 0.125;
+    const double dy = ((((double)q.sw + 2.0 * (double)q.s) + (double)q.se) -
+                       (((double)q.nw + 2.0 * (double)q.n) + (double)q.ne)) * 0.125;
+    if (dx == 0.0 && dy == 0.0) return -1.0f;
+    // compass = 90 - atan2(dy, -dx) wrapped to [0, 360)  ==  atan2(-dx, dy) wrapped:
+    // evaluating it this way keeps full relative accuracy near 0 degrees.
+    float deg = atan2f((float)(-dx), (float)dy) * 57.29577951308232f;
+    return deg < 0.0f ? deg + 360.0f : deg;
+}
+
+__device__ __forceinline__ float curvature_cell(const Nb &q, double scale) {
+#pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically
+    // curvature.py:37-39: pair sums float32, the rest float64.
+    const double d = (double)(q.s + q.n) * 0.5 - (double)q.c;
+    const double e = (double)(q.e + q.w) * 0.5 - (double)q.c;
+    return (float)((d + e) * scale);
+}
+
+__device__ __forceinline__ float hillshade_cell(const Nb &q, float sin_alt, float cos_alt,
+                                                float cos_az, float sin_az) {
+#pragma clang fp contract(off)   // (the fused multiply-adds below are explicit)
+    // hillshade.py:24-31 with the trigonometry folded away: for gx = d/drow, gy = d/dcol,
+    //   sin(pi/2 - atan g) = 1/sqrt(1+g^2),  cos(pi/2 - atan g) = g/sqrt(1+g^2),
+    //   cos(A - atan2(-gx, gy)) = (cosA*gy - sinA*gx)/g
+    // => shaded = (sin_alt + cos_alt*(cosA*gy - sinA*gx)) / sqrt(1 + gx^2 + gy^2).
+    const float gx = (q.s - q.n) * 0.5f;
+    const float gy = (q.e - q.w) * 0.5f;
+    if (__builtin_expect(isinf(gx) || isinf(gy), 0)) {
+        // An infinite gradient (+-inf cell in the DEM): the folded form would give inf * 0.  The reference's
+        // chain (hillshade.py:25-31) then has slope = pi/2 - atan(inf) = 0 exactly in float32, i.e.
+        // sin(slope) = 0 and cos(slope) = 1, and aspect = atan2(-gx, gy) is a multiple of pi/4, so
+        //   shaded = cos_alt * cos(A - aspect) = cos_alt * (cosA * cos(aspect) + sinA * sin(aspect))
+        // with (cos, sin)(aspect) read off the signs -- no trigonometry (and no inlined sinf / cosf argument
+        // reduction in every instantiation of the strip kernels).
+        if (isnan(gx) || isnan(gy)) return nan_f32();
+        const float r = (isinf(gx) && isinf(gy)) ? 0.70710678f : 1.0f;
+        const float ca = isinf(gy) ? copysignf(r, gy) : 0.0f;
+        const float sa = isinf(gx) ? copysignf(r, -gx) : 0.0f;
+        const double shaded = (double)cos_alt * (double)fmaf(cos_az, ca, sin_az * sa);
+        return (float)((shaded + 1.0) * 0.5);
+    }
+    const float num = fmaf(cos_alt, fmaf(cos_az, gy, -sin_az * gx), sin_alt);
+    const float shaded = num * rsqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
+    return (shaded + 1.0f) * 0.5f;
+}
+
+inline void hillshade_constants(double azimuth, double altitude, float &sin_alt, float &cos_alt, float &cos_az,
+                                float &sin_az) {
+    // hillshade.py:23-31: azimuth = 360 - azimuth; A = azimuth*pi/180 - pi/2
+    const double kPi = 3.14159265358979323846;
+    const double az = (360.0 - azimuth) * kPi / 180.0 - kPi / 2.0;
+    const double alt = altitude * kPi / 180.0;
+    sin_alt = (float)sin(alt); cos_alt = (float)cos(alt);
+    cos_az = (float)cos(az);   sin_az = (float)sin(az);
+}
+
+}  // namespace xrs

@@ -5,6 +5,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import fused
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
@@ -23,6 +24,9 @@ def curvature(agg: DataArray, name: Optional[str] = 'curvature') -> DataArray:
     Same signature and results as `xrspatial.curvature`; runs on the MI355X.
     """
     cellsize_x, cellsize_y = get_dataarray_resolution(agg)
+    scope = fused.current()
+    if scope is not None:       # the pass derives (cellsize_x + cellsize_y) / 2 itself
+        return scope.defer('curvature', agg, name, {'cellsize': (float(cellsize_x), float(cellsize_y))})
     cellsize = (cellsize_x + cellsize_y) / 2
     mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
     out = mapper(agg)(agg.data, cellsize)

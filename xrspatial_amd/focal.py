@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+from . import _lib, fused
 from ._launch import finish, get_stream, plane_args
 from ._xr import DataArray
 from .convolution import _kernel_f64, custom_kernel
@@ -128,6 +128,9 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
         raise ValueError("`raster` must be 2D")
     kernel = custom_kernel(kernel)
     stat = _reducer_name(func)
+    scope = fused.current()
+    if scope is not None and stat == 'mean':
+        return scope.defer('focal_mean', raster, name, {'kernel': _kernel_f64(kernel)})
 
     def run(data, kernel, stat):
         return _focal_stats_hip(data, kernel, [stat])[stat]

@@ -5,7 +5,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import _lib
+from . import _lib, fused
 from ._launch import finish, get_stream, plane_args
 from ._xr import DataArray
 from .dataset_support import supports_dataset
@@ -53,6 +53,10 @@ def hillshade(agg: DataArray,
     """
     if shadows:
         raise RuntimeError("Can only calculate shadows if cupy and rtxpy are available")
+    scope = fused.current()
+    if scope is not None:
+        return scope.defer('hillshade', agg, name, {'light': (float(azimuth), float(angle_altitude))},
+                           numpy_dtype=_NUMPY_RESULT_DTYPE)
     if isinstance(agg.data, np.ndarray):
         out = _run_numpy(agg.data, azimuth, angle_altitude)
     elif isinstance(agg.data, DeviceArray):

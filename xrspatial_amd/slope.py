@@ -5,6 +5,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import fused
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
@@ -39,6 +40,9 @@ def slope(agg: DataArray,
         out = run_geodesic(agg.data, lat, lon, is_2d, z_factor, aspect=0)
         return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)
     cellsize_x, cellsize_y = get_dataarray_resolution(agg)
+    scope = fused.current()
+    if scope is not None:
+        return scope.defer('slope', agg, name, {'cellsize': (float(cellsize_x), float(cellsize_y))})
     mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
     out = mapper(agg)(agg.data, cellsize_x, cellsize_y)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

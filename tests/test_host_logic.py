@@ -286,6 +286,46 @@ def test_xarray_stand_in_round_trip():
         ds['c']
 
 
+def test_fuse_scope_records_without_touching_the_device():
+    """Inside `fuse()` the terrain / focal-mean calls only record; nothing runs until the scope closes."""
+    r = raster(np.random.default_rng(1).random((16, 16)).astype(np.float32), res=(2.0, 3.0))
+    k = circle_kernel(1, 1, 2)
+    assert xa.fused.current() is None
+    with pytest.raises(KeyError):                 # an exception inside the scope discards the recorded calls
+        with xa.fuse() as scope:
+            assert xa.fused.current() is scope
+            h = xa.hillshade(r, azimuth=100, angle_altitude=30)
+            m = focal.apply(r, k, name='smooth')
+            s = xa.slope(r)
+            c = xa.curvature(r)
+            a = xa.aspect(r)
+            with xa.fuse() as inner:              # scopes nest; the inner one is the current one
+                assert xa.fused.current() is inner
+            assert xa.fused.current() is scope
+            raise KeyError('stop')
+    assert xa.fused.current() is None and scope.launches == 0
+    for res, name in ((h, 'hillshade'), (m, 'smooth'), (s, 'slope'), (c, 'curvature'), (a, 'aspect')):
+        assert isinstance(res.data, xa.fused.PendingResult) and res.name == name
+        assert res.shape == (16, 16) and res.dims == r.dims and res.attrs == r.attrs
+        with pytest.raises(RuntimeError):
+            res.values
+    # numpy-backed hillshade keeps the reference's result dtype (float64 under NumPy >= 2), everything else float32
+    assert h.dtype == (np.float64 if int(np.__version__.split('.')[0]) >= 2 else np.float32) and m.dtype == np.float32
+    slots = [call[0] for call in scope._calls]
+    assert slots == ['hillshade', 'focal_mean', 'slope', 'curvature', 'aspect']
+    assert scope._calls[0][1] == {'light': (100.0, 30.0)} and scope._calls[2][1] == {'cellsize': (2.0, 3.0)}
+    # argument validation still happens at the call site
+    with xa.fuse():
+        with pytest.raises(ValueError):
+            xa.slope(r, method='geodetic')
+        with pytest.raises(ValueError):
+            focal.apply(r, np.ones((2, 2)))
+    if not utils.has_hip():                       # closing a non-empty scope needs the GPU: loud failure, no fallback
+        with pytest.raises(xa.XrsError):
+            with xa.fuse():
+                xa.hillshade(r)
+
+
 def test_every_device_entry_point_refuses_to_run_without_the_gpu():
     """No silent CPU path: with arguments that pass validation, each public function must raise the
     library's own error on a box without a GPU (on a GPU box this test is a no-op)."""

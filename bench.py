@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--unfused", action="store_true",
                     help="time hillshade and the focal mean as two stand-alone launches instead of the fused pass")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: run the halo exchange and the pass back to back on one stream instead of hiding the "
+                         "exchange behind the interior rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="experiment: do not record per-kernel HIP events inside the timed region")
@@ -161,7 +164,29 @@ def main():
         L("xrs_raster_pass_f32", dem_ptr, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data, kr, kc,
           None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, ht, hb, stream)
 
+    def launch_fused_rows(first, n, top, bot):
+        off = first * cols * 4
+        L("xrs_raster_pass_f32", dem_ptr + off, None, None, None, out_hill.ptr + off, out_focal.ptr + off,
+          kernel.ctypes.data, kr, kc, None, n, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, stream)
+
+    # N > 1 with RCCL: only the 16 rows at either end of a shard wait for the neighbours' rows; the interior
+    # rows of the pass run while the exchange is in flight (xrspatial_amd.distributed.OverlappedHalo)
+    overlap = None
+    if comm is not None and not args.unfused and not args.no_overlap:
+        from xrspatial_amd.distributed import OverlappedHalo
+        overlap = OverlappedHalo(rows, HALO, edge=16, main_stream=stream)
+        halo_via += "; exchange on its own stream, hidden behind the interior rows of the pass"
+
     def step(events=None):
+        if overlap is not None:
+            if events:
+                L("xrs_event_record", events[0], stream)
+            overlap.step(lambda s: L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, s),
+                         launch_fused_rows, ht, hb)
+            if events:
+                L("xrs_event_record", events[1], stream)
+                L("xrs_event_record", events[2], stream)
+            return
         if comm is not None:
             L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, stream)
         elif world > 1:
@@ -321,7 +346,7 @@ def main():
     achieved = alg_bytes * cells_rank / (dom_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):              # HBM bytes/launch from a separate rocprofv3 --pmc run (see profiles/README.md)
+    if os.path.exists(tfile) and (rows, cols) == (ROWS_PER_GPU, COLS):   # (measured on the default raster) HBM bytes/launch from a separate rocprofv3 --pmc run (see profiles/README.md)
         try:
             traffic = json.load(open(tfile)).get(dom_name.split("<")[0])
         except Exception:

@@ -60,6 +60,7 @@ int xrs_device_sync(void);
 int xrs_event_create(void **event);
 int xrs_event_destroy(void *event);
 int xrs_event_record(void *event, void *stream);
+int xrs_stream_wait_event(void *stream, void *event);   /* later work on `stream` waits for `event` (device side) */
 int xrs_event_sync(void *event);
 int xrs_event_elapsed_ms(void *start_event, void *stop_event, float *ms);
 

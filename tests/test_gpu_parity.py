@@ -558,6 +558,55 @@ def test_fuse_scope(backend):
     assert xs.fused.current() is None
 
 
+def test_overlapped_halo_split_equals_monolithic():
+    """distributed.OverlappedHalo: interior rows launched while the (here: stand-in) exchange runs on its own
+    stream, edge rows after it -- three shards of one raster reproduce the monolithic pass, step after step."""
+    from xrspatial_amd import _lib
+    from xrspatial_amd.distributed import OverlappedHalo, shard_rows
+    import ctypes
+    z = synth.smooth_dem((150, 512), nan_frac=0.005)
+    k5 = np.ascontiguousarray(circle_kernel(1, 1, 2))
+    ref = _separate(z, k5, res=(1.0, 1.0))
+    full = xs.DeviceArray.from_numpy(z)
+    H, cols, world = 2, z.shape[1], 3
+    main = ctypes.c_void_p()
+    _lib.call("xrs_stream_create", ctypes.byref(main))
+    for rank in range(world):
+        b, e = shard_rows(z.shape[0], world, rank)
+        rows = e - b
+        ht, hb = (H if rank > 0 else 0), (H if rank < world - 1 else 0)
+        buf = xs.DeviceArray.from_numpy(np.full((rows + 2 * H, cols), np.nan, np.float32))    # halos start as NaN
+        own = buf.ptr + H * cols * 4
+        _lib.call("xrs_memcpy_d2d", own, full.ptr + b * cols * 4, rows * cols * 4, None)
+        _lib.call("xrs_stream_sync", None)
+        outs = {s: xs.DeviceArray((rows, cols), np.float32) for s in ('slope', 'hillshade', 'focal_mean')}
+
+        def exchange(stream):            # what xrs_halo_exchange_f32 delivers, as device copies on the comm stream
+            if ht:
+                _lib.call("xrs_memcpy_d2d", buf.ptr, full.ptr + (b - H) * cols * 4, H * cols * 4, stream)
+            if hb:
+                _lib.call("xrs_memcpy_d2d", own + rows * cols * 4, full.ptr + e * cols * 4, H * cols * 4, stream)
+
+        def launch(first, n, top, bot):
+            off = first * cols * 4
+            _lib.call("xrs_raster_pass_f32", own + off, outs['slope'].ptr + off, None, None, outs['hillshade'].ptr + off,
+                      outs['focal_mean'].ptr + off, k5.ctypes.data, 5, 5, None, n, cols, cols, cols, 1.0, 1.0,
+                      225.0, 25.0, top, bot, main)
+
+        ov = OverlappedHalo(rows, H, edge=16, main_stream=main)
+        plan = ov.plan(ht, hb)
+        assert sum(p[1] for p in plan) == rows and [p[4] for p in plan] == [False, True, True]
+        for _ in range(3):
+            ov.step(exchange, launch, ht, hb)
+        _lib.call("xrs_stream_sync", main)
+        ov.close()
+        for s, arr in outs.items():
+            np.testing.assert_array_equal(arr.get(), ref[s][b:e], err_msg=f"rank {rank} {s}")
+    # a shard shorter than two edges is launched whole, after the exchange
+    assert OverlappedHalo(20, 2, edge=16, main_stream=main).plan(2, 0) == [(0, 20, 2, 0, True)]
+    _lib.call("xrs_stream_destroy", main)
+
+
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
 @pytest.fixture(scope="module")
 def dem16k():

@@ -116,6 +116,10 @@ int xrs_event_create(void **event) {
 }
 int xrs_event_destroy(void *event) { if (event) XRS_HIP(hipEventDestroy((hipEvent_t)event)); return 0; }
 int xrs_event_record(void *event, void *stream) { XRS_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream))); return 0; }
+int xrs_stream_wait_event(void *stream, void *event) {
+    XRS_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+    return 0;
+}
 int xrs_event_sync(void *event) { XRS_HIP(hipEventSynchronize((hipEvent_t)event)); return 0; }
 int xrs_event_elapsed_ms(void *start_event, void *stop_event, float *ms) {
     XRS_HIP(hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event));

@@ -88,6 +88,64 @@ class Comm:
             self.handle = None
 
 
+class OverlappedHalo:
+    """Hide the halo exchange of a row-sharded stencil pass behind the pass itself.
+
+    Only the `edge` rows at the top and bottom of a shard depend on the neighbours' rows, so one step is
+        comm stream:  [wait: previous step's edge launches]  halo exchange  -> event
+        main stream:  interior rows (halo rows = the shard's own rows)  [wait: event]  top edge, bottom edge
+    The interior launch (all but 2*edge rows) runs while the exchange is in flight over xGMI; the two edge
+    launches are a few dozen workgroups each.  The C ABI needs nothing special for this: every stencil entry
+    point takes a pointer to the first owned row, a row count and halo_top / halo_bot, so a sub-range of a
+    shard is just another call.
+
+        ov = OverlappedHalo(rows, halo, edge=16, main_stream=s)
+        ov.step(exchange=lambda stream: comm.halo_exchange(buf, halo, stream),
+                launch=lambda first, n, halo_top, halo_bot: ...xrs_*_f32 on rows [first, first+n)...,
+                halo_top=ht, halo_bot=hb)
+    """
+
+    def __init__(self, rows: int, halo: int, edge: int = 16, main_stream=None):
+        _lib.require_device()
+        if edge < halo:
+            raise ValueError("edge must cover the halo")
+        self.rows, self.halo, self.edge, self.main = int(rows), int(halo), int(edge), main_stream
+        self.comm_stream = ctypes.c_void_p()
+        _lib.call("xrs_stream_create", ctypes.byref(self.comm_stream))
+        self.ev_halo, self.ev_done = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("xrs_event_create", ctypes.byref(self.ev_halo))
+        _lib.call("xrs_event_create", ctypes.byref(self.ev_done))
+        _lib.call("xrs_event_record", self.ev_done, self.main)
+
+    def plan(self, halo_top: int, halo_bot: int):
+        """[(first_row, n_rows, halo_top, halo_bot, needs_exchange)] covering the shard exactly once."""
+        rows, e, h = self.rows, self.edge, self.halo
+        if rows <= 2 * e:                       # shard too short to split: everything waits for the exchange
+            return [(0, rows, halo_top, halo_bot, True)]
+        return [(e, rows - 2 * e, h, h, False),
+                (0, e, halo_top, h, True),
+                (rows - e, e, h, halo_bot, True)]
+
+    def step(self, exchange, launch, halo_top: int, halo_bot: int):
+        # the exchange overwrites halo rows the previous step's edge launches may still be reading
+        _lib.call("xrs_stream_wait_event", self.comm_stream, self.ev_done)
+        exchange(self.comm_stream)
+        _lib.call("xrs_event_record", self.ev_halo, self.comm_stream)
+        waited = False
+        for first, n, ht, hb, needs in self.plan(halo_top, halo_bot):
+            if needs and not waited:
+                _lib.call("xrs_stream_wait_event", self.main, self.ev_halo)
+                waited = True
+            launch(first, n, ht, hb)
+        _lib.call("xrs_event_record", self.ev_done, self.main)
+
+    def close(self):
+        _lib.call("xrs_stream_sync", self.comm_stream)
+        _lib.call("xrs_stream_destroy", self.comm_stream)
+        _lib.call("xrs_event_destroy", self.ev_halo)
+        _lib.call("xrs_event_destroy", self.ev_done)
+
+
 def combine_zonal_partials(parts):
     """Host-side combine of per-rank (count, sum, sumsq, min, max) partials -- the algebra of the
     reference's dask path (zonal.py:92-99): sums add, min/max reduce.  Used by the gloo CPU tests and

@@ -47,11 +47,20 @@ int xrs_device_name(int device, char *buf, size_t buflen);
 int xrs_mem_info(size_t *free_bytes, size_t *total_bytes);
 int xrs_malloc(void **ptr_dev, size_t bytes);
 int xrs_free(void *ptr_dev);
+/* Page-locked host memory: copies to / from it run at PCIe rate and are truly asynchronous on `stream`
+ * (the host layer stages numpy-backed inputs / results through a pool of such blocks). */
+int xrs_host_alloc(void **ptr_host, size_t bytes);
+int xrs_host_free(void *ptr_host);
 int xrs_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int xrs_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int xrs_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int xrs_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
 /* streaming plane copy in the library's own access pattern: the measured-copy-bandwidth calibration point */
+/* `.astype(np.float32)` of the reference's wrappers (xrspatial/slope.py:82, hillshade.py:21, multispectral.py:834 ...)
+ * on the device: numpy-backed rasters are sent in their own dtype and converted in HBM (round to nearest even). */
+enum { XRS_DT_I8 = 0, XRS_DT_U8 = 1, XRS_DT_I16 = 2, XRS_DT_U16 = 3, XRS_DT_I32 = 4, XRS_DT_U32 = 5,
+       XRS_DT_I64 = 6, XRS_DT_U64 = 7, XRS_DT_F64 = 8 };
+int xrs_cast_f32(const void *src_dev, int src_dtype, float *dst_dev, int64_t n, void *stream);
 int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream);
 int xrs_stream_create(void **stream);
 int xrs_stream_destroy(void *stream);

@@ -607,6 +607,69 @@ def test_overlapped_halo_split_equals_monolithic():
     _lib.call("xrs_stream_destroy", main)
 
 
+def test_device_side_cast_matches_numpy_astype():
+    """Non-float32 rasters travel in their own dtype and are converted in HBM: xrs_cast_f32 == ndarray.astype('f4')
+    bit for bit (round to nearest even), for every integer width, float64 specials, odd lengths."""
+    from xrspatial_amd.device import to_device_f32
+    rng = np.random.default_rng(21)
+    cases = {
+        np.int8: rng.integers(-128, 128, 1003), np.uint8: rng.integers(0, 256, 1003),
+        np.int16: rng.integers(-32768, 32768, 4097), np.uint16: rng.integers(0, 65536, 4097),
+        np.int32: rng.integers(-2**31, 2**31, 10001), np.uint32: rng.integers(0, 2**32, 10001),
+        np.int64: np.concatenate([rng.integers(-2**63, 2**63 - 1, 5000), [2**24 + 1, 2**53 + 1, -2**63, 2**63 - 1,
+                                                                          16777217, 33554434, 33554438]]),
+        np.uint64: np.concatenate([rng.integers(0, 2**64 - 1, 5000, dtype=np.uint64),
+                                   np.array([2**64 - 1, 2**63 + 2**39, 16777219], dtype=np.uint64)]),
+        np.float64: np.concatenate([rng.normal(0, 1e3, 5000), [np.nan, np.inf, -np.inf, 1e-50, -1e-50, 1e300, 3.4e38,
+                                                              1.0000000596046448, 1.00000017881393433, -0.0]]),
+    }
+    for dt, vals in cases.items():
+        host = np.asarray(vals).astype(dt)
+        with np.errstate(over='ignore'):
+            want = host.astype(np.float32)
+        got = to_device_f32(host).get()
+        np.testing.assert_array_equal(got, want, err_msg=str(dt))
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+        dev = xs.DeviceArray.from_numpy(host)                     # device-resident arrays convert the same way
+        np.testing.assert_array_equal(dev.astype(np.float32).get(), want)
+    # through the public API: an int16 DEM and a float64 DEM give what their float32 copies give
+    z = (synth.smooth_dem((64, 260)) * 4).astype(np.int16)
+    np.testing.assert_array_equal(xs.slope(raster(z)).data, xs.slope(raster(z.astype(np.float32))).data)
+    z64 = synth.smooth_dem((64, 260)).astype(np.float64) + 1e-9
+    np.testing.assert_array_equal(xs.hillshade(raster(z64)).data, xs.hillshade(raster(z64.astype(np.float32))).data)
+    np.testing.assert_allclose(xs.slope(raster(z)).data, orc.slope(z, 0.5, 0.5), rtol=RTOL, equal_nan=True)
+
+
+def test_results_in_recycled_host_blocks_stay_valid():
+    """numpy-backed results live in recycled host blocks: a result the caller still holds is never overwritten
+    by a later call, and dropping it lets the next call reuse the pages."""
+    import gc
+    from xrspatial_amd import device
+    za, zb = synth.smooth_dem((600, 1024)), synth.smooth_dem((600, 1024), seed=99)
+    ra = xs.slope(raster(za))
+    keep = ra.data.copy()
+    inner = ra.data[1:-1, 1:-1]                 # a view the caller sliced off
+    rb = xs.slope(raster(zb))
+    rc = xs.curvature(raster(zb))
+    np.testing.assert_array_equal(ra.data, keep)
+    assert not np.array_equal(rb.data, keep, equal_nan=True)
+    addr = ra.data.__array_interface__['data'][0]
+    del ra
+    gc.collect()
+    rd = xs.slope(raster(zb))                   # `inner` still references the first block: must not be reused
+    assert rd.data.__array_interface__['data'][0] != addr
+    np.testing.assert_array_equal(inner, keep[1:-1, 1:-1])
+    del inner
+    gc.collect()
+    re_ = xs.slope(raster(za))                  # now it may be
+    assert re_.data.__array_interface__['data'][0] == addr
+    np.testing.assert_array_equal(re_.data, keep)
+    np.testing.assert_array_equal(rb.data, rd.data)
+    del rb, rc, rd, re_
+    gc.collect()
+    device.empty_cache()
+
+
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
 @pytest.fixture(scope="module")
 def dem16k():

@@ -286,6 +286,35 @@ def test_xarray_stand_in_round_trip():
         ds['c']
 
 
+def test_recycled_host_blocks():
+    """Result arrays come from recycled host blocks: a block returns to the free list only when the last NumPy
+    view of it is gone, and the next result of that size reuses it (no fresh page faults)."""
+    import gc
+    from xrspatial_amd import device
+    device.empty_cache()
+    a = device.host_empty((1024, 512), np.float32)
+    assert a.shape == (1024, 512) and a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable
+    a[:] = 7
+    addr = a.__array_interface__['data'][0]
+    view = a[100:200, ::2]
+    b = device.host_empty((1024, 512), np.float32)            # `a` still alive: a different block
+    assert b.__array_interface__['data'][0] != addr
+    del a
+    gc.collect()
+    assert device._host_pool_bytes == 0 and (view == 7).all()  # the view keeps the block out of the pool
+    del view
+    gc.collect()
+    assert device._host_pool_bytes == 1024 * 512 * 4
+    c = device.host_empty((512, 512), np.float64)             # same byte size, other dtype / shape: reused
+    assert c.__array_interface__['data'][0] == addr and device._host_pool_bytes == 0
+    small = device.host_empty((10, 10), np.float64)           # small results are plain arrays
+    assert small.flags.owndata
+    del b, c
+    gc.collect()
+    device.empty_cache()
+    assert device._host_pool_bytes == 0 and not device._host_pool
+
+
 def test_fuse_scope_records_without_touching_the_device():
     """Inside `fuse()` the terrain / focal-mean calls only record; nothing runs until the scope closes."""
     r = raster(np.random.default_rng(1).random((16, 16)).astype(np.float32), res=(2.0, 3.0))

@@ -50,6 +50,9 @@ _PROTOTYPES = {
     "xrs_event_destroy": [c_void_p],
     "xrs_event_record": [c_void_p, c_void_p],
     "xrs_stream_wait_event": [c_void_p, c_void_p],
+    "xrs_cast_f32": [c_void_p, c_int, c_void_p, c_int64, c_void_p],
+    "xrs_host_alloc": [ctypes.POINTER(c_void_p), c_size_t],
+    "xrs_host_free": [c_void_p],
     "xrs_event_sync": [c_void_p],
     "xrs_event_elapsed_ms": [c_void_p, c_void_p, ctypes.POINTER(c_float)],
     "xrs_slope_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_double,

@@ -21,9 +21,54 @@ __global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, floa
         if (base + 64 * u < n4) dst[base + 64 * u] = v[u];
 }
 
+// `.astype(np.float32)` of the reference's wrappers (e.g. xrspatial/slope.py:82, multispectral.py:834) done in
+// HBM: the host sends the raster in its own dtype (int16 DEMs: half the PCIe bytes of float32) and this kernel
+// converts -- round-to-nearest-even, like NumPy.  Four elements per thread, grid-stride.
+template <typename T>
+__global__ void __launch_bounds__(256) cast_f32_kernel(const T *__restrict__ src, float *__restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = make_float4((float)src[i], (float)src[i + 1], (float)src[i + 2], (float)src[i + 3]);
+            *reinterpret_cast<float4 *>(dst + i) = v;
+        } else {
+            for (long j = i; j < n; ++j) dst[j] = (float)src[j];
+        }
+    }
+}
+
+template <typename T>
+int launch_cast(const void *src, float *dst, long n, hipStream_t s) {
+    const long blocks = (n + 1023) / 1024;
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    hipLaunchKernelGGL(cast_f32_kernel<T>, dim3(grid), dim3(256), 0, s, static_cast<const T *>(src), dst, n);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int xrs_cast_f32(const void *src_dev, int src_dtype, float *dst_dev, int64_t n, void *stream) {
+    if (n < 0) return fail("xrs_cast_f32: negative size");
+    if (n == 0) return 0;
+    if (!src_dev || !dst_dev) return fail("xrs_cast_f32: null pointer");
+    if (!aligned16(dst_dev)) return fail("xrs_cast_f32: destination must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    switch (src_dtype) {
+        case XRS_DT_I8: return launch_cast<int8_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_U8: return launch_cast<uint8_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_I16: return launch_cast<int16_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_U16: return launch_cast<uint16_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_I32: return launch_cast<int32_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_U32: return launch_cast<uint32_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_I64: return launch_cast<int64_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_U64: return launch_cast<uint64_t>(src_dev, dst_dev, n, s);
+        case XRS_DT_F64: return launch_cast<double>(src_dev, dst_dev, n, s);
+        default: return fail("xrs_cast_f32: unknown source dtype code %d", src_dtype);
+    }
+}
 
 int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream) {
     if (n < 0) return fail("xrs_copy_f32: negative size");
@@ -116,6 +161,15 @@ int xrs_event_create(void **event) {
 }
 int xrs_event_destroy(void *event) { if (event) XRS_HIP(hipEventDestroy((hipEvent_t)event)); return 0; }
 int xrs_event_record(void *event, void *stream) { XRS_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream))); return 0; }
+int xrs_host_alloc(void **ptr_host, size_t bytes) {
+    if (!ptr_host) return fail("xrs_host_alloc: null out pointer");
+    XRS_HIP(hipHostMalloc(ptr_host, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+int xrs_host_free(void *ptr_host) {
+    if (ptr_host) XRS_HIP(hipHostFree(ptr_host));
+    return 0;
+}
 int xrs_stream_wait_event(void *stream, void *event) {
     XRS_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
     return 0;

@@ -7,10 +7,18 @@ a numpy-backed DataArray is copied in and out around each call.
 
 Freed buffers go to a small size-keyed free list so steady-state pipelines
 (bench.py, repeated calls) do not pay hipMalloc/hipFree per call.
+
+Host side of the numpy-in / numpy-out path (measured on the MI355X box, tools/hostcopy_probe.py): copies run
+at PCIe rate (~56 GB/s) in both directions EXCEPT into a freshly allocated result array, where the first touch
+of every page (kernel zero-fill, ~12 GB/s) dominates the whole call.  Results therefore land in recycled host
+blocks (`host_empty`): the block goes back to a free list when the last NumPy view of it is garbage-collected
+and the next result of that size reuses the already-faulted pages.  Inputs that are not float32 are sent in
+their own dtype and converted in HBM (`xrs_cast_f32`) instead of `.astype(np.float32)` on one CPU core.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -53,14 +61,80 @@ def _raw_free(ptr: int, nbytes: int):
 
 
 def empty_cache():
-    """Return every cached buffer to the driver."""
-    global _pool_bytes
+    """Return every cached device buffer to the driver and drop the recycled host blocks."""
+    global _pool_bytes, _host_pool_bytes
+    with _host_lock:
+        _host_pool.clear()
+        _host_pool_bytes = 0
     with _pool_lock:
         for lst in _pool.values():
             for p in lst:
                 _lib.load().xrs_free(p)
         _pool.clear()
         _pool_bytes = 0
+
+
+# ------------------------------------------------------------------ recycled host blocks for results
+_host_pool = {}
+_host_lock = threading.Lock()
+_host_pool_bytes = 0
+_HOST_POOL_MAX_BYTES = int(os.environ.get("XRS_HOST_POOL_MAX_BYTES", 16 << 30))
+_HOST_POOL_MIN_BLOCK = 1 << 20          # smaller results: plain np.empty
+
+
+class _HostBlock:
+    """Owner of one recycled block.  NumPy arrays created from it keep it alive through `.base`; when the last
+    of them (including any view the caller sliced off) is collected, the memory returns to the free list."""
+
+    __slots__ = ("raw", "__weakref__")
+
+    def __init__(self, raw):
+        self.raw = raw                     # uint8 ndarray that owns the (already touched) pages
+
+    @property
+    def __array_interface__(self):
+        return self.raw.__array_interface__
+
+    def __del__(self):
+        global _host_pool_bytes
+        try:
+            raw = self.raw
+            with _host_lock:
+                if _host_pool_bytes + raw.nbytes <= _HOST_POOL_MAX_BYTES:
+                    _host_pool.setdefault(raw.nbytes, []).append(raw)
+                    _host_pool_bytes += raw.nbytes
+        except Exception:                  # interpreter shutdown
+            pass
+
+
+def host_empty(shape, dtype) -> np.ndarray:
+    """Like np.empty, but large arrays come from the recycled-block pool (contents undefined)."""
+    global _host_pool_bytes
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < _HOST_POOL_MIN_BLOCK:
+        return np.empty(shape, dtype)
+    raw = None
+    with _host_lock:
+        lst = _host_pool.get(nbytes)
+        if lst:
+            raw = lst.pop()
+            _host_pool_bytes -= nbytes
+    if raw is None:
+        raw = np.empty(nbytes, np.uint8)
+    return np.asarray(_HostBlock(raw)).view(dtype).reshape(shape)
+
+
+_CAST_CODE = {np.dtype(t): c for c, t in enumerate(
+    (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.float64))}
+
+
+def _cast_f32_on_device(src: "DeviceArray", stream=None) -> "DeviceArray":
+    out = DeviceArray(src.shape, np.float32)
+    _lib.call("xrs_cast_f32", src.ptr, _CAST_CODE[src.dtype], out.ptr, src.size, stream)
+    _lib.call("xrs_stream_sync", stream)          # `src` may be a temporary that goes back to the pool
+    return out
 
 
 class DeviceArray:
@@ -108,7 +182,7 @@ class DeviceArray:
 
     def get(self, stream=None) -> np.ndarray:
         """Copy to a new NumPy array (cupy's spelling)."""
-        out = np.empty(self.shape, dtype=self.dtype)
+        out = host_empty(self.shape, self.dtype)
         if out.nbytes:
             _lib.call("xrs_memcpy_d2h", out.ctypes.data, self.ptr, out.nbytes, stream)
             _lib.call("xrs_stream_sync", stream)
@@ -127,6 +201,8 @@ class DeviceArray:
     def astype(self, dtype):
         if np.dtype(dtype) == self.dtype:
             return self
+        if np.dtype(dtype) == np.float32 and self.dtype in _CAST_CODE:
+            return _cast_f32_on_device(self)
         return DeviceArray.from_numpy(self.get().astype(dtype))
 
     def __repr__(self):
@@ -156,7 +232,10 @@ def to_device_f32(data) -> DeviceArray:
     """`data.astype(np.float32)` of the reference runners, landing in HBM."""
     if isinstance(data, DeviceArray):
         return data.astype(np.float32)
-    return DeviceArray.from_numpy(np.asarray(data), dtype=np.float32)
+    host = np.asarray(data)
+    if host.dtype != np.float32 and host.dtype in _CAST_CODE and host.size:
+        return _cast_f32_on_device(DeviceArray.from_numpy(host))      # native dtype over PCIe, converted in HBM
+    return DeviceArray.from_numpy(host, dtype=np.float32)
 
 
 def synchronize():

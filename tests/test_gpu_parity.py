@@ -670,6 +670,33 @@ def test_results_in_recycled_host_blocks_stay_valid():
     device.empty_cache()
 
 
+def test_banded_host_pipeline_equals_single_call(monkeypatch):
+    """Large numpy-backed rasters are uploaded / computed / downloaded in overlapping row bands: same results as
+    the one-shot device path, for every terrain operator, float32 / int16 / float64 inputs, ragged last band."""
+    from xrspatial_amd import _launch
+    monkeypatch.setattr(_launch, "_PIPE_MIN_BYTES", 1 << 20)
+    monkeypatch.setattr(_launch, "_PIPE_BAND_BYTES", 1 << 20)           # 256-row bands at 1024 columns
+    calls = []
+    real = _launch._stencil_pipelined
+    monkeypatch.setattr(_launch, "_stencil_pipelined", lambda *a, **k: calls.append(a[0]) or real(*a, **k))
+    for rows in (1500, 1024, 1090):
+        z = synth.smooth_dem((rows, 1024), nan_frac=0.002)
+        for host in (z, (np.nan_to_num(z) * 3).astype(np.int16), z.astype(np.float64)):
+            hagg, dagg = raster(host, res=(5.0, 7.0)), raster(host.astype(np.float32), res=(5.0, 7.0), backend='hip')
+            for fn in (xs.slope, xs.aspect, xs.curvature, xs.hillshade):
+                n0 = len(calls)
+                got = fn(hagg)
+                assert len(calls) == n0 + 1, fn.__name__            # took the banded path
+                want = fn(dagg).data.get()
+                assert isinstance(got.data, np.ndarray)
+                np.testing.assert_array_equal(got.data, want.astype(got.data.dtype), err_msg=f"{fn.__name__} {host.dtype} {rows}")
+    # small rasters / odd widths keep the one-shot path
+    n0 = len(calls)
+    xs.slope(raster(synth.smooth_dem((100, 1024))))
+    xs.slope(raster(synth.smooth_dem((1500, 1022))))
+    assert len(calls) == n0
+
+
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
 @pytest.fixture(scope="module")
 def dem16k():

@@ -7,8 +7,14 @@ back either a NumPy array (numpy-backed input: strict drop-in) or the DeviceArra
 """
 from __future__ import annotations
 
+import ctypes
+import os
+import threading
+
+import numpy as np
+
 from . import _lib
-from .device import DeviceArray, to_device_f32
+from .device import _CAST_CODE, DeviceArray, host_empty, is_pinned, to_device_f32
 
 # The stream every host-level call uses (None = HIP null stream).  bench.py swaps in its own.
 _stream = None
@@ -36,14 +42,106 @@ def finish(out: DeviceArray, like_numpy: bool):
     return out
 
 
-def stencil(fn_name, data, out_dtype, extra, halo=(0, 0)):
-    """Run a (in, out, rows, cols, ld_in, ld_out, *extra, halo_top, halo_bot, stream) entry point."""
+# ------------------------------------------------------------------ banded host pipeline
+# A numpy-backed call moves 4 B/cell up and 4-8 B/cell down over PCIe and spends microseconds in the kernel, so
+# what there is to win is running the two directions at the same time (PCIe is full duplex).  The raster is cut
+# into row bands: band i+1 uploads while band i computes and band i-1 downloads into a page-locked result
+# block (so that the download is asynchronous).  Every stencil entry point takes a pointer to the first row it
+# owns, a row count and halo_top / halo_bot, so a band is just another call on a sub-range of the same plane.
+_PIPE_MIN_BYTES = int(os.environ.get("XRS_PIPELINE_MIN_BYTES", 32 << 20))
+_PIPE_BAND_BYTES = 32 << 20
+
+
+class _Pipe(threading.local):
+    """Three streams (upload / compute / download) and a growing list of events, per host thread."""
+
+    def __init__(self):
+        self.streams = None
+        self.events = []
+
+    def get(self, n_events):
+        if self.streams is None:
+            self.streams = [ctypes.c_void_p() for _ in range(3)]
+            for s in self.streams:
+                _lib.call("xrs_stream_create", ctypes.byref(s))
+        while len(self.events) < n_events:
+            e = ctypes.c_void_p()
+            _lib.call("xrs_event_create", ctypes.byref(e))
+            self.events.append(e)
+        return self.streams, self.events
+
+
+_pipe = _Pipe()
+
+
+def _stencil_pipelined(fn_name, host, out_dtype, pre, extra, halo_rows):
+    rows, cols = host.shape
+    out_dtype = np.dtype(out_dtype)
+    band = max(256, (_PIPE_BAND_BYTES // (cols * 4) + 15) // 16 * 16)
+    cuts = list(range(0, rows, band)) + [rows]
+    if cuts[-1] - cuts[-2] < 64 and len(cuts) > 2:          # no sliver at the end
+        del cuts[-2]
+    nb = len(cuts) - 1
+    (s_up, s_run, s_down), ev = _pipe.get(2 * nb)
+    dev_in = DeviceArray((rows, cols), np.float32)
+    dev_out = DeviceArray((rows, cols), out_dtype)
+    native = host.dtype == np.float32
+    raw = None if native else DeviceArray((max(b - a for a, b in zip(cuts, cuts[1:])), cols), host.dtype)
+    out_host = host_empty((rows, cols), out_dtype, pinned=True)
+    async_down = is_pinned(out_host)
+    isz, osz = host.dtype.itemsize, out_dtype.itemsize
+
+    def run(j):
+        a, b = cuts[j], cuts[j + 1]
+        _lib.call("xrs_stream_wait_event", s_run, ev[min(j + 1, nb - 1)])       # rows below the band are up
+        _lib.call(fn_name, dev_in.ptr + a * cols * 4, dev_out.ptr + a * cols * osz, *pre, b - a, cols, cols, cols,
+                  *extra, halo_rows if j > 0 else 0, halo_rows if j < nb - 1 else 0, s_run)
+        _lib.call("xrs_event_record", ev[nb + j], s_run)
+        _lib.call("xrs_stream_wait_event", s_down, ev[nb + j])
+        _lib.call("xrs_memcpy_d2h", out_host.ctypes.data + a * cols * osz, dev_out.ptr + a * cols * osz,
+                  (b - a) * cols * osz, s_down)
+        if not async_down:
+            _lib.call("xrs_stream_sync", s_down)
+
+    for i in range(nb):
+        a, b = cuts[i], cuts[i + 1]
+        if native:
+            _lib.call("xrs_memcpy_h2d", dev_in.ptr + a * cols * 4, host.ctypes.data + a * cols * 4,
+                      (b - a) * cols * 4, s_up)
+        else:
+            _lib.call("xrs_memcpy_h2d", raw.ptr, host.ctypes.data + a * cols * isz, (b - a) * cols * isz, s_up)
+            _lib.call("xrs_cast_f32", raw.ptr, _CAST_CODE[host.dtype], dev_in.ptr + a * cols * 4, (b - a) * cols, s_up)
+        _lib.call("xrs_event_record", ev[i], s_up)
+        if i >= 1:
+            run(i - 1)
+    run(nb - 1)
+    for s in (s_up, s_run, s_down):
+        _lib.call("xrs_stream_sync", s)
+    return out_host
+
+
+def _pipeline_ok(data, cols_bytes_multiple=16):
+    if not isinstance(data, np.ndarray) or data.ndim != 2 or not data.flags.c_contiguous:
+        return False
+    if data.dtype != np.float32 and data.dtype not in _CAST_CODE:
+        return False
+    # (sub-range launches keep the 16-byte fast path only if every band starts on a 16-byte boundary)
+    return data.size * 4 >= _PIPE_MIN_BYTES and (data.shape[1] * 4) % cols_bytes_multiple == 0 and data.shape[0] >= 512
+
+
+def stencil(fn_name, data, out_dtype, extra, halo=(0, 0), pre=(), window_rows=1):
+    """Run a (in, out, *pre, rows, cols, ld_in, ld_out, *extra, halo_top, halo_bot, stream) entry point.
+
+    Large numpy-backed rasters go through the banded upload / compute / download pipeline (`window_rows` = the
+    rows of context a band needs from its neighbours); everything else is one upload, one call, one download."""
     _lib.require_device()
     like_numpy = not isinstance(data, DeviceArray)
     if len(data.shape) != 2:
         raise ValueError("expected a 2D raster")
+    if like_numpy and halo == (0, 0) and _pipeline_ok(np.asarray(data)):
+        return _stencil_pipelined(fn_name, np.asarray(data), out_dtype, pre, extra, window_rows)
     src = to_device_f32(data)
     rows, cols, ld = plane_args(src)
     out = DeviceArray((rows, cols), out_dtype)
-    _lib.call(fn_name, src.ptr, out.ptr, rows, cols, ld, ld, *extra, halo[0], halo[1], _stream)
+    _lib.call(fn_name, src.ptr, out.ptr, *pre, rows, cols, ld, ld, *extra, halo[0], halo[1], _stream)
     return finish(out, like_numpy)

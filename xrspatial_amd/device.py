@@ -62,10 +62,15 @@ def _raw_free(ptr: int, nbytes: int):
 
 def empty_cache():
     """Return every cached device buffer to the driver and drop the recycled host blocks."""
-    global _pool_bytes, _host_pool_bytes
+    global _pool_bytes, _host_pool_bytes, _pinned_pool_bytes
     with _host_lock:
         _host_pool.clear()
         _host_pool_bytes = 0
+        for lst in _pinned_pool.values():
+            for ptr in lst:
+                _lib.load().xrs_host_free(ptr)
+        _pinned_pool.clear()
+        _pinned_pool_bytes = 0
     with _pool_lock:
         for lst in _pool.values():
             for p in lst:
@@ -82,39 +87,74 @@ _HOST_POOL_MAX_BYTES = int(os.environ.get("XRS_HOST_POOL_MAX_BYTES", 16 << 30))
 _HOST_POOL_MIN_BLOCK = 1 << 20          # smaller results: plain np.empty
 
 
+_pinned_pool = {}                        # nbytes -> [host pointers from xrs_host_alloc]
+_pinned_pool_bytes = 0
+_PINNED_POOL_MAX_BYTES = int(os.environ.get("XRS_PINNED_POOL_MAX_BYTES", 8 << 30))
+
+
 class _HostBlock:
     """Owner of one recycled block.  NumPy arrays created from it keep it alive through `.base`; when the last
-    of them (including any view the caller sliced off) is collected, the memory returns to the free list."""
+    of them (including any view the caller sliced off) is collected, the memory returns to the free list.
+    Two kinds: pageable (`raw`, a uint8 ndarray that owns already-touched pages) and page-locked (`ptr` from
+    xrs_host_alloc: device-to-host copies into it are asynchronous, which the banded pipeline of
+    `_launch.stencil` needs to overlap them with the uploads)."""
 
-    __slots__ = ("raw", "__weakref__")
+    __slots__ = ("raw", "ptr", "nbytes", "__weakref__")
 
-    def __init__(self, raw):
-        self.raw = raw                     # uint8 ndarray that owns the (already touched) pages
+    def __init__(self, raw=None, ptr=0, nbytes=0):
+        self.raw, self.ptr, self.nbytes = raw, ptr, nbytes
 
     @property
     def __array_interface__(self):
-        return self.raw.__array_interface__
+        if self.raw is not None:
+            return self.raw.__array_interface__
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
 
     def __del__(self):
-        global _host_pool_bytes
+        global _host_pool_bytes, _pinned_pool_bytes
         try:
-            raw = self.raw
+            if self.raw is not None:
+                raw = self.raw
+                with _host_lock:
+                    if _host_pool_bytes + raw.nbytes <= _HOST_POOL_MAX_BYTES:
+                        _host_pool.setdefault(raw.nbytes, []).append(raw)
+                        _host_pool_bytes += raw.nbytes
+                return
             with _host_lock:
-                if _host_pool_bytes + raw.nbytes <= _HOST_POOL_MAX_BYTES:
-                    _host_pool.setdefault(raw.nbytes, []).append(raw)
-                    _host_pool_bytes += raw.nbytes
+                if _pinned_pool_bytes + self.nbytes <= _PINNED_POOL_MAX_BYTES:
+                    _pinned_pool.setdefault(self.nbytes, []).append(self.ptr)
+                    _pinned_pool_bytes += self.nbytes
+                    return
+            _lib.load().xrs_host_free(self.ptr)
         except Exception:                  # interpreter shutdown
             pass
 
 
-def host_empty(shape, dtype) -> np.ndarray:
-    """Like np.empty, but large arrays come from the recycled-block pool (contents undefined)."""
-    global _host_pool_bytes
+def host_empty(shape, dtype, pinned: bool = False) -> np.ndarray:
+    """Like np.empty, but large arrays come from the recycled-block pools (contents undefined).
+    `pinned`: page-locked memory (falls back to pageable if the driver refuses the allocation)."""
+    global _host_pool_bytes, _pinned_pool_bytes
     dtype = np.dtype(dtype)
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if nbytes < _HOST_POOL_MIN_BLOCK:
         return np.empty(shape, dtype)
+    if pinned:
+        ptr = 0
+        with _host_lock:
+            lst = _pinned_pool.get(nbytes)
+            if lst:
+                ptr = lst.pop()
+                _pinned_pool_bytes -= nbytes
+        if not ptr:
+            p = ctypes.c_void_p()
+            try:
+                _lib.call("xrs_host_alloc", ctypes.byref(p), nbytes)
+                ptr = p.value
+            except _lib.XrsError:
+                ptr = 0
+        if ptr:
+            return np.asarray(_HostBlock(ptr=ptr, nbytes=nbytes)).view(dtype).reshape(shape)
     raw = None
     with _host_lock:
         lst = _host_pool.get(nbytes)
@@ -123,7 +163,15 @@ def host_empty(shape, dtype) -> np.ndarray:
             _host_pool_bytes -= nbytes
     if raw is None:
         raw = np.empty(nbytes, np.uint8)
-    return np.asarray(_HostBlock(raw)).view(dtype).reshape(shape)
+    return np.asarray(_HostBlock(raw=raw)).view(dtype).reshape(shape)
+
+
+def is_pinned(arr: np.ndarray) -> bool:
+    """True if `arr` lives in a page-locked block handed out by host_empty(..., pinned=True)."""
+    base = arr
+    while isinstance(base, np.ndarray) and base.base is not None:
+        base = base.base
+    return isinstance(base, _HostBlock) and base.raw is None
 
 
 _CAST_CODE = {np.dtype(t): c for c, t in enumerate(

@@ -5,11 +5,11 @@ from typing import Optional
 
 import numpy as np
 
-from . import _lib, fused
-from ._launch import finish, get_stream, plane_args
+from . import fused
+from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
-from .device import DeviceArray, to_device_f32
+from .device import DeviceArray
 
 # The reference's NumPy runner returns float64 under NumPy >= 2 (its final combine is
 # promoted by a np.float64 scalar) and float32 under NumPy 1.x; its CuPy
@@ -27,16 +27,8 @@ def _run_hip(data, azimuth, angle_altitude):
 
 def _hill(data, out_dtype, azimuth, angle_altitude):
     # replaces _run_numpy (hillshade.py:20-35); the entry point has an `out_f64` flag after `out`
-    _lib.require_device()
-    like_numpy = not isinstance(data, DeviceArray)
-    if len(data.shape) != 2:
-        raise ValueError("expected a 2D raster")
-    src = to_device_f32(data)
-    rows, cols, ld = plane_args(src)
-    out = DeviceArray((rows, cols), out_dtype)
-    _lib.call("xrs_hillshade_f32", src.ptr, out.ptr, int(np.dtype(out_dtype) == np.float64), rows, cols,
-              ld, ld, float(azimuth), float(angle_altitude), 0, 0, get_stream())
-    return finish(out, like_numpy)
+    return stencil("xrs_hillshade_f32", data, out_dtype, (float(azimuth), float(angle_altitude)),
+                   pre=(int(np.dtype(out_dtype) == np.float64),))
 
 
 @supports_dataset

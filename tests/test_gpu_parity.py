@@ -695,6 +695,20 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
     xs.slope(raster(synth.smooth_dem((100, 1024))))
     xs.slope(raster(synth.smooth_dem((1500, 1022))))
     assert len(calls) == n0
+    # per-cell indices: same pipeline over flat chunks (ragged tail, mixed input dtypes)
+    pc = []
+    real_pc = _launch.percell_pipelined
+    from xrspatial_amd import multispectral as ms
+    monkeypatch.setattr(ms, "percell_pipelined", lambda *a, **k: pc.append(a[0]) or real_pc(*a, **k))
+    shape = (1201, 1003)
+    nir, red, blue = (synth.bands(shape, s) for s in (1, 2, 3))
+    red16 = (red * 100).astype(np.uint16)
+    for fn, args in ((xs.ndvi, (nir, red)), (xs.evi, (nir, red, blue)), (xs.savi, (nir, red)), (xs.arvi, (nir, red, blue)),
+                     (xs.ndvi, (nir, red16)), (xs.sipi, (nir.astype(np.float64), red, blue))):
+        got = fn(*[raster(a) for a in args]).data
+        want = fn(*[raster(np.asarray(a, dtype=np.float32), backend='hip') for a in args]).data.get()
+        np.testing.assert_array_equal(got, want, err_msg=fn.__name__)
+    assert len(pc) == 6
 
 
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)

@@ -120,6 +120,50 @@ def _stencil_pipelined(fn_name, host, out_dtype, pre, extra, halo_rows):
     return out_host
 
 
+def percell_pipelined(fn_name, hosts, extra):
+    """Banded pipeline for the per-cell entry points (`fn(in_0, .., in_k, out, n, *extra, stream)`, flat float32
+    planes): chunk i+1 of every band uploads while chunk i computes and chunk i-1 downloads.  Returns the
+    float32 result as a NumPy array of the inputs' shape, or None if the inputs do not qualify."""
+    shape = hosts[0].shape
+    n = hosts[0].size
+    for h in hosts:
+        if not isinstance(h, np.ndarray) or h.shape != shape or not h.flags.c_contiguous:
+            return None
+        if h.dtype != np.float32 and h.dtype not in _CAST_CODE:
+            return None
+    if n * 4 < _PIPE_MIN_BYTES:
+        return None
+    chunk = max(1 << 16, (_PIPE_BAND_BYTES // 4) >> 12 << 12)       # elements; multiple of 4096 keeps 16 KiB chunks whole
+    cuts = list(range(0, n, chunk)) + [n]
+    nb = len(cuts) - 1
+    (s_up, s_run, s_down), ev = _pipe.get(2 * nb)
+    dev_in = [DeviceArray((n,), np.float32) for _ in hosts]
+    raws = [None if h.dtype == np.float32 else DeviceArray((min(chunk, n),), h.dtype) for h in hosts]
+    dev_out = DeviceArray((n,), np.float32)
+    out_host = host_empty(shape, np.float32, pinned=True)
+    async_down = is_pinned(out_host)
+    for i in range(nb):
+        a, b = cuts[i], cuts[i + 1]
+        for h, d, raw in zip(hosts, dev_in, raws):
+            if raw is None:
+                _lib.call("xrs_memcpy_h2d", d.ptr + a * 4, h.ctypes.data + a * 4, (b - a) * 4, s_up)
+            else:
+                isz = h.dtype.itemsize
+                _lib.call("xrs_memcpy_h2d", raw.ptr, h.ctypes.data + a * isz, (b - a) * isz, s_up)
+                _lib.call("xrs_cast_f32", raw.ptr, _CAST_CODE[h.dtype], d.ptr + a * 4, b - a, s_up)
+        _lib.call("xrs_event_record", ev[i], s_up)
+        _lib.call("xrs_stream_wait_event", s_run, ev[i])
+        _lib.call(fn_name, *[d.ptr + a * 4 for d in dev_in], dev_out.ptr + a * 4, b - a, *extra, s_run)
+        _lib.call("xrs_event_record", ev[nb + i], s_run)
+        _lib.call("xrs_stream_wait_event", s_down, ev[nb + i])
+        _lib.call("xrs_memcpy_d2h", out_host.ctypes.data + a * 4, dev_out.ptr + a * 4, (b - a) * 4, s_down)
+        if not async_down:
+            _lib.call("xrs_stream_sync", s_down)
+    for s in (s_up, s_run, s_down):
+        _lib.call("xrs_stream_sync", s)
+    return out_host
+
+
 def _pipeline_ok(data, cols_bytes_multiple=16):
     if not isinstance(data, np.ndarray) or data.ndim != 2 or not data.flags.c_contiguous:
         return False

@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from ._launch import finish, get_stream
+from ._launch import finish, get_stream, percell_pipelined
 from ._xr import DataArray
 from .dataset_support import supports_dataset_bands
 from .device import DeviceArray, to_device_f32
@@ -18,6 +18,10 @@ def _percell(fn_name, bands, extra):
     """bands: tuple of same-shape arrays -> float32 result of the same shape."""
     _lib.require_device()
     like_numpy = not isinstance(bands[0], DeviceArray)
+    if like_numpy:                                    # large numpy rasters: overlapped upload / compute / download
+        out = percell_pipelined(fn_name, [np.asarray(b) for b in bands], extra)
+        if out is not None:
+            return out
     dev = [to_device_f32(b) for b in bands]           # `.astype('f4')` of the reference wrappers
     out = DeviceArray(dev[0].shape, np.float32)
     _lib.call(fn_name, *[d.ptr for d in dev], out.ptr, out.size, *extra, get_stream())

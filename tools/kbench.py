@@ -168,6 +168,9 @@ def main():
         "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
         "focal25_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),
         "focal25_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 32),
+        "focal25_sum": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 1 << 6, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),
+        "focal25_minmaxrange": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 0b1110, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 16),
+        "focal25_meanvarstd": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 0b110001, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 16),
         "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),

@@ -128,6 +128,10 @@ __device__ __forceinline__ void store_row(float *out, long ld, long y, long x0, 
 // view advanced one 16-byte slot per 4 taps; a slot whose 4 mask bits are all set runs without per-tap
 // tests, an empty one is skipped (the slot after the last needed one is read and ignored; the tile
 // allocation carries 64 bytes of slack for it).
+__device__ __forceinline__ void keep4(float4 &q) {
+    asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+}
+
 template <int KH, int KW, typename F>
 __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile, int orow, int lane,
                                             const unsigned long long *rowmask, F &&f) {
@@ -156,12 +160,19 @@ __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile,
             if (!bits) continue;
             const float4 *r4 = reinterpret_cast<const float4 *>(tile + (orow + ky) * a.pitch) + lane;
             // slots are fetched four at a time (ds_read_b128 x4 in flight) and consumed from registers
+            // Every slot is loaded whole: `keep4` makes all four components live, otherwise the compiler narrows the
+            // 16-byte reads to the dwords a path happens to use (ds_read_b96 / b64 / read2_b32), and at a lane
+            // stride of 16 bytes those are 2- to 4-way bank conflicts where ds_read_b128 has none (PMC on the 25x25
+            // float32 walk: 65 % of the LDS cycles were conflicts, LDS 93 % busy).
             float4 slot[5];
             slot[0] = r4[0];
+            keep4(slot[0]);
             for (int jg = 0; jg < nchunks; jg += 4) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) slot[c + 1] = r4[jg + c + 1];      // (reads past the row's last slot land in
 #pragma unroll                                                                //  the next row / the allocation's slack)
+                for (int c = 0; c < 4; ++c) keep4(slot[c + 1]);                // (after all four are in flight)
+#pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int jc = jg + c;
                     const unsigned b4 = jc < nchunks ? (unsigned)(bits >> (4 * jc)) & 15u : 0u;
@@ -186,11 +197,14 @@ __device__ __forceinline__ void walk_window(const KxkArgs &a, const float *tile,
 // All statistics / any kernel shape.  Per output row: pass 1 walks the window row-major (the order the
 // reference's reducers visit their scratch array), pass 2 (std / var only) accumulates squared deviations.
 // MODE 0: mean only.  1: every requested statistic.  2: the float32 statistics only (sum, max, min, range) --
-// used for large masks whose mean / var / std come from the prefix-sum kernel of kxk_runs.hip.
+// used for large masks whose mean / var / std come from the prefix-sum kernel of kxk_runs.hip; 3: of those only
+// the row-major float32 sum; 4: only max / min / range.
 template <int KH, int KW, int MODE, bool VEC>
 __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float *tile, long X0, long Y0,
                                                    bool nan_free = false) {
     constexpr bool MEAN_ONLY = MODE == 0;
+    constexpr bool F32_ONLY = MODE >= 2;                 // no float64 statistics
+    constexpr bool WANT_SUM = MODE != 4, WANT_MM = MODE != 3;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const long x0 = X0 + lane * 4;
     if (x0 >= a.cols) return;
@@ -207,15 +221,17 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
         float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-        if (MODE == 2 && nan_free) {
+        if (F32_ONLY && nan_free) {
             // float32 statistics of a tile without NaN / out-of-raster cells: three VALU ops per tap
             walk_window<KH, KW>(a, tile, orow, lane, a.mask_rows, [&](int, int, float v0, float v1, float v2, float v3) {
                 const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    sum32[o] += v[o];
-                    mn[o] = fminf(mn[o], v[o]);
-                    mx[o] = fmaxf(mx[o], v[o]);
+                    if (WANT_SUM) sum32[o] += v[o];
+                    if (WANT_MM) {
+                        mn[o] = fminf(mn[o], v[o]);
+                        mx[o] = fmaxf(mx[o], v[o]);
+                    }
                 }
             });
 #pragma unroll
@@ -226,12 +242,14 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const bool ok = !isnan(v[o]);
-                    if (MODE != 2) sum64[o] += ok ? (double)v[o] : 0.0;
+                    if (!F32_ONLY) sum64[o] += ok ? (double)v[o] : 0.0;
                     cnt[o] += ok ? 1 : 0;
                     if (!MEAN_ONLY) {
-                        sum32[o] = ok ? sum32[o] + v[o] : sum32[o];
-                        mn[o] = fminf(mn[o], v[o]);
-                        mx[o] = fmaxf(mx[o], v[o]);
+                        if (WANT_SUM) sum32[o] = ok ? sum32[o] + v[o] : sum32[o];
+                        if (WANT_MM) {
+                            mn[o] = fminf(mn[o], v[o]);
+                            mx[o] = fmaxf(mx[o], v[o]);
+                        }
                     }
                 }
             });
@@ -244,7 +262,7 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
             mean[o] = sum64[o] * rcp_count(cnt[o]);
             o_tmp[o] = (float)mean[o];
         }
-        if (MODE != 2) store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
+        if (!F32_ONLY) store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
         if (MEAN_ONLY) continue;
 
         if (a.out[XRS_STAT_MAX]) {
@@ -262,9 +280,9 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
             for (int o = 0; o < 4; ++o) o_tmp[o] = cnt[o] ? mx[o] - mn[o] : nan_f32();
             store_row<VEC>(a.out[XRS_STAT_RANGE], a.ld_out, y, x0, a.cols, o_tmp);
         }
-        store_row<VEC>(a.out[XRS_STAT_SUM], a.ld_out, y, x0, a.cols, sum32);
+        if (WANT_SUM) store_row<VEC>(a.out[XRS_STAT_SUM], a.ld_out, y, x0, a.cols, sum32);
 
-        if (MODE != 2 && (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR])) {
+        if (!F32_ONLY && (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR])) {
             double ssd[4] = {0, 0, 0, 0};
             walk_window<KH, KW>(a, tile, orow, lane, a.mask_rows, [&](int, int, float v0, float v1, float v2, float v3) {
                 const float v[4] = {v0, v1, v2, v3};
@@ -1001,6 +1019,10 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         if (rc > 0) return rc;
         if (rc == 0) {
             if (!(stat_mask & ~f64_stats)) return 0;
+            const bool want_sum = stat_mask >> XRS_STAT_SUM & 1;
+            const bool want_mm = stat_mask & ((1u << XRS_STAT_MAX) | (1u << XRS_STAT_MIN) | (1u << XRS_STAT_RANGE));
+            if (!want_mm) return launch_focal<0, 0, 3>(a, vec, lds, s);
+            if (!want_sum) return launch_focal<0, 0, 4>(a, vec, lds, s);
             return launch_focal<0, 0, 2>(a, vec, lds, s);
         }
     }

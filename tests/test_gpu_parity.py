@@ -252,6 +252,52 @@ def test_kxk_vs_oracle(kname, shape):
     np.testing.assert_array_equal(apply(agg, k, _calc_sum).data, corc.focal_apply(z, k, 'sum'))
 
 
+@pytest.mark.parametrize("radius", range(4, 13))
+def test_circular_masks_column_walker(radius):
+    """Circles of radius 4..12 cells take the column-walker kernel for sum / max / min / range (kxk_circle.hip):
+    bit-exact against the oracle's row-major float32 sum and its extrema, with NaN holes, +-inf, windows wider
+    than the raster, all-NaN windows, widths that are not multiples of 64, and row shards with halos."""
+    from xrspatial_amd import _lib
+    k = circle_kernel(1, 1, radius)
+    K = 2 * radius + 1
+    assert k.shape == (K, K)
+    rng = np.random.default_rng(radius)
+    for shape in ((150, 331), (K - 2, 70), (3 * K, K + 5)):
+        z = synth.smooth_dem(shape, nan_frac=0.02, seed=radius)
+        z[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = np.inf
+        z[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = -np.inf
+        if shape[0] > 100:
+            z[40:40 + 2 * K, 100:100 + 2 * K] = np.nan            # windows without a single valid cell
+        got = focal_stats(raster(z), k, stats_funcs=['sum', 'max', 'min', 'range', 'mean'])
+        with np.errstate(all='ignore'):
+            for i, stat in enumerate(('sum', 'max', 'min', 'range')):
+                np.testing.assert_array_equal(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), err_msg=f"{stat} {shape}")
+            np.testing.assert_allclose(got.data[4], corc.focal_apply(z, k, 'mean', nthreads=8), rtol=1e-6, equal_nan=True)
+        # single statistics take the lean instantiations
+        np.testing.assert_array_equal(apply(raster(z), k, _calc_sum).data, got.data[0])
+        np.testing.assert_array_equal(focal_stats(raster(z), k, stats_funcs=['min', 'range']).data, got.data[[2, 3]])
+    # row shard with halo rows: rows [50, 110) of the first raster, halos in the same allocation
+    z = synth.smooth_dem((150, 320), nan_frac=0.01, seed=radius + 100)
+    want = {s: corc.focal_apply(z, k, s, nthreads=8) for s in ('sum', 'max')}
+    full = xs.DeviceArray.from_numpy(z)
+    import ctypes
+    for first, n, ht, hb in ((50, 60, radius, radius), (0, 40, 0, radius), (110, 40, radius, 0)):
+        o_sum, o_max = xs.DeviceArray((n, 320), np.float32), xs.DeviceArray((n, 320), np.float32)
+        ptrs = (ctypes.c_void_p * 7)()
+        ptrs[6], ptrs[1] = o_sum.ptr, o_max.ptr
+        kk = np.ascontiguousarray(k, dtype=np.float64)
+        _lib.call("xrs_focal_stats_f32", full.ptr + first * 320 * 4, ptrs, (1 << 6) | (1 << 1), n, 320, 320, 320,
+                  kk.ctypes.data, K, K, None, ht, hb, None)
+        _lib.call("xrs_stream_sync", None)
+        np.testing.assert_array_equal(o_sum.get(), want['sum'][first:first + n])
+        np.testing.assert_array_equal(o_max.get(), want['max'][first:first + n])
+    # a mask of the same size that is NOT the circle keeps the general walk (and its results)
+    k2 = k.copy()
+    k2[0, 0] = 1.0
+    z = synth.smooth_dem((60, 200), nan_frac=0.02)
+    np.testing.assert_array_equal(apply(raster(z), k2, _calc_sum).data, corc.focal_apply(z, k2, 'sum', nthreads=8))
+
+
 def test_focal_runs_kernel_inf_and_nan_tiles():
     # the prefix-sum kernel: a tile with +-inf takes its direct fallback, NaN tiles count taps
     z = synth.smooth_dem((90, 300), nan_frac=0.03)

@@ -1019,6 +1019,11 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         if (rc > 0) return rc;
         if (rc == 0) {
             if (!(stat_mask & ~f64_stats)) return 0;
+            // circles of radius 4..12 cells: column walker (kxk_circle.hip); any other run-structured mask: tap walk
+            const int rc2 = try_launch_focal_circle_f32(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN],
+                                                        a.out[XRS_STAT_RANGE], rows, cols, ld_in, ld_out, kernel, krows,
+                                                        kcols, halo_top, halo_bot, s);
+            if (rc2 >= 0) return rc2;
             const bool want_sum = stat_mask >> XRS_STAT_SUM & 1;
             const bool want_mm = stat_mask & ((1u << XRS_STAT_MAX) | (1u << XRS_STAT_MIN) | (1u << XRS_STAT_RANGE));
             if (!want_mm) return launch_focal<0, 0, 3>(a, vec, lds, s);

@@ -69,4 +69,10 @@ int try_launch_focal_meanvar_runs(const float *in, float *out_mean, float *out_v
                                   long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols,
                                   int halo_top, int halo_bot, hipStream_t s);
 
+// kxk_circle.hip: float32 sum / max / min / range for circular masks of radius 4..12 cells (column walker).
+// 0 = launched, -1 = not such a circle (caller walks the taps), > 0 = error.  Null outputs are skipped.
+int try_launch_focal_circle_f32(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                                long rows, long cols, long ld_in, long ld_out, const double *kernel, int krows,
+                                int kcols, int halo_top, int halo_bot, hipStream_t s);
+
 }  // namespace xrs

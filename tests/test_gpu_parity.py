@@ -268,11 +268,18 @@ def test_circular_masks_column_walker(radius):
         z[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = -np.inf
         if shape[0] > 100:
             z[40:40 + 2 * K, 100:100 + 2 * K] = np.nan            # windows without a single valid cell
-        got = focal_stats(raster(z), k, stats_funcs=['sum', 'max', 'min', 'range', 'mean'])
+        if shape[0] > 100:
+            z[100:140, 200:280] = 777.25                          # a lake: var exactly 0 inside (guarded one-pass variance)
+        got = focal_stats(raster(z), k, stats_funcs=['sum', 'max', 'min', 'range', 'mean', 'var', 'std'])
         with np.errstate(all='ignore'):
             for i, stat in enumerate(('sum', 'max', 'min', 'range')):
                 np.testing.assert_array_equal(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), err_msg=f"{stat} {shape}")
-            np.testing.assert_allclose(got.data[4], corc.focal_apply(z, k, 'mean', nthreads=8), rtol=1e-6, equal_nan=True)
+            for i, stat in ((4, 'mean'), (5, 'var'), (6, 'std')):     # float64 moments (kxk_circle64.hip)
+                np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=0,
+                                           equal_nan=True, err_msg=f"{stat} {shape}")
+        if shape[0] > 100:
+            inner = got.data[5][100 + radius:140 - radius, 200 + radius:280 - radius]
+            assert inner.size and (inner == 0).all()
         # single statistics take the lean instantiations
         np.testing.assert_array_equal(apply(raster(z), k, _calc_sum).data, got.data[0])
         np.testing.assert_array_equal(focal_stats(raster(z), k, stats_funcs=['min', 'range']).data, got.data[[2, 3]])
@@ -296,6 +303,35 @@ def test_circular_masks_column_walker(radius):
     k2[0, 0] = 1.0
     z = synth.smooth_dem((60, 200), nan_frac=0.02)
     np.testing.assert_array_equal(apply(raster(z), k2, _calc_sum).data, corc.focal_apply(z, k2, 'sum', nthreads=8))
+
+
+def test_flat_windows_have_exactly_zero_variance():
+    """A window over equal cells: the reference divides sum by count exactly, so mean == the cell value and
+    var == std == 0 exactly -- for every kernel family (3x3 / 5x5 register strips, 7x7 LDS tile, large masks through
+    prefix sums, circles through the column walkers), awkward values and counts (13, 29, 441 taps ...)."""
+    rng = np.random.default_rng(31)
+    z = synth.smooth_dem((160, 384), nan_frac=0.01)
+    vals = np.float32([2000.3, 1234.567, 0.1, 16777217.0, 3.3333333e-5])
+    boxes = [(10 + 28 * i, 20 + 70 * i) for i in range(5)]
+    for (r0, c0), val in zip(boxes, vals):
+        z[r0:r0 + 27, c0:c0 + 66] = val
+    ragged = (rng.random((11, 11)) < 0.6).astype(float)
+    ragged[5, 5] = 1.0
+    masks = {'box3': np.ones((3, 3)), 'circle5': circle_kernel(1, 1, 2), 'annulus7': annulus_kernel(1, 1, 3, 1),
+             'circle9': circle_kernel(1, 1, 4), 'ragged11': ragged, 'box11': np.ones((11, 11)),
+             'circle25': circle_kernel(1, 1, 12)}
+    for name, k in masks.items():
+        r = k.shape[0] // 2
+        got = focal_stats(raster(z), k, stats_funcs=['mean', 'var', 'std'])
+        for (r0, c0), val in zip(boxes, vals):
+            inner = (slice(r0 + r, r0 + 27 - r), slice(c0 + r, c0 + 66 - r))
+            assert got.data[0][inner].size
+            np.testing.assert_array_equal(got.data[0][inner], val, err_msg=f"{name} mean {val}")
+            np.testing.assert_array_equal(got.data[1][inner], 0.0, err_msg=f"{name} var {val}")
+            np.testing.assert_array_equal(got.data[2][inner], 0.0, err_msg=f"{name} std {val}")
+        for i, stat in enumerate(('mean', 'var', 'std')):
+            np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=0,
+                                       equal_nan=True, err_msg=f"{name} {stat}")
 
 
 def test_focal_runs_kernel_inf_and_nan_tiles():

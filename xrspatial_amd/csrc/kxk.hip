@@ -259,7 +259,7 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
         float o_tmp[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            mean[o] = sum64[o] * rcp_count(cnt[o]);
+            mean[o] = div_refined(sum64[o], (double)cnt[o], rcp_count(cnt[o]));
             o_tmp[o] = (float)mean[o];
         }
         if (!F32_ONLY) store_row<VEC>(a.out[XRS_STAT_MEAN], a.ld_out, y, x0, a.cols, o_tmp);
@@ -516,7 +516,7 @@ __device__ __forceinline__ void focal_stats_direct_rows(const KxkArgs &a, long x
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             inv[o] = CAREFUL ? rcp_count(cnt[o]) : a.inv_ntaps;
-            mean[o] = sum64[o] * inv[o];
+            mean[o] = div_refined(sum64[o], CAREFUL ? (double)cnt[o] : (double)a.ntaps, inv[o]);
         }
         if (a.out[XRS_STAT_STD] || a.out[XRS_STAT_VAR]) {
 #pragma unroll
@@ -1013,7 +1013,12 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         // the float32 statistics (row-major sum, min, max, range) from one tap walk over the LDS tile
         const unsigned f64_stats = (1u << XRS_STAT_MEAN) | (1u << XRS_STAT_VAR) | (1u << XRS_STAT_STD);
         int rc = 0;
-        if (stat_mask & f64_stats)
+        if (stat_mask & f64_stats) {
+            rc = try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols,
+                                             ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            if (rc > 0) return rc;
+        }
+        if ((stat_mask & f64_stats) && rc < 0)
             rc = try_launch_focal_meanvar_runs(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows,
                                                cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
         if (rc > 0) return rc;

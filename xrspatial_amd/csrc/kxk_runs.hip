@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(1024, 4) focal_meanvar_runs_kernel(const RunAr
                 if (!isnan(val)) { s += (double)val; ++n; }
             }
         }
-        mean = s * rcp_count(n);
+        mean = n ? s / (double)n : nan("");               // true division: a flat window must give its value exactly
         double ssd = 0.0;
         for (int ky = 0; ky < a.krows; ++ky) {
             const long yy = y - ry + ky;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(1024, 4) focal_meanvar_runs_kernel(const RunAr
                 if (!isnan(val)) { const double d = (double)val - mean; ssd += d * d; }
             }
         }
-        var = ssd * rcp_count(n);
+        var = n ? ssd / (double)n : nan("");
     };
 
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};

@@ -16,6 +16,14 @@ __device__ __forceinline__ double rcp_count(int n) {
     return n ? r : nan("");
 }
 
+// s / n from a reciprocal, with one residual correction: exact whenever the quotient is representable, so the
+// mean of a flat window is the cell value itself and its variance exactly 0, as with the reference's true division.
+__device__ __forceinline__ double div_refined(double s, double n, double inv) {
+    const double q = s * inv;
+    const double q2 = fma(fma(-q, n, s), inv, q);
+    return isfinite(q2) ? q2 : q;          // (+-inf sums, empty windows: keep the inf / NaN)
+}
+
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at dword alignment
 
 // Strip loader shared by the register-resident kernels: v[r][0..NV) = columns x0-RX .. x0+3+RX of input

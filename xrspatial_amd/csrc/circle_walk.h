@@ -1,0 +1,327 @@
+// Column-walker building blocks for circular focal masks (kxk_circle.hip: float32 sum / max / min / range;
+// kxk_circle64.hip: float64 mean / var / std; small radii run both in one kernel).
+//
+// A lane owns ONE column of a 256 x CTH tile and walks down its input rows.  Every input row y' is read once per
+// column (2R+1 neighbouring cells, L1 hits) and contributes to the 2R+1 output rows y' - dy that see it; their
+// partial results live in a register ring that shifts one slot per input row, so the loop body is the same for
+// every row, and because the circle's half-widths are compile-time constants every register index is static.
+// No LDS, no barriers.  Reference semantics: xrspatial/focal.py:226-258 (numba reducers) over the cells under
+// `kernel == 1` in row-major order (:268-326), NaN cells skipped, window clipped at the raster edge.
+#pragma once
+#include "xrs_common.h"
+
+#include <cmath>
+
+namespace xrs {
+
+constexpr int CTH = 128;     // output rows per tile (input rows walked: CTH + 2R)
+
+// half-width of the circle's row dy: largest dx with dx^2 + dy^2 <= R^2 (the division-free test of
+// convolution.py:144 on square cells)
+constexpr int half_width(int R, int dy) {
+    int h = 0;
+    while ((h + 1) * (h + 1) + dy * dy <= R * R) ++h;
+    return h;
+}
+
+constexpr int circle_taps(int R) {
+    int n = 0;
+    for (int dy = -R; dy <= R; ++dy) n += 2 * half_width(R, dy < 0 ? -dy : dy) + 1;
+    return n;
+}
+
+template <int R>
+inline bool is_circle(const double *kernel) {
+    constexpr int K = 2 * R + 1;
+    for (int ky = 0; ky < K; ++ky) {
+        const int dy = ky < R ? R - ky : ky - R, h = half_width(R, dy);
+        for (int kx = 0; kx < K; ++kx) {
+            const int dx = kx < R ? R - kx : kx - R;
+            if ((kernel[ky * K + kx] == 1.0) != (dx <= h)) return false;
+        }
+    }
+    return true;
+}
+
+struct WalkGeom {
+    const float *in;
+    long rows, cols, ld_in, ld_out;
+    int halo_top, halo_bot;
+    long tiles_x, n_tiles;
+};
+
+// The 2R+1 cells of input row yy around column x (NaN outside the raster / the shard's halo rows).
+template <int R>
+__device__ __forceinline__ void walk_load_row(const WalkGeom &g, long yy, long xw, int lane, float (&v)[2 * R + 1]) {
+    constexpr int K = 2 * R + 1;
+    const long x = xw + lane;
+    const float qnan = nan_f32();
+    const bool row_ok = yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;        // wave-uniform
+    if (row_ok) {
+        const float *p = g.in + yy * g.ld_in + xw + lane;                           // scalar row base + lane
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const long xc = x + k - R;
+            v[k] = (xc >= 0 && xc < g.cols) ? p[k - R] : qnan;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = qnan;
+    }
+}
+
+typedef float walk_v2f __attribute__((ext_vector_type(2)));
+
+// ---- float32 row-major sum, max, min, range
+//   * max / min: the running extremum over the centred run of half-width h, m_h = min(m_{h-1}, v[-h], v[+h]), costs
+//     R `v_min3` per row and is exactly what output row y' - dy needs for h = hw(dy): 2R+1 more `v_min` instead of
+//     one per tap (441 -> 37 per cell for R = 12);
+//   * sum: the reference adds the taps sequentially in float32 (numba nansum keeps the array dtype), so the rounding
+//     of every partial sum is part of the result and nothing can be shared or re-associated -- but output rows dy
+//     and -dy append the SAME values in the SAME order, so their two accumulators share one packed `v_pk_add_f32`
+//     per value (441 -> 233 instructions per cell).  NaN cells are added as +0.0 (exact: an accumulator that
+//     starts at +0.0 is never -0.0) and skipped by IEEE minNum / maxNum; a window without a valid cell gives sum 0
+//     and NaN for max / min / range, like the reference.
+template <int R, bool WANT_SUM, bool WANT_MM>
+struct WalkF32 {
+    static constexpr int K = 2 * R + 1;
+    walk_v2f sp[R > 0 ? R : 1];   // (slot j, slot 2R - j) for j < R; ring slot j = output row (input row) - (j - R)
+    float sc;                     // slot R (dy = 0)
+    float mn[K], mx[K];
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < R; ++j) sp[j] = (walk_v2f)(0.0f);
+        sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { mn[j] = INFINITY; mx[j] = -INFINITY; }
+    }
+
+    __device__ __forceinline__ void row(const float (&v)[K]) {
+        if (WANT_MM) {
+            float lo = v[R], hi = v[R];
+#pragma unroll
+            for (int h = 0; h <= R; ++h) {
+                if (h > 0) {
+                    lo = fminf(fminf(lo, v[R - h]), v[R + h]);
+                    hi = fmaxf(fmaxf(hi, v[R - h]), v[R + h]);
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (half_width(R, dy < 0 ? -dy : dy) == h) {
+                        mn[j] = fminf(mn[j], lo);
+                        mx[j] = fmaxf(mx[j], hi);
+                    }
+                }
+            }
+        }
+        if (WANT_SUM) {
+            float z[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] = isnan(v[k]) ? 0.0f : v[k];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int h = half_width(R, R - j);
+#pragma unroll
+                for (int k = R - h; k <= R + h; ++k) sp[j] += (walk_v2f)(z[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) sc += z[k];
+        }
+    }
+
+    // results of the completed output row (slot 2R)
+    __device__ __forceinline__ void emit(long off, float *out_sum, float *out_max, float *out_min, float *out_range) const {
+        if (WANT_SUM && out_sum) out_sum[off] = R > 0 ? sp[0].y : sc;
+        if (WANT_MM) {
+            const float qnan = nan_f32();
+            const bool none = mn[2 * R] > mx[2 * R];                // no valid cell under the window
+            if (out_max) out_max[off] = none ? qnan : mx[2 * R];
+            if (out_min) out_min[off] = none ? qnan : mn[2 * R];
+            if (out_range) out_range[off] = none ? qnan : mx[2 * R] - mn[2 * R];
+        }
+    }
+
+    __device__ __forceinline__ void shift() {
+        if (WANT_SUM && R > 0) {
+            // slots 0..R-1 are the .x halves (moving up), slots R+1..2R the .y halves of sp[2R - slot]
+#pragma unroll
+            for (int j = 0; j + 1 < R; ++j) sp[j].y = sp[j + 1].y;      // slot 2R-j <- slot 2R-j-1
+            const float old_c = sc;
+            sc = sp[R - 1].x;                                           // slot R <- slot R-1
+            sp[R - 1].y = old_c;                                        // slot R+1 <- slot R
+#pragma unroll
+            for (int j = R - 1; j > 0; --j) sp[j].x = sp[j - 1].x;      // slot j <- slot j-1
+            sp[0].x = 0.0f;
+        }
+        if (WANT_MM) {
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) { mn[j] = mn[j - 1]; mx[j] = mx[j - 1]; }
+            mn[0] = INFINITY; mx[0] = -INFINITY;
+        }
+    }
+};
+
+// ---- float64 mean, var, std (numba nanmean / nanvar: float64 accumulation, two-pass variance, float32 store)
+// Per input row a lane forms, from the centre outwards, the float64 sum S_h and sum of squares Q_h of the SHIFTED
+// values d = v - c over the centred run of half-width h, plus the count C_h of valid cells; output row y' - dy
+// adds (S, Q, C) of h = hw(dy) to its ring slot: 2R+1 triple-adds per row and column instead of one per tap.  c is
+// the lane's own column value at the middle row of the tile (every output is produced by one lane, so the shift may
+// differ per lane, and a nearby value keeps d small).  At the end  mean = c + S/n,  var = (Q - S^2/n)/n;  if that
+// one-pass variance is not comfortably above the rounding noise of its operands (flat patches inside high-relief
+// tiles, +-inf under the window) the output is recomputed tap by tap with the reference's two-pass loops.  Sums are
+// re-associated relative to the reference's row-major order: invisible after the float32 rounding (tests: 1e-6).
+__device__ __forceinline__ double walk_rcp(int n) {
+    const double c = (double)n;
+    double r = __builtin_amdgcn_rcp(c);
+    r = fma(fma(-c, r, 1.0), r, r);
+    return n ? r : nan("");
+}
+
+template <int R>
+struct WalkF64 {
+    static constexpr int K = 2 * R + 1;
+    double sd[K], sq[K];
+    int cn[K];
+    float amax, cf;               // running max |v - c| over everything this lane has read (guard scale); the shift
+
+    __device__ __forceinline__ void init(const WalkGeom &g, long y0, long x) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { sd[j] = 0.0; sq[j] = 0.0; cn[j] = 0; }
+        amax = 0.0f;
+        cf = 0.0f;
+        const long yc = (y0 + CTH / 2 < g.rows ? y0 + CTH / 2 : g.rows - 1);
+        if (x < g.cols) {
+            const float c0 = g.in[yc * g.ld_in + x];
+            if (isfinite(c0)) cf = c0;
+        }
+    }
+
+    __device__ __forceinline__ void row(const float (&v)[K]) {
+        const double shift = (double)cf;
+        double S = 0.0, Q = 0.0;
+        int C = 0;
+#pragma unroll
+        for (int h = 0; h <= R; ++h) {
+#pragma unroll
+            for (int side = 0; side < (h == 0 ? 1 : 2); ++side) {
+                const float val = v[side == 0 ? R - h : R + h];
+                const bool ok = !isnan(val);
+                const double d = ok ? (double)val - shift : 0.0;
+                S += d;
+                Q = fma(d, d, Q);
+                C += ok ? 1 : 0;
+                amax = fmaxf(amax, isfinite(val) ? fabsf(val - cf) : 0.0f);   // (+-inf: the sums go non-finite -> exact path)
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int dy = j - R;
+                if (half_width(R, dy < 0 ? -dy : dy) == h) { sd[j] += S; sq[j] += Q; cn[j] += C; }
+            }
+        }
+    }
+
+    // completed output row yo (slot 2R), column x
+    __device__ __forceinline__ void emit(const WalkGeom &g, long yo, long x, float *out_mean, float *out_var,
+                                         float *out_std) const {
+        const long y_lo = -(long)g.halo_top, y_hi = g.rows + g.halo_bot;
+        const double shift = (double)cf;
+        const int n = cn[2 * R];
+        const double inv = walk_rcp(n);
+        const double ms = sd[2 * R] * inv;                              // mean of the shifted values
+        const double ssd = sq[2 * R] - sd[2 * R] * ms;
+        double mean = shift + ms;
+        double var = (ssd > 0.0 ? ssd : 0.0) * inv;
+        // rounding noise of Q and S^2/n is ~ ntaps * eps * max(d^2); 1e6 of headroom as in kxk_runs.hip
+        const double guard = 1e-9 * (double)circle_taps(R) * ((double)amax * (double)amax);
+        if (n != 0 && !(ssd >= guard)) {
+            // ill-conditioned / exactly flat window, or +-inf under it: the reference's two-pass loops
+            double s = 0.0;
+            int m = 0;
+            for (int ky = 0; ky < K; ++ky) {
+                const long yr = yo - R + ky;
+                if (yr < y_lo || yr >= y_hi) continue;
+                const int h = half_width(R, ky < R ? R - ky : ky - R);
+                for (int kx = R - h; kx <= R + h; ++kx) {
+                    const long xr = x - R + kx;
+                    if (xr < 0 || xr >= g.cols) continue;
+                    const float val = g.in[yr * g.ld_in + xr];
+                    if (!isnan(val)) { s += (double)val; ++m; }
+                }
+            }
+            mean = m ? s / (double)m : nan("");          // true division: a flat window must give its value exactly
+            double dev = 0.0;
+            for (int ky = 0; ky < K; ++ky) {
+                const long yr = yo - R + ky;
+                if (yr < y_lo || yr >= y_hi) continue;
+                const int h = half_width(R, ky < R ? R - ky : ky - R);
+                for (int kx = R - h; kx <= R + h; ++kx) {
+                    const long xr = x - R + kx;
+                    if (xr < 0 || xr >= g.cols) continue;
+                    const float val = g.in[yr * g.ld_in + xr];
+                    if (!isnan(val)) { const double d = (double)val - mean; dev += d * d; }
+                }
+            }
+            var = m ? dev / (double)m : nan("");
+        }
+        const long off = yo * g.ld_out + x;
+        if (out_mean) out_mean[off] = (float)mean;
+        if (out_var) out_var[off] = (float)var;
+        if (out_std) out_std[off] = (float)sqrt(var);
+    }
+
+    __device__ __forceinline__ void shift() {
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) { sd[j] = sd[j - 1]; sq[j] = sq[j - 1]; cn[j] = cn[j - 1]; }
+        sd[0] = 0.0; sq[0] = 0.0; cn[0] = 0;
+    }
+};
+
+struct WalkOuts {
+    float *sum, *max, *min, *range, *mean, *var, *std;      // any may be NULL
+};
+
+// One kernel body for every combination: F32 = run the float32 statistics, F64 = run the moments.
+template <int R, bool F32, bool WANT_SUM, bool WANT_MM, bool F64>
+__device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
+    constexpr int K = 2 * R + 1;
+    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    if (t < 0) return;
+    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long xw = tx * 256 + wv * 64;                 // first column of this wave (scalar)
+    const long x = xw + lane;
+    const long y0 = ty * CTH;
+    const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);        // output rows [y0, y_end)
+    if (xw >= g.cols) return;
+
+    WalkF32<R, WANT_SUM, WANT_MM> a32;
+    WalkF64<R> a64;
+    if (F32) a32.init();
+    if (F64) a64.init(g, y0, x);
+    for (long yy = y0 - R; yy < y_end + R; ++yy) {
+        float v[K];
+        walk_load_row<R>(g, yy, xw, lane, v);
+        if (F32) a32.row(v);
+        if (F64) a64.row(v);
+        const long yo = yy - R;                         // the output row that is now complete
+        if (yo >= y0 && x < g.cols) {
+            if (F32) a32.emit(yo * g.ld_out + x, o.sum, o.max, o.min, o.range);
+            if (F64) a64.emit(g, yo, x, o.mean, o.var, o.std);
+        }
+        if (F32) a32.shift();
+        if (F64) a64.shift();
+    }
+}
+
+inline int walk_grid(WalkGeom &g, long *grid) {
+    g.tiles_x = (g.cols + 255) / 256;
+    g.n_tiles = g.tiles_x * ((g.rows + CTH - 1) / CTH);
+    *grid = xcd_grid(g.n_tiles);
+    if (*grid > 0x7fffffffL) return fail("focal circle: raster too large for one launch");
+    return 0;
+}
+
+}  // namespace xrs

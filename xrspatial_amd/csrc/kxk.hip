@@ -898,6 +898,12 @@ bool prefer_lds() {
     return e && strcmp(e, "lds") == 0;
 }
 
+// XRS_FOCAL_VARIANT=strip keeps small circular masks on the register-strip all-statistics kernel (A/B; default: walker)
+bool prefer_strip() {
+    const char *e = getenv("XRS_FOCAL_VARIANT");
+    return e && (strcmp(e, "strip") == 0 || strcmp(e, "lds") == 0);
+}
+
 template <bool MEAN_ONLY>
 int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
     if (MEAN_ONLY && vec && !prefer_lds()) {
@@ -1026,8 +1032,8 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
             if (!(stat_mask & ~f64_stats)) return 0;
             // circles of radius 4..12 cells: column walker (kxk_circle.hip); any other run-structured mask: tap walk
             const int rc2 = try_launch_focal_circle_f32(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN],
-                                                        a.out[XRS_STAT_RANGE], rows, cols, ld_in, ld_out, kernel, krows,
-                                                        kcols, halo_top, halo_bot, s);
+                                                        a.out[XRS_STAT_RANGE], nullptr, nullptr, nullptr, rows, cols,
+                                                        ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
             if (rc2 >= 0) return rc2;
             const bool want_sum = stat_mask >> XRS_STAT_SUM & 1;
             const bool want_mm = stat_mask & ((1u << XRS_STAT_MAX) | (1u << XRS_STAT_MIN) | (1u << XRS_STAT_RANGE));
@@ -1037,6 +1043,18 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         }
     }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
+    if ((krows == 5 || krows == 7) && krows == kcols && !prefer_strip()) {
+        // small circles (circle_kernel radius 2, 3): all requested statistics from one column-walker kernel
+        const bool f32_stats = a.out[XRS_STAT_SUM] || a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
+        const int rc = f32_stats
+            ? try_launch_focal_circle_f32(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN],
+                                          a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR],
+                                          a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols,
+                                          halo_top, halo_bot, s)
+            : try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows,
+                                          cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc >= 0) return rc;
+    }
     // the all-statistics kernel always produces the mean internally; give it somewhere to go
     return dispatch_focal<false>(a, vec, lds, s);
 }

@@ -69,11 +69,13 @@ int try_launch_focal_meanvar_runs(const float *in, float *out_mean, float *out_v
                                   long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols,
                                   int halo_top, int halo_bot, hipStream_t s);
 
-// kxk_circle.hip: float32 sum / max / min / range for circular masks of radius 4..12 cells (column walker).
+// kxk_circle.hip: float32 sum / max / min / range for circular masks of radius 2..12 cells (column walker).
 // 0 = launched, -1 = not such a circle (caller walks the taps), > 0 = error.  Null outputs are skipped.
+// With any of out_mean / out_var / out_std non-null all seven statistics come from one kernel (radius 2, 3 only).
 int try_launch_focal_circle_f32(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                                long rows, long cols, long ld_in, long ld_out, const double *kernel, int krows,
-                                int kcols, int halo_top, int halo_bot, hipStream_t s);
+                                float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in,
+                                long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                                hipStream_t s);
 
 // kxk_circle64.hip: mean / var / std for the same circles (float64 moments of shifted values, guarded).
 int try_launch_focal_circle_f64(const float *in, float *out_mean, float *out_var, float *out_std, long rows, long cols,

@@ -11,6 +11,7 @@
 #include "xrs_common.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace xrs {
 
@@ -51,7 +52,8 @@ struct WalkGeom {
 };
 
 // The 2R+1 cells of input row yy around column x (NaN outside the raster / the shard's halo rows).
-template <int R>
+// EDGE = false: the wave's columns xw - R .. xw + 63 + R all lie inside the raster (wave-uniform fact): no column tests.
+template <int R, bool EDGE>
 __device__ __forceinline__ void walk_load_row(const WalkGeom &g, long yy, long xw, int lane, float (&v)[2 * R + 1]) {
     constexpr int K = 2 * R + 1;
     const long x = xw + lane;
@@ -61,8 +63,12 @@ __device__ __forceinline__ void walk_load_row(const WalkGeom &g, long yy, long x
         const float *p = g.in + yy * g.ld_in + xw + lane;                           // scalar row base + lane
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const long xc = x + k - R;
-            v[k] = (xc >= 0 && xc < g.cols) ? p[k - R] : qnan;
+            if (EDGE) {
+                const long xc = x + k - R;
+                v[k] = (xc >= 0 && xc < g.cols) ? p[k - R] : qnan;
+            } else {
+                v[k] = p[k - R];
+            }
         }
     } else {
 #pragma unroll
@@ -179,16 +185,18 @@ __device__ __forceinline__ double walk_rcp(int n) {
     return n ? r : nan("");
 }
 
-template <int R>
+template <int R, bool WANT_VAR = true>       // WANT_VAR = false: mean only (no squares, no guard)
 struct WalkF64 {
     static constexpr int K = 2 * R + 1;
-    double sd[K], sq[K];
+    double sd[K], sq[WANT_VAR ? K : 1];
     int cn[K];
     float amax, cf;               // running max |v - c| over everything this lane has read (guard scale); the shift
 
     __device__ __forceinline__ void init(const WalkGeom &g, long y0, long x) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) { sd[j] = 0.0; sq[j] = 0.0; cn[j] = 0; }
+        for (int j = 0; j < K; ++j) { sd[j] = 0.0; cn[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < (WANT_VAR ? K : 1); ++j) sq[j] = 0.0;
         amax = 0.0f;
         cf = 0.0f;
         const long yc = (y0 + CTH / 2 < g.rows ? y0 + CTH / 2 : g.rows - 1);
@@ -210,14 +218,20 @@ struct WalkF64 {
                 const bool ok = !isnan(val);
                 const double d = ok ? (double)val - shift : 0.0;
                 S += d;
-                Q = fma(d, d, Q);
                 C += ok ? 1 : 0;
-                amax = fmaxf(amax, isfinite(val) ? fabsf(val - cf) : 0.0f);   // (+-inf: the sums go non-finite -> exact path)
+                if (WANT_VAR) {
+                    Q = fma(d, d, Q);
+                    amax = fmaxf(amax, isfinite(val) ? fabsf(val - cf) : 0.0f);   // (+-inf: the sums go non-finite -> exact path)
+                }
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int dy = j - R;
-                if (half_width(R, dy < 0 ? -dy : dy) == h) { sd[j] += S; sq[j] += Q; cn[j] += C; }
+                if (half_width(R, dy < 0 ? -dy : dy) == h) {
+                    sd[j] += S;
+                    cn[j] += C;
+                    if (WANT_VAR) sq[j] += Q;
+                }
             }
         }
     }
@@ -230,7 +244,12 @@ struct WalkF64 {
         const int n = cn[2 * R];
         const double inv = walk_rcp(n);
         const double ms = sd[2 * R] * inv;                              // mean of the shifted values
-        const double ssd = sq[2 * R] - sd[2 * R] * ms;
+        if (!WANT_VAR) {
+            // mean only: c + S/n needs no guard (a +-inf under the window gives +-inf / NaN like the reference's sum)
+            if (out_mean) out_mean[yo * g.ld_out + x] = (float)(shift + ms);
+            return;
+        }
+        const double ssd = sq[WANT_VAR ? 2 * R : 0] - sd[2 * R] * ms;
         double mean = shift + ms;
         double var = (ssd > 0.0 ? ssd : 0.0) * inv;
         // rounding noise of Q and S^2/n is ~ ntaps * eps * max(d^2); 1e6 of headroom as in kxk_runs.hip
@@ -273,7 +292,11 @@ struct WalkF64 {
 
     __device__ __forceinline__ void shift() {
 #pragma unroll
-        for (int j = K - 1; j > 0; --j) { sd[j] = sd[j - 1]; sq[j] = sq[j - 1]; cn[j] = cn[j - 1]; }
+        for (int j = K - 1; j > 0; --j) { sd[j] = sd[j - 1]; cn[j] = cn[j - 1]; }
+        if (WANT_VAR) {
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) sq[j] = sq[j - 1];
+        }
         sd[0] = 0.0; sq[0] = 0.0; cn[0] = 0;
     }
 };
@@ -283,7 +306,7 @@ struct WalkOuts {
 };
 
 // One kernel body for every combination: F32 = run the float32 statistics, F64 = run the moments.
-template <int R, bool F32, bool WANT_SUM, bool WANT_MM, bool F64>
+template <int R, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
 __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
     constexpr int K = 2 * R + 1;
     const long t = xcd_tile(blockIdx.x, g.n_tiles);
@@ -298,22 +321,27 @@ __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) 
     if (xw >= g.cols) return;
 
     WalkF32<R, WANT_SUM, WANT_MM> a32;
-    WalkF64<R> a64;
+    WalkF64<R, WANT_VAR> a64;
     if (F32) a32.init();
     if (F64) a64.init(g, y0, x);
-    for (long yy = y0 - R; yy < y_end + R; ++yy) {
-        float v[K];
-        walk_load_row<R>(g, yy, xw, lane, v);
-        if (F32) a32.row(v);
-        if (F64) a64.row(v);
-        const long yo = yy - R;                         // the output row that is now complete
-        if (yo >= y0 && x < g.cols) {
-            if (F32) a32.emit(yo * g.ld_out + x, o.sum, o.max, o.min, o.range);
-            if (F64) a64.emit(g, yo, x, o.mean, o.var, o.std);
+    auto walk = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        for (long yy = y0 - R; yy < y_end + R; ++yy) {
+            float v[K];
+            walk_load_row<R, EDGE>(g, yy, xw, lane, v);
+            if (F32) a32.row(v);
+            if (F64) a64.row(v);
+            const long yo = yy - R;                     // the output row that is now complete
+            if (yo >= y0 && (!EDGE || x < g.cols)) {
+                if (F32) a32.emit(yo * g.ld_out + x, o.sum, o.max, o.min, o.range);
+                if (F64) a64.emit(g, yo, x, o.mean, o.var, o.std);
+            }
+            if (F32) a32.shift();
+            if (F64) a64.shift();
         }
-        if (F32) a32.shift();
-        if (F64) a64.shift();
-    }
+    };
+    if (xw >= R && xw + 64 + R <= g.cols) walk(std::false_type{});     // interior wave: no column predicates
+    else walk(std::true_type{});
 }
 
 inline int walk_grid(WalkGeom &g, long *grid) {

@@ -6,9 +6,9 @@ using namespace xrs;
 
 namespace {
 
-template <int R>
+template <int R, bool WANT_VAR>
 __global__ void __launch_bounds__(256) focal_circle_f64_kernel(const WalkGeom g, const WalkOuts o) {
-    walk_tile<R, false, false, false, true>(g, o);
+    walk_tile<R, false, false, false, true, WANT_VAR>(g, o);
 }
 
 template <int R>
@@ -16,7 +16,10 @@ int launch64(WalkGeom &g, const WalkOuts &o, const double *kernel, hipStream_t s
     if (!is_circle<R>(kernel)) return -1;
     long grid;
     if (int rc = walk_grid(g, &grid)) return rc;
-    hipLaunchKernelGGL((focal_circle_f64_kernel<R>), dim3((unsigned)grid), dim3(256), 0, s, g, o);
+    if (o.var || o.std)
+        hipLaunchKernelGGL((focal_circle_f64_kernel<R, true>), dim3((unsigned)grid), dim3(256), 0, s, g, o);
+    else
+        hipLaunchKernelGGL((focal_circle_f64_kernel<R, false>), dim3((unsigned)grid), dim3(256), 0, s, g, o);
     XRS_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,27 @@
+"""Time xrs_zonal_majority_f32 on a 16384^2 raster (1000 block zones): continuous float values (every value
+nearly unique: the sort path) and a categorical raster (32 classes)."""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import xrspatial_amd as xs
+from tests import synth
+from tools.kbench import Timer, device_raster
+from xrspatial_amd import _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+L = _lib.call
+dem = device_raster(n, n, lambda r, c, y0: synth.asv_dem(r, c, y0=y0, total_rows=n))
+cat = device_raster(n, n, lambda r, c, y0: np.random.default_rng(y0).integers(0, 32, (r, c)).astype(np.float32))
+zones = xs.DeviceArray((n, n), np.int32)
+for y0 in range(0, n, 2048):
+    z = synth.block_zones(min(2048, n - y0), n, y0=y0)
+    L("xrs_memcpy_h2d", zones.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
+L("xrs_stream_sync", None)
+nz = 1000
+nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(n * n, nz, 0))
+work = xs.DeviceArray((nbytes,), np.uint8)
+out = xs.DeviceArray((nz,), np.float64)
+t = Timer()
+for name, vals in (("continuous", dem), ("categorical32", cat)):
+    med, mn = t.time(lambda: L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None), 3, warmup=1)
+    print(f"majority {name:14s} {med:9.2f} ms  ({n*n/med/1e3:8.0f} Mcells/s)  workspace {nbytes/2**30:.1f} GiB", flush=True)

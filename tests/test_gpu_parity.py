@@ -793,6 +793,36 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
     assert len(pc) == 6
 
 
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.uint32, np.uint64, np.float32, np.float64])
+@pytest.mark.parametrize("size", [(2, 4), (100, 152)])
+def test_summarize_terrain(size, dtype, golden):
+    """analytics.summarize_terrain (reference test_analytics.py:8-33 + the docstring's compass rose): the bundle
+    equals the individual calls, from one fused launch."""
+    from xrspatial_amd.analytics import summarize_terrain
+    data = (np.random.default_rng(5).random(size) * 200).astype(dtype)
+    t = raster(data)
+    t.name = 'myterrain'
+    ds = summarize_terrain(t)
+    assert [v for v in ds] == ['myterrain', 'myterrain-slope', 'myterrain-curvature', 'myterrain-aspect']
+    np.testing.assert_array_equal(ds['myterrain-slope'].data, xs.slope(t).data)
+    np.testing.assert_array_equal(ds['myterrain-curvature'].data, xs.curvature(t).data)
+    np.testing.assert_array_equal(ds['myterrain-aspect'].data, xs.aspect(t).data)
+    np.testing.assert_allclose(ds['myterrain-slope'].data, orc.slope(data, 0.5, 0.5), rtol=RTOL, equal_nan=True)
+    none = raster(data)
+    none.name = None
+    with pytest.raises(NameError, match="Requires xr.DataArray.name property to be set"):
+        summarize_terrain(none)
+    if size == (2, 4) and dtype == np.float64:
+        spikes = np.zeros((5, 8))
+        spikes[2, 2], spikes[2, 5] = 1, -1
+        r = xs.DataArray(spikes, name='myraster', attrs={'res': (1, 1)})
+        out = summarize_terrain(r)
+        np.testing.assert_allclose(out['myraster-aspect'].data[1:4, 1:7],
+                                   [[315, 0, 45, 135, 180, 225], [270, -1, 90, 90, -1, 270], [225, 180, 135, 45, 0, 315]])
+        np.testing.assert_allclose(out['myraster-curvature'].data[2, 1:7], [-100, 400, -100, 100, -400, 100])
+        np.testing.assert_allclose(out['myraster-slope'].data[1, 1:4], [10.024988, 14.036243, 10.024988], rtol=1e-6)
+
+
 # ------------------------------------------------------------------ BASELINE full size (16384 x 16384)
 @pytest.fixture(scope="module")
 def dem16k():

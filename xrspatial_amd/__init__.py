@@ -25,6 +25,6 @@ from .slope import slope  # noqa: F401
 from .zonal import crosstab as zonal_crosstab  # noqa: F401
 from .zonal import stats as zonal_stats  # noqa: F401
 
-from . import convolution, focal, multispectral, zonal  # noqa: F401
+from . import analytics, convolution, focal, multispectral, zonal  # noqa: F401
 
 __version__ = "0.1.0"

@@ -120,7 +120,11 @@ except ImportError:
             return all(np.array_equal(_host(self.coords[k].data), _host(other.coords[k].data))
                        for k in self.coords)
 
-        def to_dataset(self, dim):
+        def to_dataset(self, dim=None):
+            if dim is None:                     # xarray: a one-variable Dataset named after the array
+                if self.name is None:
+                    raise ValueError("unable to convert unnamed DataArray to a Dataset without providing an explicit name")
+                return Dataset({self.name: self}, attrs=self.attrs)
             ax = self.dims.index(dim)
             labels = _host(self.coords[dim].data) if dim in self.coords else np.arange(self.shape[ax])
             rest = tuple(d for d in self.dims if d != dim)

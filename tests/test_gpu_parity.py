@@ -252,7 +252,7 @@ def test_kxk_vs_oracle(kname, shape):
     np.testing.assert_array_equal(apply(agg, k, _calc_sum).data, corc.focal_apply(z, k, 'sum'))
 
 
-@pytest.mark.parametrize("radius", range(4, 13))
+@pytest.mark.parametrize("radius", range(2, 13))
 def test_circular_masks_column_walker(radius):
     """Circles of radius 4..12 cells take the column-walker kernel for sum / max / min / range (kxk_circle.hip):
     bit-exact against the oracle's row-major float32 sum and its extrema, with NaN holes, +-inf, windows wider

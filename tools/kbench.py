@@ -99,6 +99,8 @@ def main():
     k5 = np.ascontiguousarray(circle_kernel(1, 1, 2))
     k3 = np.ones((3, 3))
     k25 = np.ascontiguousarray(circle_kernel(1, 1, 12))
+    k7 = np.ascontiguousarray(circle_kernel(1, 1, 3))
+    k13 = np.ascontiguousarray(circle_kernel(1, 1, 6))
     w5 = np.ascontiguousarray(k5 / k5.sum())
     work = xs.DeviceArray((1 << 16,), np.uint8)
     ptr1 = (ctypes.c_void_p * 7)()
@@ -166,6 +168,10 @@ def main():
         "focal5_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 8),
         "focal3_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 8),
         "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
+        "focal7_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 8),
+        "focal7_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 32),
+        "focal13_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k13.ctypes.data, 13, 13, None, 0, 0, S), 8),
+        "focal13_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k13.ctypes.data, 13, 13, None, 0, 0, S), 32),
         "focal25_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),
         "focal25_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 32),
         "focal25_sum": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 1 << 6, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 8),

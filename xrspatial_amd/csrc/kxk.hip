@@ -989,7 +989,7 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     }
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = as_stream(stream);
-    if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols > 49 && !getenv("XRS_FOCAL_MEAN_RUNS")) {
+    if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !getenv("XRS_FOCAL_MEAN_RUNS")) {
         // circles of radius 4..12 cells: column walker (running float64 sums over centred runs)
         const int rc = try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out,
                                                    kernel, krows, kcols, halo_top, halo_bot, s);

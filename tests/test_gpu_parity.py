@@ -252,14 +252,16 @@ def test_kxk_vs_oracle(kname, shape):
     np.testing.assert_array_equal(apply(agg, k, _calc_sum).data, corc.focal_apply(z, k, 'sum'))
 
 
+@pytest.mark.parametrize("shape_kind", ["circle", "box"])
 @pytest.mark.parametrize("radius", range(2, 13))
-def test_circular_masks_column_walker(radius):
-    """Circles of radius 4..12 cells take the column-walker kernel for sum / max / min / range (kxk_circle.hip):
-    bit-exact against the oracle's row-major float32 sum and its extrema, with NaN holes, +-inf, windows wider
-    than the raster, all-NaN windows, widths that are not multiples of 64, and row shards with halos."""
+def test_circular_masks_column_walker(radius, shape_kind):
+    """Circles and boxes of radius 2..12 cells take the column-walker kernels (kxk_circle*.hip, kxk_box*.hip):
+    sum / max / min / range bit-exact against the oracle's row-major float32 sum and its extrema, mean / var / std to
+    1e-6, with NaN holes, +-inf, windows wider than the raster, all-NaN windows, flat patches, widths that are not
+    multiples of 64, and row shards with halos."""
     from xrspatial_amd import _lib
-    k = circle_kernel(1, 1, radius)
     K = 2 * radius + 1
+    k = circle_kernel(1, 1, radius) if shape_kind == "circle" else np.ones((K, K))
     assert k.shape == (K, K)
     rng = np.random.default_rng(radius)
     for shape in ((150, 331), (K - 2, 70), (3 * K, K + 5)):

@@ -100,6 +100,7 @@ def main():
     k3 = np.ones((3, 3))
     k25 = np.ascontiguousarray(circle_kernel(1, 1, 12))
     k7 = np.ascontiguousarray(circle_kernel(1, 1, 3))
+    kb5, kb11 = np.ones((5, 5)), np.ones((11, 11))
     k13 = np.ascontiguousarray(circle_kernel(1, 1, 6))
     w5 = np.ascontiguousarray(k5 / k5.sum())
     work = xs.DeviceArray((1 << 16,), np.uint8)
@@ -168,6 +169,10 @@ def main():
         "focal5_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 8),
         "focal3_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 8),
         "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
+        "box3_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 32),
+        "box5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, kb5.ctypes.data, 5, 5, None, 0, 0, S), 32),
+        "box11_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, kb11.ctypes.data, 11, 11, None, 0, 0, S), 8),
+        "box11_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, kb11.ctypes.data, 11, 11, None, 0, 0, S), 32),
         "focal7_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 8),
         "focal7_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 32),
         "focal13_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k13.ctypes.data, 13, 13, None, 0, 0, S), 8),

@@ -1,5 +1,6 @@
-// Column-walker building blocks for circular focal masks (kxk_circle.hip: float32 sum / max / min / range;
-// kxk_circle64.hip: float64 mean / var / std; small radii run both in one kernel).
+// Column-walker building blocks for focal masks whose rows are centred runs -- circles and boxes
+// (walk_f32_impl.h -> kxk_circle.hip / kxk_box.hip: float32 sum / max / min / range; walk_f64_impl.h ->
+// kxk_circle64.hip / kxk_box64.hip: float64 mean / var / std; small radii run both in one kernel).
 //
 // A lane owns ONE column of a 256 x CTH tile and walks down its input rows.  Every input row y' is read once per
 // column (2R+1 neighbouring cells, L1 hits) and contributes to the 2R+1 output rows y' - dy that see it; their
@@ -17,25 +18,31 @@ namespace xrs {
 
 constexpr int CTH = 128;     // output rows per tile (input rows walked: CTH + 2R)
 
-// half-width of the circle's row dy: largest dx with dx^2 + dy^2 <= R^2 (the division-free test of
-// convolution.py:144 on square cells)
-constexpr int half_width(int R, int dy) {
-    int h = 0;
-    while ((h + 1) * (h + 1) + dy * dy <= R * R) ++h;
-    return h;
-}
+// Mask shapes the walkers are instantiated for: every row of the (2R+1)^2 mask is ONE run centred on the kernel's
+// centre column, with a compile-time half-width hw(R, |dy|).
+struct CircleShape {      // circle_kernel on square cells: largest dx with dx^2 + dy^2 <= R^2 (convolution.py:144)
+    static constexpr int hw(int R, int dy) {
+        int h = 0;
+        while ((h + 1) * (h + 1) + dy * dy <= R * R) ++h;
+        return h;
+    }
+};
+struct BoxShape {         // np.ones((2R+1, 2R+1))
+    static constexpr int hw(int R, int) { return R; }
+};
 
-constexpr int circle_taps(int R) {
+template <typename Shape>
+constexpr int shape_taps(int R) {
     int n = 0;
-    for (int dy = -R; dy <= R; ++dy) n += 2 * half_width(R, dy < 0 ? -dy : dy) + 1;
+    for (int dy = -R; dy <= R; ++dy) n += 2 * Shape::hw(R, dy < 0 ? -dy : dy) + 1;
     return n;
 }
 
-template <int R>
-inline bool is_circle(const double *kernel) {
+template <int R, typename Shape>
+inline bool is_shape(const double *kernel) {
     constexpr int K = 2 * R + 1;
     for (int ky = 0; ky < K; ++ky) {
-        const int dy = ky < R ? R - ky : ky - R, h = half_width(R, dy);
+        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy);
         for (int kx = 0; kx < K; ++kx) {
             const int dx = kx < R ? R - kx : kx - R;
             if ((kernel[ky * K + kx] == 1.0) != (dx <= h)) return false;
@@ -88,7 +95,7 @@ typedef float walk_v2f __attribute__((ext_vector_type(2)));
 //     per value (441 -> 233 instructions per cell).  NaN cells are added as +0.0 (exact: an accumulator that
 //     starts at +0.0 is never -0.0) and skipped by IEEE minNum / maxNum; a window without a valid cell gives sum 0
 //     and NaN for max / min / range, like the reference.
-template <int R, bool WANT_SUM, bool WANT_MM>
+template <int R, typename Shape, bool WANT_SUM, bool WANT_MM>
 struct WalkF32 {
     static constexpr int K = 2 * R + 1;
     walk_v2f sp[R > 0 ? R : 1];   // (slot j, slot 2R - j) for j < R; ring slot j = output row (input row) - (j - R)
@@ -115,7 +122,7 @@ struct WalkF32 {
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
                     const int dy = j - R;
-                    if (half_width(R, dy < 0 ? -dy : dy) == h) {
+                    if (Shape::hw(R, dy < 0 ? -dy : dy) == h) {
                         mn[j] = fminf(mn[j], lo);
                         mx[j] = fmaxf(mx[j], hi);
                     }
@@ -128,7 +135,7 @@ struct WalkF32 {
             for (int k = 0; k < K; ++k) z[k] = isnan(v[k]) ? 0.0f : v[k];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int h = half_width(R, R - j);
+                const int h = Shape::hw(R, R - j);
 #pragma unroll
                 for (int k = R - h; k <= R + h; ++k) sp[j] += (walk_v2f)(z[k]);
             }
@@ -185,7 +192,7 @@ __device__ __forceinline__ double walk_rcp(int n) {
     return n ? r : nan("");
 }
 
-template <int R, bool WANT_VAR = true>       // WANT_VAR = false: mean only (no squares, no guard)
+template <int R, typename Shape, bool WANT_VAR = true>       // WANT_VAR = false: mean only (no squares, no guard)
 struct WalkF64 {
     static constexpr int K = 2 * R + 1;
     double sd[K], sq[WANT_VAR ? K : 1];
@@ -227,7 +234,7 @@ struct WalkF64 {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int dy = j - R;
-                if (half_width(R, dy < 0 ? -dy : dy) == h) {
+                if (Shape::hw(R, dy < 0 ? -dy : dy) == h) {
                     sd[j] += S;
                     cn[j] += C;
                     if (WANT_VAR) sq[j] += Q;
@@ -253,7 +260,7 @@ struct WalkF64 {
         double mean = shift + ms;
         double var = (ssd > 0.0 ? ssd : 0.0) * inv;
         // rounding noise of Q and S^2/n is ~ ntaps * eps * max(d^2); 1e6 of headroom as in kxk_runs.hip
-        const double guard = 1e-9 * (double)circle_taps(R) * ((double)amax * (double)amax);
+        const double guard = 1e-9 * (double)shape_taps<Shape>(R) * ((double)amax * (double)amax);
         if (n != 0 && !(ssd >= guard)) {
             // ill-conditioned / exactly flat window, or +-inf under it: the reference's two-pass loops
             double s = 0.0;
@@ -261,7 +268,7 @@ struct WalkF64 {
             for (int ky = 0; ky < K; ++ky) {
                 const long yr = yo - R + ky;
                 if (yr < y_lo || yr >= y_hi) continue;
-                const int h = half_width(R, ky < R ? R - ky : ky - R);
+                const int h = Shape::hw(R, ky < R ? R - ky : ky - R);
                 for (int kx = R - h; kx <= R + h; ++kx) {
                     const long xr = x - R + kx;
                     if (xr < 0 || xr >= g.cols) continue;
@@ -274,7 +281,7 @@ struct WalkF64 {
             for (int ky = 0; ky < K; ++ky) {
                 const long yr = yo - R + ky;
                 if (yr < y_lo || yr >= y_hi) continue;
-                const int h = half_width(R, ky < R ? R - ky : ky - R);
+                const int h = Shape::hw(R, ky < R ? R - ky : ky - R);
                 for (int kx = R - h; kx <= R + h; ++kx) {
                     const long xr = x - R + kx;
                     if (xr < 0 || xr >= g.cols) continue;
@@ -306,7 +313,7 @@ struct WalkOuts {
 };
 
 // One kernel body for every combination: F32 = run the float32 statistics, F64 = run the moments.
-template <int R, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
+template <int R, typename Shape, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
 __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
     constexpr int K = 2 * R + 1;
     const long t = xcd_tile(blockIdx.x, g.n_tiles);
@@ -320,8 +327,8 @@ __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) 
     const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);        // output rows [y0, y_end)
     if (xw >= g.cols) return;
 
-    WalkF32<R, WANT_SUM, WANT_MM> a32;
-    WalkF64<R, WANT_VAR> a64;
+    WalkF32<R, Shape, WANT_SUM, WANT_MM> a32;
+    WalkF64<R, Shape, WANT_VAR> a64;
     if (F32) a32.init();
     if (F64) a64.init(g, y0, x);
     auto walk = [&](auto edge_tag) {

@@ -898,6 +898,27 @@ bool prefer_lds() {
     return e && strcmp(e, "lds") == 0;
 }
 
+// Column walkers (kxk_circle*.hip, kxk_box*.hip) for masks that are circles or boxes: -1 if neither.
+int try_walk_f32(const float *in, float *const *out, bool with_moments, long rows, long cols, long ld_in, long ld_out,
+                 const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
+    float *mean = with_moments ? out[XRS_STAT_MEAN] : nullptr, *var = with_moments ? out[XRS_STAT_VAR] : nullptr,
+          *sd = with_moments ? out[XRS_STAT_STD] : nullptr;
+    int rc = try_launch_focal_circle_f32(in, out[XRS_STAT_SUM], out[XRS_STAT_MAX], out[XRS_STAT_MIN], out[XRS_STAT_RANGE],
+                                         mean, var, sd, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+    if (rc < 0)
+        rc = try_launch_focal_box_f32(in, out[XRS_STAT_SUM], out[XRS_STAT_MAX], out[XRS_STAT_MIN], out[XRS_STAT_RANGE], mean,
+                                      var, sd, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+    return rc;
+}
+int try_walk_f64(const float *in, float *mean, float *var, float *sd, long rows, long cols, long ld_in, long ld_out,
+                 const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
+    int rc = try_launch_focal_circle_f64(in, mean, var, sd, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                                         halo_bot, s);
+    if (rc < 0)
+        rc = try_launch_focal_box_f64(in, mean, var, sd, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+    return rc;
+}
+
 // XRS_FOCAL_VARIANT=strip keeps small circular masks on the register-strip all-statistics kernel (A/B; default: walker)
 bool prefer_strip() {
     const char *e = getenv("XRS_FOCAL_VARIANT");
@@ -990,9 +1011,9 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = as_stream(stream);
     if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !getenv("XRS_FOCAL_MEAN_RUNS")) {
-        // circles of radius 4..12 cells: column walker (running float64 sums over centred runs)
-        const int rc = try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out,
-                                                   kernel, krows, kcols, halo_top, halo_bot, s);
+        // circles and boxes, 7x7 .. 25x25: column walker (running float64 sums over centred runs)
+        const int rc = try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,
+                                    krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols > 49) {
@@ -1026,8 +1047,8 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         const unsigned f64_stats = (1u << XRS_STAT_MEAN) | (1u << XRS_STAT_VAR) | (1u << XRS_STAT_STD);
         int rc = 0;
         if (stat_mask & f64_stats) {
-            rc = try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols,
-                                             ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            rc = try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out,
+                              kernel, krows, kcols, halo_top, halo_bot, s);
             if (rc > 0) return rc;
         }
         if ((stat_mask & f64_stats) && rc < 0)
@@ -1036,10 +1057,9 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         if (rc > 0) return rc;
         if (rc == 0) {
             if (!(stat_mask & ~f64_stats)) return 0;
-            // circles of radius 4..12 cells: column walker (kxk_circle.hip); any other run-structured mask: tap walk
-            const int rc2 = try_launch_focal_circle_f32(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN],
-                                                        a.out[XRS_STAT_RANGE], nullptr, nullptr, nullptr, rows, cols,
-                                                        ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            // circles and boxes: column walker (kxk_circle.hip / kxk_box.hip); any other run-structured mask: tap walk
+            const int rc2 = try_walk_f32(in_dev, a.out, false, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                                         halo_bot, s);
             if (rc2 >= 0) return rc2;
             const bool want_sum = stat_mask >> XRS_STAT_SUM & 1;
             const bool want_mm = stat_mask & ((1u << XRS_STAT_MAX) | (1u << XRS_STAT_MIN) | (1u << XRS_STAT_RANGE));
@@ -1049,16 +1069,13 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         }
     }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
-    if ((krows == 5 || krows == 7) && krows == kcols && !prefer_strip()) {
-        // small circles (circle_kernel radius 2, 3): all requested statistics from one column-walker kernel
+    if (krows <= 7 && krows == kcols && (krows >= 5 || getenv("XRS_FOCAL_WALK3")) && !prefer_strip()) {
+        // small circles / boxes (5x5, 7x7): all requested statistics from one column-walker kernel
         const bool f32_stats = a.out[XRS_STAT_SUM] || a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
         const int rc = f32_stats
-            ? try_launch_focal_circle_f32(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN],
-                                          a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR],
-                                          a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols,
-                                          halo_top, halo_bot, s)
-            : try_launch_focal_circle_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows,
-                                          cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            ? try_walk_f32(in_dev, a.out, true, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s)
+            : try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in,
+                           ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     // the all-statistics kernel always produces the mean internally; give it somewhere to go

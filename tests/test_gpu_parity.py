@@ -287,19 +287,22 @@ def test_circular_masks_column_walker(radius, shape_kind):
         np.testing.assert_array_equal(focal_stats(raster(z), k, stats_funcs=['min', 'range']).data, got.data[[2, 3]])
     # row shard with halo rows: rows [50, 110) of the first raster, halos in the same allocation
     z = synth.smooth_dem((150, 320), nan_frac=0.01, seed=radius + 100)
-    want = {s: corc.focal_apply(z, k, s, nthreads=8) for s in ('sum', 'max')}
+    want = {s: corc.focal_apply(z, k, s, nthreads=8) for s in ('sum', 'max', 'mean', 'var')}
     full = xs.DeviceArray.from_numpy(z)
     import ctypes
     for first, n, ht, hb in ((50, 60, radius, radius), (0, 40, 0, radius), (110, 40, radius, 0)):
         o_sum, o_max = xs.DeviceArray((n, 320), np.float32), xs.DeviceArray((n, 320), np.float32)
+        o_mean, o_var = xs.DeviceArray((n, 320), np.float32), xs.DeviceArray((n, 320), np.float32)
         ptrs = (ctypes.c_void_p * 7)()
-        ptrs[6], ptrs[1] = o_sum.ptr, o_max.ptr
+        ptrs[6], ptrs[1], ptrs[0], ptrs[5] = o_sum.ptr, o_max.ptr, o_mean.ptr, o_var.ptr
         kk = np.ascontiguousarray(k, dtype=np.float64)
-        _lib.call("xrs_focal_stats_f32", full.ptr + first * 320 * 4, ptrs, (1 << 6) | (1 << 1), n, 320, 320, 320,
-                  kk.ctypes.data, K, K, None, ht, hb, None)
+        _lib.call("xrs_focal_stats_f32", full.ptr + first * 320 * 4, ptrs, (1 << 6) | (1 << 1) | 1 | (1 << 5), n, 320, 320,
+                  320, kk.ctypes.data, K, K, None, ht, hb, None)
         _lib.call("xrs_stream_sync", None)
         np.testing.assert_array_equal(o_sum.get(), want['sum'][first:first + n])
         np.testing.assert_array_equal(o_max.get(), want['max'][first:first + n])
+        np.testing.assert_allclose(o_mean.get(), want['mean'][first:first + n], rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(o_var.get(), want['var'][first:first + n], rtol=1e-6, equal_nan=True)
     # a mask of the same size that is NOT the circle keeps the general walk (and its results)
     k2 = k.copy()
     k2[0, 0] = 1.0

@@ -339,6 +339,41 @@ def test_flat_windows_have_exactly_zero_variance():
                                        equal_nan=True, err_msg=f"{name} {stat}")
 
 
+@pytest.mark.parametrize("shape_kind", ["circle", "box"])
+@pytest.mark.parametrize("radius", [3, 4, 7, 12])
+def test_uniform_weight_convolution_column_walker(radius, shape_kind):
+    """convolve_2d with one weight value on a circle / box (normalised circle_kernel, np.ones / k^2 -- what
+    focal.hotspots is fed) takes the column-walker kernel: NaN border of R cells, NaN / inf anywhere in the SQUARE
+    window poisons the result exactly as the reference's `num += kernel * data` over every kernel cell does."""
+    K = 2 * radius + 1
+    mask = circle_kernel(1, 1, radius) if shape_kind == "circle" else np.ones((K, K))
+    k = mask / mask.sum()
+    for shape in ((140, 300), (K + 3, 2 * K + 70), (K - 1, 90)):
+        z = synth.smooth_dem(shape, nan_frac=0.0005, seed=radius)
+        if shape[0] > 100:
+            z[60, 150] = np.inf
+            z[100, 40] = -np.inf
+        with np.errstate(all='ignore'):
+            want = corc.convolve_2d(z, k, nthreads=8)
+        got = convolve_2d(z, k)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True, err_msg=str(shape))
+        dev = convolve_2d(xs.DeviceArray.from_numpy(z), k)
+        np.testing.assert_array_equal(dev.get(), got)
+    # other weights on the same footprint keep the tap kernel
+    k2 = k.copy()
+    k2[radius, radius] *= 2
+    z = synth.smooth_dem((60, 200))
+    np.testing.assert_allclose(convolve_2d(z, k2), corc.convolve_2d(z, k2, nthreads=8), rtol=1e-6, equal_nan=True)
+    # hotspots on top of it
+    if radius == 4:
+        from xrspatial_amd.focal import hotspots
+        zz = synth.smooth_dem((120, 260), nan_frac=0.001)
+        got_h = hotspots(raster(zz), mask).data
+        want_h = orc.hotspots(zz, mask)[0]
+        assert (got_h != want_h).mean() < 1e-4            # z-scores on a class boundary may round either way
+
+
 def test_focal_runs_kernel_inf_and_nan_tiles():
     # the prefix-sum kernel: a tile with +-inf takes its direct fallback, NaN tiles count taps
     z = synth.smooth_dem((90, 300), nan_frac=0.03)

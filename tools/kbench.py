@@ -103,6 +103,9 @@ def main():
     kb5, kb11 = np.ones((5, 5)), np.ones((11, 11))
     k13 = np.ascontiguousarray(circle_kernel(1, 1, 6))
     w5 = np.ascontiguousarray(k5 / k5.sum())
+    w25 = np.ascontiguousarray(k25 / k25.sum())
+    k9 = circle_kernel(1, 1, 4)
+    w9 = np.ascontiguousarray(k9 / k9.sum())
     work = xs.DeviceArray((1 << 16,), np.uint8)
     ptr1 = (ctypes.c_void_p * 7)()
     ptr1[0] = outs[0].ptr
@@ -183,6 +186,8 @@ def main():
         "focal25_minmaxrange": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 0b1110, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 16),
         "focal25_meanvarstd": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 0b110001, n, n, n, n, k25.ctypes.data, 25, 25, None, 0, 0, S), 16),
         "convolve5": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w5.ctypes.data, 5, 5, work.ptr, 0, 0, S), 8),
+        "convolve25_circle": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w25.ctypes.data, 25, 25, work.ptr, 0, 0, S), 8),
+        "convolve9_circle": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, w9.ctypes.data, 9, 9, work.ptr, 0, 0, S), 8),
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
         "zonal_1000_scattered": (zonal_scatter, 8),

@@ -308,6 +308,128 @@ struct WalkF64 {
     }
 };
 
+// ---- convolve_2d with ONE weight value on a circle / box (the normalised kernels focal.hotspots and the reference's
+// examples use: circle_kernel / np.ones divided by their sum).  Reference _convolve_2d_numpy (convolution.py:285-313):
+// float64 `num += kernel[k, h] * data[..]` over the WHOLE (2R+1)^2 window (zero weights included, so a NaN or inf
+// anywhere in the square makes the result NaN), NaN border of R cells, float32 store.  Here: w * (ntaps * c + S) with S
+// the walker's float64 sum of shifted values under the mask; windows whose square holds a non-finite cell (counted
+// with a running row total) are recomputed tap by tap in the reference's order.
+template <int R, typename Shape>
+struct WalkConv {
+    static constexpr int K = 2 * R + 1;
+    double sd[K];
+    int bad_at[K];                // running non-finite total when the slot was opened
+    int bad_total;
+    float cf;
+
+    __device__ __forceinline__ void init(const WalkGeom &g, long y0, long x) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { sd[j] = 0.0; bad_at[j] = 0; }
+        bad_total = 0;
+        cf = 0.0f;
+        const long yc = (y0 + CTH / 2 < g.rows ? y0 + CTH / 2 : g.rows - 1);
+        if (x < g.cols) {
+            const float c0 = g.in[yc * g.ld_in + x];
+            if (isfinite(c0)) cf = c0;
+        }
+    }
+
+    __device__ __forceinline__ void row(const float (&v)[K]) {
+        const double shift = (double)cf;
+        double S = 0.0;
+        int nbad = 0;
+#pragma unroll
+        for (int h = 0; h <= R; ++h) {
+#pragma unroll
+            for (int side = 0; side < (h == 0 ? 1 : 2); ++side) {
+                const float val = v[side == 0 ? R - h : R + h];
+                const bool ok = isfinite(val);
+                S += ok ? (double)val - shift : 0.0;
+                nbad += ok ? 0 : 1;
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int dy = j - R;
+                if (Shape::hw(R, dy < 0 ? -dy : dy) == h) sd[j] += S;
+            }
+        }
+        bad_total += nbad;            // the whole row segment x-R .. x+R belongs to every window that sees this row
+    }
+
+    // completed output row yo (slot 2R), column x; `weights`: the (2R+1)^2 float64 kernel in device memory
+    __device__ __forceinline__ void emit(const WalkGeom &g, long yo, long x, float *out, double w,
+                                         const double *weights) const {
+        const long y_lo = -(long)g.halo_top, y_hi = g.rows + g.halo_bot;
+        float res = nan_f32();
+        if (yo - R >= y_lo && yo + R < y_hi && x - R >= 0 && x + R < g.cols) {
+            if (bad_total - bad_at[2 * R] == 0) {
+                res = (float)(w * ((double)shape_taps<Shape>(R) * (double)cf + sd[2 * R]));
+            } else {
+                double num = 0.0;                                       // the reference's loop, zero weights included
+                for (int ky = 0; ky < K; ++ky)
+                    for (int kx = 0; kx < K; ++kx)
+                        num += weights[ky * K + kx] * (double)g.in[(yo - R + ky) * g.ld_in + (x - R + kx)];
+                res = (float)num;
+            }
+        }
+        out[yo * g.ld_out + x] = res;
+    }
+
+    __device__ __forceinline__ void shift() {
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) { sd[j] = sd[j - 1]; bad_at[j] = bad_at[j - 1]; }
+        sd[0] = 0.0;
+        bad_at[0] = bad_total;
+    }
+};
+
+template <int R, typename Shape>
+__device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, double w, const double *weights) {
+    constexpr int K = 2 * R + 1;
+    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    if (t < 0) return;
+    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long xw = tx * 256 + wv * 64;
+    const long x = xw + lane;
+    const long y0 = ty * CTH;
+    const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);
+    if (xw >= g.cols) return;
+    WalkConv<R, Shape> c;
+    c.init(g, y0, x);
+    auto walk = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        for (long yy = y0 - R; yy < y_end + R; ++yy) {
+            float v[K];
+            walk_load_row<R, EDGE>(g, yy, xw, lane, v);
+            c.row(v);
+            const long yo = yy - R;
+            if (yo >= y0 && (!EDGE || x < g.cols)) c.emit(g, yo, x, out, w, weights);
+            c.shift();
+        }
+    };
+    if (xw >= R && xw + 64 + R <= g.cols) walk(std::false_type{});
+    else walk(std::true_type{});
+}
+
+// host: does `kernel` put ONE weight value on exactly the cells of the shape (zero elsewhere)?
+template <int R, typename Shape>
+inline bool is_uniform_shape(const double *kernel, double *weight) {
+    constexpr int K = 2 * R + 1;
+    const double w = kernel[R * K + R];
+    if (!(w != 0.0) || !std::isfinite(w)) return false;
+    for (int ky = 0; ky < K; ++ky) {
+        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy);
+        for (int kx = 0; kx < K; ++kx) {
+            const int dx = kx < R ? R - kx : kx - R;
+            if (kernel[ky * K + kx] != (dx <= h ? w : 0.0)) return false;
+        }
+    }
+    *weight = w;
+    return true;
+}
+
 struct WalkOuts {
     float *sum, *max, *min, *range, *mean, *var, *std;      // any may be NULL
 };

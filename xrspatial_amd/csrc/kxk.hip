@@ -972,6 +972,15 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     hipStream_t s = as_stream(stream);
     XRS_HIP(hipMemcpyAsync(work_dev, kernel, (size_t)krows * kcols * sizeof(double), hipMemcpyHostToDevice, s));
     a.weights = static_cast<const double *>(work_dev);
+    if (krows >= 7 && !getenv("XRS_CONV_TAPS")) {
+        // one weight value on a circle / box (normalised circle_kernel, np.ones / k^2): column walker
+        int rc = try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top,
+                                        halo_bot, s);
+        if (rc < 0)
+            rc = try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top,
+                                     halo_bot, s);
+        if (rc >= 0) return rc;
+    }
     a.tiles_x = (cols + TW - 1) / TW;
     a.n_tiles = a.tiles_x * ((rows + a.th - 1) / a.th);
     const unsigned grid = (unsigned)xcd_grid(a.n_tiles);

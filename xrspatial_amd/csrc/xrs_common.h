@@ -81,6 +81,11 @@ int try_launch_focal_box_f32(const float *in, float *out_sum, float *out_max, fl
                              float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in,
                              long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
                              hipStream_t s);      // kxk_box.hip: the same for np.ones((k, k)) masks
+// kxk_circle_conv.hip / kxk_box_conv.hip: convolve_2d with one weight value on a circle / box of radius 3..12 cells
+int try_launch_conv_circle(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
+                           const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_conv_box(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
+                        const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 // kxk_circle64.hip / kxk_box64.hip: mean / var / std for the same shapes (float64 moments of shifted values, guarded).
 int try_launch_focal_box_f64(const float *in, float *out_mean, float *out_var, float *out_std, long rows, long cols,
                              long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,

@@ -208,6 +208,18 @@ int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev,
                            int n_zones, float nodata, int has_nodata,
                            uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                            float *min_dev, float *max_dev, void *stream);
+/* Same reduction straight from the RAW int32 zone raster: `lut_dev[id - zone_min]` (zone_range entries, built from
+ * xrs_zonal_scan / xrs_zonal_presence) gives the dense index of an id, -1 for ids that are not a zone; ids outside the
+ * window belong to no zone.  Saves materialising the dense index raster (4 B written + 4 B read per cell) when only
+ * the partial-sum statistics are wanted (np.unique(zones) + per-zone masks in the reference, zonal.py:290-311). */
+int xrs_zonal_partials_lut_f32(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
+                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata,
+                               uint64_t *count_dev, double *sum_dev, double *sumsq_dev, float *min_dev, float *max_dev,
+                               void *stream);
+int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
+                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata,
+                               uint64_t *count_dev, double *sum_dev, double *sumsq_dev, double *min_dev, double *max_dev,
+                               void *stream);
 /* float64 values (the reference does not cast `values`: float64 and integer rasters keep
  * their precision; integers are widened to float64 by the host layer).  min/max are float64. */
 int xrs_zonal_init_f64(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,

@@ -28,7 +28,9 @@ namespace {
 
 template <typename VT>
 struct ZonalArgs {
-    const int32_t *zidx;
+    const int32_t *zidx;          // dense zone indices -- or raw int32 zone ids when `lut` is set
+    const int32_t *lut;           // optional: raw id -> dense index table over [zmin, zmin + rng), -1 = not a zone
+    int zmin, rng;
     const VT *vals;
     long n;
     int nz;
@@ -81,6 +83,13 @@ struct Part {            // a partial reduction for ONE zone
     double s, q;
     VT mn, mx;
 };
+
+// raw zone id -> dense index through the (L1-resident) table; ids outside the table's window belong to no zone
+template <typename VT>
+__device__ __forceinline__ int zone_of(const ZonalArgs<VT> &a, int raw) {
+    const unsigned off = (unsigned)(raw - a.zmin);          // (wraps for raw < zmin: then >= rng)
+    return off < (unsigned)a.rng ? a.lut[off] : -1;
+}
 
 template <typename VT>
 __device__ __forceinline__ bool cell_ok(const ZonalArgs<VT> &a, int z, VT v) {
@@ -154,6 +163,10 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
             if (i < c_end) {
                 const int4 zi = reinterpret_cast<const int4 *>(a.zidx)[i];
                 z[4 * u] = zi.x; z[4 * u + 1] = zi.y; z[4 * u + 2] = zi.z; z[4 * u + 3] = zi.w;
+                if (a.lut) {                                            // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) z[4 * u + k] = zone_of(a, z[4 * u + k]);
+                }
                 if constexpr (sizeof(VT) == 4) {
                     const float4 vf = reinterpret_cast<const float4 *>(a.vals)[i];
                     v[4 * u] = vf.x; v[4 * u + 1] = vf.y; v[4 * u + 2] = vf.z; v[4 * u + 3] = vf.w;
@@ -204,7 +217,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
 
     // scalar tail (n % 4 cells, or everything when the buffers are not 16-byte aligned)
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
-        const int z = a.zidx[i];
+        const int z = a.lut ? zone_of(a, a.zidx[i]) : a.zidx[i];
         const VT v = a.vals[i];
         if (cell_ok(a, z, v)) {
             Part<VT> p; p.z = z; p.c = 1; p.s = (double)v; p.q = (double)v * (double)v; p.mn = v; p.mx = v;
@@ -250,13 +263,15 @@ int zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_
 template <typename VT>
 int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n, int n_zones, VT nodata,
                    int has_nodata, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev,
-                   VT *max_dev, void *stream) {
+                   VT *max_dev, void *stream, const int32_t *lut_dev = nullptr, int zmin = 0, int rng = 0) {
     if (n < 0 || n_zones < 0) return fail("xrs_zonal_partials: negative size");
     if (n == 0 || n_zones == 0) return 0;
     if (!zone_idx_dev || !values_dev || !count_dev || !sum_dev || !sumsq_dev || !min_dev || !max_dev)
         return fail("xrs_zonal_partials: null pointer");
     ZonalArgs<VT> a;
     a.zidx = zone_idx_dev; a.vals = values_dev; a.n = n; a.nz = n_zones;
+    a.lut = lut_dev; a.zmin = zmin; a.rng = rng;
+    if (lut_dev && rng <= 0) return fail("xrs_zonal_partials_lut: empty id window");
     a.nodata = nodata; a.has_nodata = has_nodata;
     a.count = reinterpret_cast<unsigned long long *>(count_dev);
     a.sum = sum_dev; a.sumsq = sumsq_dev; a.mn = min_dev; a.mx = max_dev;
@@ -302,6 +317,23 @@ int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev
                            double *sumsq_dev, double *min_dev, double *max_dev, void *stream) {
     return zonal_partials<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev,
                                   sumsq_dev, min_dev, max_dev, stream);
+}
+
+int xrs_zonal_partials_lut_f32(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
+                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata,
+                               uint64_t *count_dev, double *sum_dev, double *sumsq_dev, float *min_dev, float *max_dev,
+                               void *stream) {
+    if (!lut_dev) return fail("xrs_zonal_partials_lut_f32: null table");
+    return zonal_partials<float>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev, sumsq_dev,
+                                 min_dev, max_dev, stream, lut_dev, zone_min, zone_range);
+}
+int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
+                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata,
+                               uint64_t *count_dev, double *sum_dev, double *sumsq_dev, double *min_dev, double *max_dev,
+                               void *stream) {
+    if (!lut_dev) return fail("xrs_zonal_partials_lut_f64: null table");
+    return zonal_partials<double>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev, sumsq_dev,
+                                  min_dev, max_dev, stream, lut_dev, zone_min, zone_range);
 }
 
 }  // extern "C"

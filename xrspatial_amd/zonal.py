@@ -61,6 +61,31 @@ def _dense_zone_index(zones: np.ndarray):
 _ZONE_DTYPE_CODE = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
 
 
+def _zone_table_device(zones_dev: DeviceArray):
+    """(unique ids, zmin, range, int32 DeviceArray table id - zmin -> dense index) for an integral zone raster in
+    HBM, without touching the raster on the host; None if the ids are not integral / too spread out / all invalid."""
+    code = _ZONE_DTYPE_CODE.get(zones_dev.dtype)
+    if code is None:
+        return None
+    stream = get_stream()
+    n = zones_dev.size
+    res = DeviceArray((4,), np.float64)
+    _lib.call("xrs_zonal_scan", zones_dev.ptr, code, n, res.ptr, stream)
+    raw = res.get(stream)
+    zmin, zmax = raw[0], raw[1]
+    n_finite = int(raw[2:3].view(np.uint64)[0])
+    all_integral = int(raw[3:4].view(np.int32)[0])
+    if n_finite == 0 or not all_integral or zmax - zmin >= _DENSE_RANGE_LIMIT:
+        return None
+    rng = int(zmax - zmin) + 1
+    present = DeviceArray((rng,), np.uint8)
+    _lib.call("xrs_zonal_presence", zones_dev.ptr, code, n, float(zmin), rng, present.ptr, stream)
+    mask = present.get(stream).astype(bool)
+    lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
+    uniq = (np.flatnonzero(mask).astype(np.float64) + zmin).astype(zones_dev.dtype)
+    return uniq, zmin, rng, DeviceArray.from_numpy(lut)
+
+
 def _dense_zone_index_device(zones_dev: DeviceArray):
     """Device-side counterpart of `_dense_zone_index` for zone rasters already in HBM: returns
     (unique ids as a host array of the zones dtype, int32 DeviceArray of dense indices), or None when
@@ -104,11 +129,13 @@ def _stage(zone_idx, values):
     return zdev, vdev
 
 
-def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
+def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, table=None):
     """Per-zone (count, sum, sumsq, min, max) NumPy arrays for dense `zone_idx` (device or host arrays).
 
     `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
-    all-reduced over it so every rank returns the global result."""
+    all-reduced over it so every rank returns the global result.
+    `table`: (zmin, range, lut DeviceArray) -- `zone_idx` then holds RAW int32 zone ids that the kernel maps through
+    the table itself (no dense index raster is materialised)."""
     _lib.require_device()
     stream = get_stream()
     zdev, vdev = _stage(zone_idx, values)
@@ -123,8 +150,14 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None):
     _lib.call("xrs_zonal_init" + sfx, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, n_zones, stream)
     has_nodata = nodata_values is not None
     nodata = float(nodata_values) if has_nodata else 0.0
-    _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
-              n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
+    if table is not None:
+        zmin, rng, lut_dev = table
+        _lib.call("xrs_zonal_partials_lut_f64" if f64 else "xrs_zonal_partials_lut_f32", zdev.ptr, int(zmin), int(rng),
+                  lut_dev.ptr, vdev.ptr, vdev.size, n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr,
+                  mx.ptr, stream)
+    else:
+        _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
+                  n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
     if comm is not None:
         _lib.call("xrs_zonal_allreduce", comm.handle, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, int(f64),
                   n_zones, stream)
@@ -169,6 +202,30 @@ def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None):
 def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, return_type, comm=None):
     like_numpy = not isinstance(values_data, DeviceArray)
     mapped = None
+    small_int = zones_data.dtype in (np.int32, np.int16, np.int8, np.uint16, np.uint8)
+    if (small_int and return_type == 'pandas.DataFrame' and 'majority' not in stat_names and int(zones_data.size) > 0
+            and (isinstance(zones_data, np.ndarray) or zones_data.dtype == np.int32)):
+        # integer zones (<= 32 bit), partial-sum statistics only: the raw ids go to HBM as they are and the reduction
+        # kernel maps them through a small table itself -- no pass over the raster on the host and no dense index
+        # raster (4 B written + 4 B read per cell) on the device
+        _lib.require_device()
+        if isinstance(zones_data, np.ndarray):
+            zones_data = DeviceArray.from_numpy(np.ascontiguousarray(zones_data, dtype=np.int32))
+        tab = _zone_table_device(zones_data)
+        if tab is not None:
+            unique_zones, zmin, rng, lut_dev = tab
+            nz = len(unique_zones)
+            _, vdev = _stage(zones_data, values_data)
+            count, s1, s2, mn, mx = zonal_partials(zones_data, vdev, nz, nodata_values, comm, table=(zmin, rng, lut_dev))
+            cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None)
+            if zone_ids is None:
+                keep = np.arange(nz)
+            else:
+                keep = np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
+            frame = {'zone': unique_zones[keep]}
+            for name in stat_names:
+                frame[name] = cols[name][keep]
+            return pd.DataFrame(frame)
     if isinstance(zones_data, DeviceArray):
         _lib.require_device()
         mapped = _dense_zone_index_device(zones_data)           # stays in HBM when ids are integral

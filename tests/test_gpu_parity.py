@@ -905,6 +905,40 @@ def test_full_size_bands_match_oracle(dem16k):
                                        err_msg=f"{name} band {y0}")
 
 
+def test_full_size_fused_pass_and_large_masks(dem16k):
+    """BASELINE headline / configs[2] at full size: the fused raster pass (bench.py's step) and the 25x25 circular
+    focal statistics on the 16384^2 raster, checked against the C oracle on bands (top edge, interior, bottom edge)."""
+    n, dev, bands = dem16k
+    agg = xs.DataArray(dev, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+    k5, k25 = circle_kernel(1, 1, 2), circle_kernel(1, 1, 12)
+    with xs.fuse() as scope:
+        shade, smooth, steep = xs.hillshade(agg), apply(agg, k5), xs.slope(agg)
+    assert scope.launches == 1
+    stats25 = focal_stats(agg, k25)                               # all seven: column-walker kernels
+    names = list(host(stats25['stats'].data))
+    R, B = 12, 160                                                # oracle rows per band (25x25 x 7 stats is slow on a CPU)
+    for y0, band in bands.items():
+        first, last = y0 == 0, y0 + 2048 == n
+        sub = band[:B + 2 * R] if not last else band[-(B + 2 * R):]
+        off = y0 if not last else n - (B + 2 * R)
+        lo, hi = (0 if first else R), (B + 2 * R if last else B + R)     # rows whose windows the sub-band fully holds
+        rows = slice(off + lo, off + hi)
+        np.testing.assert_array_equal(shade.data.rows(rows.start, rows.stop).get()[1:-1],
+                                      xs.hillshade(xs.DataArray(dev.rows(rows.start, rows.stop))).data.get()[1:-1])
+        np.testing.assert_allclose(smooth.data.rows(rows.start, rows.stop).get(),
+                                   corc.focal_apply(sub, k5, 'mean', nthreads=8)[lo:hi], rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(steep.data.rows(rows.start, rows.stop).get()[1:-1],
+                                   corc.slope(sub, 1.0, 1.0, nthreads=8)[lo:hi][1:-1], rtol=RTOL, equal_nan=True)
+        for i, stat in enumerate(names):
+            want = corc.focal_apply(sub, k25, stat, nthreads=8)[lo:hi]
+            got = xs.DeviceArray((hi - lo, n), np.float32, _ptr=stats25.data.ptr + (i * n + rows.start) * n * 4,
+                                 _base=stats25.data).get()
+            if stat in ('sum', 'max', 'min', 'range'):
+                np.testing.assert_array_equal(got, want, err_msg=f"{stat} band {y0}")
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{stat} band {y0}")
+
+
 def test_full_size_properties(dem16k):
     """Size-independent properties on the full 16384^2 raster."""
     n, dev, _ = dem16k

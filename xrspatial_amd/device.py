@@ -62,13 +62,14 @@ def _raw_free(ptr: int, nbytes: int):
 
 def empty_cache():
     """Return every cached device buffer to the driver and drop the recycled host blocks."""
-    global _pool_bytes, _host_pool_bytes, _pinned_pool_bytes
+    global _pool_bytes, _host_pool_bytes, _pinned_pool_bytes, _pinned_total_bytes
     with _host_lock:
         _host_pool.clear()
         _host_pool_bytes = 0
-        for lst in _pinned_pool.values():
+        for nb, lst in _pinned_pool.items():
             for ptr in lst:
                 _lib.load().xrs_host_free(ptr)
+                _pinned_total_bytes -= nb
         _pinned_pool.clear()
         _pinned_pool_bytes = 0
     with _pool_lock:
@@ -90,6 +91,8 @@ _HOST_POOL_MIN_BLOCK = 1 << 20          # smaller results: plain np.empty
 _pinned_pool = {}                        # nbytes -> [host pointers from xrs_host_alloc]
 _pinned_pool_bytes = 0
 _PINNED_POOL_MAX_BYTES = int(os.environ.get("XRS_PINNED_POOL_MAX_BYTES", 8 << 30))
+_pinned_total_bytes = 0                  # every page-locked byte this process holds (results in use + free list)
+_PINNED_TOTAL_MAX_BYTES = int(os.environ.get("XRS_PINNED_TOTAL_MAX_BYTES", 32 << 30))   # beyond: pageable blocks
 
 
 class _HostBlock:
@@ -111,7 +114,7 @@ class _HostBlock:
         return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
 
     def __del__(self):
-        global _host_pool_bytes, _pinned_pool_bytes
+        global _host_pool_bytes, _pinned_pool_bytes, _pinned_total_bytes
         try:
             if self.raw is not None:
                 raw = self.raw
@@ -125,6 +128,7 @@ class _HostBlock:
                     _pinned_pool.setdefault(self.nbytes, []).append(self.ptr)
                     _pinned_pool_bytes += self.nbytes
                     return
+                _pinned_total_bytes -= self.nbytes
             _lib.load().xrs_host_free(self.ptr)
         except Exception:                  # interpreter shutdown
             pass
@@ -133,7 +137,7 @@ class _HostBlock:
 def host_empty(shape, dtype, pinned: bool = False) -> np.ndarray:
     """Like np.empty, but large arrays come from the recycled-block pools (contents undefined).
     `pinned`: page-locked memory (falls back to pageable if the driver refuses the allocation)."""
-    global _host_pool_bytes, _pinned_pool_bytes
+    global _host_pool_bytes, _pinned_pool_bytes, _pinned_total_bytes
     dtype = np.dtype(dtype)
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
@@ -146,11 +150,13 @@ def host_empty(shape, dtype, pinned: bool = False) -> np.ndarray:
             if lst:
                 ptr = lst.pop()
                 _pinned_pool_bytes -= nbytes
-        if not ptr:
+        if not ptr and _pinned_total_bytes + nbytes <= _PINNED_TOTAL_MAX_BYTES:
             p = ctypes.c_void_p()
             try:
                 _lib.call("xrs_host_alloc", ctypes.byref(p), nbytes)
                 ptr = p.value
+                with _host_lock:
+                    _pinned_total_bytes += nbytes
             except _lib.XrsError:
                 ptr = 0
         if ptr:

@@ -1295,6 +1295,21 @@ def test_unaligned_device_views():
     np.testing.assert_allclose(got['sum'].to_numpy(), want['sum'], rtol=RTOL)
 
 
+def test_slope_of_tiny_and_huge_gradients():
+    """slope's square root: gradients whose squares are tiny, ordinary, and near the float32 maximum.  (Squares below
+    the float32 normal range -- elevations around 1e-20 -- are flushed to zero by the GPU's float32 mode, where NumPy
+    keeps denormals: not a case the parity bar covers.)"""
+    rng = np.random.default_rng(17)
+    for scale in (1e-17, 1e-8, 1.0, 1e15, 1e18):
+        z = (rng.random((40, 260)) * scale).astype(np.float32)
+        z[10:20, 50:90] = z[10, 50]                       # exactly flat patch: slope exactly 0
+        got = xs.slope(raster(z, res=(1.0, 1.0))).data
+        with np.errstate(all='ignore'):
+            want = orc.slope(z, 1.0, 1.0)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=0, equal_nan=True, err_msg=str(scale))
+        assert (got[12:18, 52:88] == 0).all()
+
+
 def test_terrain_with_infinite_cells():
     """+-inf cells in the DEM: every terrain operator follows the reference's arithmetic through inf / NaN."""
     z = synth.smooth_dem((40, 256))

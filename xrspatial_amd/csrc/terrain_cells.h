@@ -22,7 +22,12 @@ __device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double i
     const double dy = ((((double)q.nw + 2.0 * (double)q.n) + (double)q.ne) -
                        (((double)q.sw + 2.0 * (double)q.s) + (double)q.se)) * inv8cy;
     const float fx = (float)dx, fy = (float)dy;
-    return atanf(sqrtf(fx * fx + fy * fy)) * 57.29578f;
+    // Hardware square root (v_sqrt_f32, <= 1 ulp: 6e-8 relative against a 1e-5 parity bar) instead of the correctly
+    // rounded library sequence: the kernel is VALU-bound.  v_sqrt_f32 flushes denormal inputs, so the argument is
+    // scaled by 2^64 (exact) and the root by 2^-32: squares down to the smallest denormal stay exact, and squares
+    // above 2^64 (gradient > 4e9, where the slope already rounds to 90 degrees from 1.5e7 on) become inf -> 90.
+    const float r = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) * 0x1p64f) * 0x1p-32f;
+    return atanf(r) * 57.29578f;
 }
 
 __device__ __forceinline__ float aspect_cell(const Nb &q) {

@@ -230,6 +230,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
+    exchange_ms = overlap.last_exchange_ms() if overlap is not None else None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -381,6 +382,7 @@ def main():
             "sharding": "rows" if world > 1 else "none",
             "halo_exchange": halo_via,
             "halo_check": halo_check,
+            "halo_exchange_ms_last_step": None if exchange_ms is None else round(exchange_ms, 4),
             "kernel_ms": kernel_ms,
             **extra,
         },

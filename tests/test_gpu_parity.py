@@ -721,6 +721,7 @@ def test_overlapped_halo_split_equals_monolithic():
         for _ in range(3):
             ov.step(exchange, launch, ht, hb)
         _lib.call("xrs_stream_sync", main)
+        assert 0.0 <= ov.last_exchange_ms() < 50.0
         ov.close()
         for s, arr in outs.items():
             np.testing.assert_array_equal(arr.get(), ref[s][b:e], err_msg=f"rank {rank} {s}")

@@ -112,9 +112,10 @@ class OverlappedHalo:
         self.rows, self.halo, self.edge, self.main = int(rows), int(halo), int(edge), main_stream
         self.comm_stream = ctypes.c_void_p()
         _lib.call("xrs_stream_create", ctypes.byref(self.comm_stream))
-        self.ev_halo, self.ev_done = ctypes.c_void_p(), ctypes.c_void_p()
+        self.ev_halo, self.ev_done, self.ev_x0 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         _lib.call("xrs_event_create", ctypes.byref(self.ev_halo))
         _lib.call("xrs_event_create", ctypes.byref(self.ev_done))
+        _lib.call("xrs_event_create", ctypes.byref(self.ev_x0))
         _lib.call("xrs_event_record", self.ev_done, self.main)
 
     def plan(self, halo_top: int, halo_bot: int):
@@ -129,6 +130,7 @@ class OverlappedHalo:
     def step(self, exchange, launch, halo_top: int, halo_bot: int):
         # the exchange overwrites halo rows the previous step's edge launches may still be reading
         _lib.call("xrs_stream_wait_event", self.comm_stream, self.ev_done)
+        _lib.call("xrs_event_record", self.ev_x0, self.comm_stream)
         exchange(self.comm_stream)
         _lib.call("xrs_event_record", self.ev_halo, self.comm_stream)
         waited = False
@@ -139,11 +141,19 @@ class OverlappedHalo:
             launch(first, n, ht, hb)
         _lib.call("xrs_event_record", self.ev_done, self.main)
 
+    def last_exchange_ms(self) -> float:
+        """Device time of the most recent exchange on the comm stream (it ran concurrently with the interior rows)."""
+        _lib.call("xrs_event_sync", self.ev_halo)
+        ms = ctypes.c_float()
+        _lib.call("xrs_event_elapsed_ms", self.ev_x0, self.ev_halo, ctypes.byref(ms))
+        return float(ms.value)
+
     def close(self):
         _lib.call("xrs_stream_sync", self.comm_stream)
         _lib.call("xrs_stream_destroy", self.comm_stream)
         _lib.call("xrs_event_destroy", self.ev_halo)
         _lib.call("xrs_event_destroy", self.ev_done)
+        _lib.call("xrs_event_destroy", self.ev_x0)
 
 
 def combine_zonal_partials(parts):

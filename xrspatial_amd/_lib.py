@@ -154,17 +154,24 @@ def check(rc: int, what: str = ""):
         raise XrsError(f"{what}: {last_error()}" if what else last_error())
 
 
+_device_ready = False
+_device_index = 0
+_tls = threading.local()
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise XrsError on failure."""
-    check(getattr(load(), name)(*args), name)
-
-
-_device_ready = False
+    lib = load()
+    if _device_ready and not getattr(_tls, "bound", False):
+        # the HIP "current device" is per host thread: bind every new thread to this process's GPU once
+        _tls.bound = True
+        check(lib.xrs_set_device(_device_index), "xrs_set_device")
+    check(getattr(lib, name)(*args), name)
 
 
 def require_device():
     """Fail loudly unless a HIP device is usable (selects LOCAL_RANK's GPU once)."""
-    global _device_ready
+    global _device_ready, _device_index
     if _device_ready:
         return
     lib = load()
@@ -175,6 +182,8 @@ def require_device():
                        % (last_error() or "device count is 0"))
     dev = int(os.environ.get("XRS_DEVICE", os.environ.get("LOCAL_RANK", "0"))) % n.value
     check(lib.xrs_set_device(dev), "xrs_set_device")
+    _device_index = dev
+    _tls.bound = True
     _device_ready = True
 
 

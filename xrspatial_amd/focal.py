@@ -80,7 +80,7 @@ def _mean_hip(data, excludes, passes):
         host = np.asarray(data)
         # float32 rasters are widened on the fly by the first pass; everything else is cast like
         # the reference's `.astype(float)`
-        cur = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+        cur = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64, copy=False))
     rows, cols = cur.shape
     ex = np.asarray(list(excludes), dtype=np.float64)
     stream = get_stream()
@@ -156,7 +156,12 @@ def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 
             raise KeyError(s)
     if not isinstance(agg.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(agg)))
-    if isinstance(agg.data, np.ndarray):
+    if isinstance(agg.data, np.ndarray) and len(set(stats_funcs)) == len(stats_funcs):
+        # the planes are produced side by side in one device buffer and come back in ONE copy
+        dev = DeviceArray((len(stats_funcs),) + tuple(agg.shape), np.float32)
+        _focal_stats_hip(to_device_f32(agg.data), kernel, stats_funcs, stacked=dev)
+        stacked = dev.get(get_stream())
+    elif isinstance(agg.data, np.ndarray):
         planes = _focal_stats_hip(agg.data, kernel, stats_funcs)
         stacked = np.stack([planes[s] for s in stats_funcs])
     else:

@@ -83,7 +83,7 @@ def run_geodesic(data, lat, lon, is_2d, z_factor, aspect):
     else:
         host = np.asarray(data)
         # the reference widens to float64 (slope.py:168-169); float32 rasters are widened in registers
-        src = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+        src = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64, copy=False))
     if is_2d and (lat.shape != (rows, cols) or lon.shape != (rows, cols)):
         raise ValueError("2-D lat/lon coordinates must have the raster's shape")
     if not is_2d and (lat.shape != (rows,) or lon.shape != (cols,)):

@@ -125,7 +125,7 @@ def _stage(zone_idx, values):
         vdev = values if values.dtype in (np.float32, np.float64) else values.astype(np.float64)
     else:
         host = np.asarray(values)
-        vdev = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64))
+        vdev = DeviceArray.from_numpy(host if host.dtype == np.float32 else host.astype(np.float64, copy=False))
     return zdev, vdev
 
 
@@ -226,6 +226,13 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
             for name in stat_names:
                 frame[name] = cols[name][keep]
             return pd.DataFrame(frame)
+    if isinstance(zones_data, np.ndarray) and zones_data.dtype in _ZONE_DTYPE_CODE and zones_data.size:
+        # numpy zones: one upload, then the ids are mapped on the device (a host np.unique over the raster costs more
+        # than the whole reduction); non-integral / widely spread ids fall back to the host below
+        _lib.require_device()
+        zdev = DeviceArray.from_numpy(np.ascontiguousarray(zones_data))
+        mapped = _dense_zone_index_device(zdev)
+        del zdev
     if isinstance(zones_data, DeviceArray):
         _lib.require_device()
         mapped = _dense_zone_index_device(zones_data)           # stays in HBM when ids are integral

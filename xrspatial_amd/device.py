@@ -184,10 +184,11 @@ _CAST_CODE = {np.dtype(t): c for c, t in enumerate(
     (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.float64))}
 
 
-def _cast_f32_on_device(src: "DeviceArray", stream=None) -> "DeviceArray":
+def _cast_f32_on_device(src: "DeviceArray", stream=None, src_is_temporary=True) -> "DeviceArray":
     out = DeviceArray(src.shape, np.float32)
     _lib.call("xrs_cast_f32", src.ptr, _CAST_CODE[src.dtype], out.ptr, src.size, stream)
-    _lib.call("xrs_stream_sync", stream)          # `src` may be a temporary that goes back to the pool
+    if src_is_temporary:
+        _lib.call("xrs_stream_sync", stream)      # a temporary goes back to the pool when the caller drops it
     return out
 
 
@@ -256,7 +257,7 @@ class DeviceArray:
         if np.dtype(dtype) == self.dtype:
             return self
         if np.dtype(dtype) == np.float32 and self.dtype in _CAST_CODE:
-            return _cast_f32_on_device(self)
+            return _cast_f32_on_device(self, src_is_temporary=False)     # (the caller's array outlives the kernel)
         return DeviceArray.from_numpy(self.get().astype(dtype))
 
     def __repr__(self):

@@ -11,7 +11,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxrs_hip.so")
+LIB_PATH = os.environ.get("XRS_LIB") or os.path.join(_HERE, "libxrs_hip.so")   # XRS_LIB: A/B builds of the same ABI
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

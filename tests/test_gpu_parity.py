@@ -374,6 +374,23 @@ def test_uniform_weight_convolution_column_walker(radius, shape_kind):
         assert (got_h != want_h).mean() < 1e-4            # z-scores on a class boundary may round either way
 
 
+def test_focal_mean_division_is_exact():
+    """focal.mean's interior path divides the nine-cell float64 sum by 9 with a reciprocal + two exact residual
+    corrections instead of the hardware division sequence: bit-identical to true division (the oracle's), over
+    magnitudes from 1e-300 to 1e300, float32 and float64 inputs."""
+    rng = np.random.default_rng(77)
+    for dtype in (np.float64, np.float32):
+        mags = (-300, 300) if dtype == np.float64 else (-36, 36)
+        z = (rng.random((260, 1024)) + 0.5) * 10.0 ** rng.integers(mags[0], mags[1], (260, 1024)).astype(np.float64)
+        z *= rng.choice([-1.0, 1.0], z.shape)
+        z = z.astype(dtype)
+        got = xs.focal.mean(raster(z)).data
+        want = orc.focal_mean3x3(z)
+        np.testing.assert_array_equal(got, want)
+        smooth = (1000.0 + rng.random((260, 1024))).astype(dtype)     # sums with long significands
+        np.testing.assert_array_equal(xs.focal.mean(raster(smooth), passes=3).data, orc.focal_mean3x3(smooth, passes=3))
+
+
 def test_focal_runs_kernel_inf_and_nan_tiles():
     # the prefix-sum kernel: a tile with +-inf takes its direct fallback, NaN tiles count taps
     z = synth.smooth_dem((90, 300), nan_frac=0.03)

@@ -733,6 +733,20 @@ __device__ __forceinline__ bool is_excluded(const Mean3Args &a, double c) {
     return ex;
 }
 
+// s / 9 correctly rounded without the division sequence (v_div_scale / v_rcp / ~8 fma / v_div_fmas / v_div_fixup): with
+// y = RN(1/9) exact, two residual corrections q <- q + (s - 9 q) y (each residual exact in one fma) give the correctly
+// rounded quotient (Markstein; the divisor's significand is not all ones).  Finite s only (the caller guarantees it).
+// Results that would be subnormal or overflow the scaling-free form take the true division.
+__device__ __forceinline__ double div9_exact(double s) {
+    const double y = 0x1.c71c71c71c71cp-4;                 // RN(1/9)
+    const double as = fabs(s);
+    if (__builtin_expect(!(as > 0x1p-900 && as < 0x1p900), 0)) return s / 9.0;
+    double q = s * y;
+    q = fma(fma(-9.0, q, s), y, q);
+    q = fma(fma(-9.0, q, s), y, q);
+    return q;
+}
+
 template <typename InT>
 __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
     constexpr int RB = 4;
@@ -766,7 +780,7 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
                     for (int kx = 0; kx < 3; ++kx) s += d[r + ky][o + kx];
                 bad |= !isfinite(s);
                 const double c = d[r + 1][o + 1];
-                res[r][o] = is_excluded(a, c) ? c : s / 9.0;
+                res[r][o] = is_excluded(a, c) ? c : div9_exact(s);
             }
         if (!__any(bad)) {
 #pragma unroll

@@ -835,6 +835,17 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
     xs.slope(raster(synth.smooth_dem((100, 1024))))
     xs.slope(raster(synth.smooth_dem((1500, 1022))))
     assert len(calls) == n0
+    # k x k windows: the bands carry k//2 halo rows (focal.apply / focal_stats / convolve_2d, small and large masks)
+    z = synth.smooth_dem((1400, 1024), nan_frac=0.002)
+    zdev = xs.DeviceArray.from_numpy(z)
+    for k in (circle_kernel(1, 1, 2), np.ones((3, 3)), annulus_kernel(1, 1, 3, 1), circle_kernel(1, 1, 9), np.ones((11, 11))):
+        got = focal_stats(raster(z), k)
+        want = focal_stats(raster(z, backend='hip'), k).data.get()
+        assert isinstance(got.data, np.ndarray) and got.shape == (7, 1400, 1024)
+        np.testing.assert_array_equal(got.data, want, err_msg=f"focal_stats {k.shape}")
+        np.testing.assert_array_equal(apply(raster(z), k).data, want[0])
+        w = k / k.sum()
+        np.testing.assert_array_equal(convolve_2d(z, w), convolve_2d(zdev, w).get(), err_msg=f"convolve {k.shape}")
     # per-cell indices: same pipeline over flat chunks (ragged tail, mixed input dtypes)
     pc = []
     real_pc = _launch.percell_pipelined

@@ -74,32 +74,48 @@ class _Pipe(threading.local):
 _pipe = _Pipe()
 
 
-def _stencil_pipelined(fn_name, host, out_dtype, pre, extra, halo_rows):
+def pipelined_rows(host, out_dtypes, launch, halo_rows):
+    """Banded upload / compute / download of one 2-D raster through a row-range kernel.
+
+    `launch(in_ptr, out_ptrs, n_rows, halo_top, halo_bot, stream)` enqueues the kernel for the band whose first owned
+    row is at `in_ptr` (float32 plane of the raster's width) and whose outputs start at `out_ptrs` (one device
+    pointer per entry of `out_dtypes`).  Returns one page-locked (recycled) host array of shape
+    (len(out_dtypes), rows, cols) when all dtypes agree, else a list of arrays."""
     rows, cols = host.shape
-    out_dtype = np.dtype(out_dtype)
+    out_dtypes = [np.dtype(d) for d in out_dtypes]
+    n_out = len(out_dtypes)
     band = max(256, (_PIPE_BAND_BYTES // (cols * 4) + 15) // 16 * 16)
+    band = max(band, 4 * halo_rows)
     cuts = list(range(0, rows, band)) + [rows]
-    if cuts[-1] - cuts[-2] < 64 and len(cuts) > 2:          # no sliver at the end
+    if cuts[-1] - cuts[-2] < max(64, halo_rows) and len(cuts) > 2:      # no sliver at the end
         del cuts[-2]
     nb = len(cuts) - 1
     (s_up, s_run, s_down), ev = _pipe.get(2 * nb)
     dev_in = DeviceArray((rows, cols), np.float32)
-    dev_out = DeviceArray((rows, cols), out_dtype)
     native = host.dtype == np.float32
     raw = None if native else DeviceArray((max(b - a for a, b in zip(cuts, cuts[1:])), cols), host.dtype)
-    out_host = host_empty((rows, cols), out_dtype, pinned=True)
-    async_down = is_pinned(out_host)
-    isz, osz = host.dtype.itemsize, out_dtype.itemsize
+    same = all(d == out_dtypes[0] for d in out_dtypes)
+    if same:
+        stacked_host = host_empty((n_out, rows, cols), out_dtypes[0], pinned=True)
+        out_hosts = [stacked_host[i] for i in range(n_out)]
+    else:
+        stacked_host = None
+        out_hosts = [host_empty((rows, cols), d, pinned=True) for d in out_dtypes]
+    dev_outs = [DeviceArray((rows, cols), d) for d in out_dtypes]
+    async_down = all(is_pinned(h) for h in out_hosts)
+    isz = host.dtype.itemsize
 
     def run(j):
         a, b = cuts[j], cuts[j + 1]
         _lib.call("xrs_stream_wait_event", s_run, ev[min(j + 1, nb - 1)])       # rows below the band are up
-        _lib.call(fn_name, dev_in.ptr + a * cols * 4, dev_out.ptr + a * cols * osz, *pre, b - a, cols, cols, cols,
-                  *extra, halo_rows if j > 0 else 0, halo_rows if j < nb - 1 else 0, s_run)
+        launch(dev_in.ptr + a * cols * 4, [d.ptr + a * cols * d.dtype.itemsize for d in dev_outs], b - a,
+               halo_rows if j > 0 else 0, halo_rows if j < nb - 1 else 0, s_run)
         _lib.call("xrs_event_record", ev[nb + j], s_run)
         _lib.call("xrs_stream_wait_event", s_down, ev[nb + j])
-        _lib.call("xrs_memcpy_d2h", out_host.ctypes.data + a * cols * osz, dev_out.ptr + a * cols * osz,
-                  (b - a) * cols * osz, s_down)
+        for d, h in zip(dev_outs, out_hosts):
+            osz = d.dtype.itemsize
+            _lib.call("xrs_memcpy_d2h", h.ctypes.data + a * cols * osz, d.ptr + a * cols * osz, (b - a) * cols * osz,
+                      s_down)
         if not async_down:
             _lib.call("xrs_stream_sync", s_down)
 
@@ -117,7 +133,16 @@ def _stencil_pipelined(fn_name, host, out_dtype, pre, extra, halo_rows):
     run(nb - 1)
     for s in (s_up, s_run, s_down):
         _lib.call("xrs_stream_sync", s)
-    return out_host
+    return stacked_host if same else out_hosts
+
+
+def _stencil_pipelined(fn_name, host, out_dtype, pre, extra, halo_rows):
+    cols = host.shape[1]
+
+    def launch(in_ptr, out_ptrs, n_rows, ht, hb, stream):
+        _lib.call(fn_name, in_ptr, out_ptrs[0], *pre, n_rows, cols, cols, cols, *extra, ht, hb, stream)
+
+    return pipelined_rows(host, [out_dtype], launch, halo_rows)[0]
 
 
 def percell_pipelined(fn_name, hosts, extra):
@@ -162,6 +187,11 @@ def percell_pipelined(fn_name, hosts, extra):
     for s in (s_up, s_run, s_down):
         _lib.call("xrs_stream_sync", s)
     return out_host
+
+
+def pipeline_ok(data):
+    """Public spelling of the eligibility test (k x k wrappers)."""
+    return isinstance(data, np.ndarray) and _pipeline_ok(data)
 
 
 def _pipeline_ok(data, cols_bytes_multiple=16):

@@ -11,7 +11,7 @@ import re
 import numpy as np
 
 from . import _lib
-from ._launch import finish, get_stream, plane_args
+from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args
 from ._xr import DataArray
 from .device import DeviceArray, to_device_f32
 from .utils import get_dataarray_resolution
@@ -109,6 +109,16 @@ def _convolve_2d_hip(data, kernel):
     if len(data.shape) != 2:
         raise ValueError("expected a 2D raster")
     k = _kernel_f64(kernel)
+    if pipeline_ok(data) and max(k.shape) // 2 < 128:
+        # large numpy raster: row bands upload / compute / download concurrently
+        cols = data.shape[1]
+        work = DeviceArray((max(int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])), 16),), np.uint8)
+
+        def launch(in_ptr, out_ptrs, n_rows, ht, hb, stream):
+            _lib.call("xrs_convolve2d_f32", in_ptr, out_ptrs[0], n_rows, cols, cols, cols, k.ctypes.data, k.shape[0],
+                      k.shape[1], work.ptr, ht, hb, stream)
+
+        return pipelined_rows(data, [np.float32], launch, k.shape[0] // 2)[0]
     src = to_device_f32(data)
     rows, cols, ld = plane_args(src)
     out = DeviceArray((rows, cols), np.float32)

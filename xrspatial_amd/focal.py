@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from . import _lib, fused
-from ._launch import finish, get_stream, plane_args
+from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args
 from ._xr import DataArray
 from .convolution import _kernel_f64, custom_kernel
 from .dataset_support import supports_dataset
@@ -68,6 +68,26 @@ def _focal_stats_hip(data, kernel, stats, stacked=None):
     if like_numpy:
         return {s: arr.get(stream) for s, arr in outs.items()}
     return outs
+
+
+def _focal_stats_banded(host, kernel, stats):
+    """Large numpy-backed rasters: row bands upload / compute / download concurrently (_launch.pipelined_rows);
+    returns the (len(stats), rows, cols) float32 stack."""
+    _lib.require_device()
+    k = _kernel_f64(kernel)
+    cols = host.shape[1]
+    mask = 0
+    for s in stats:
+        mask |= 1 << _STAT_INDEX[s]
+
+    def launch(in_ptr, out_ptrs, n_rows, ht, hb, stream):
+        ptrs = (ctypes.c_void_p * 7)()
+        for s, ptr in zip(stats, out_ptrs):
+            ptrs[_STAT_INDEX[s]] = ptr
+        _lib.call("xrs_focal_stats_f32", in_ptr, ptrs, mask, n_rows, cols, cols, cols, k.ctypes.data, k.shape[0],
+                  k.shape[1], None, ht, hb, stream)
+
+    return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
 
 
 def _mean_hip(data, excludes, passes):
@@ -133,6 +153,8 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
         return scope.defer('focal_mean', raster, name, {'kernel': _kernel_f64(kernel)})
 
     def run(data, kernel, stat):
+        if pipeline_ok(data) and max(np.asarray(kernel).shape) // 2 < 128:
+            return _focal_stats_banded(data, kernel, [stat])[0]
         return _focal_stats_hip(data, kernel, [stat])[stat]
 
     mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
@@ -156,7 +178,9 @@ def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 
             raise KeyError(s)
     if not isinstance(agg.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(agg)))
-    if isinstance(agg.data, np.ndarray) and len(set(stats_funcs)) == len(stats_funcs):
+    if pipeline_ok(agg.data) and len(set(stats_funcs)) == len(stats_funcs) and max(kernel.shape) // 2 < 128:
+        stacked = _focal_stats_banded(agg.data, kernel, stats_funcs)
+    elif isinstance(agg.data, np.ndarray) and len(set(stats_funcs)) == len(stats_funcs):
         # the planes are produced side by side in one device buffer and come back in ONE copy
         dev = DeviceArray((len(stats_funcs),) + tuple(agg.shape), np.float32)
         _focal_stats_hip(to_device_f32(agg.data), kernel, stats_funcs, stacked=dev)

@@ -62,50 +62,43 @@ class ArrayTypeFunctionMapping(object):
 
 
 def validate_arrays(*arrays):
-    """Equal shapes and equal array types (reference: utils.py:146-165)."""
+    """All rasters must share one shape and one array backend (same errors as upstream, utils.py:146-165)."""
     if len(arrays) < 2:
         raise ValueError("validate_arrays() input must contain 2 or more arrays")
-    first = arrays[0]
+    head = arrays[0].data
     for other in arrays[1:]:
-        if not first.data.shape == other.data.shape:
+        if tuple(other.data.shape) != tuple(head.shape):
             raise ValueError("input arrays must have equal shapes")
-        if not isinstance(first.data, type(other.data)):
+        if not isinstance(head, type(other.data)):
             raise ValueError("input arrays must have same type")
 
 
+def _coordinate_extent(raster, dim):
+    coord = raster[dim]
+    return coord.min().item(), coord.max().item()
+
+
 def get_xy_range(raster, xdim=None, ydim=None):
-    if ydim is None:
-        ydim = raster.dims[-2]
-    if xdim is None:
-        xdim = raster.dims[-1]
-    xmin = raster[xdim].min().item()
-    xmax = raster[xdim].max().item()
-    ymin = raster[ydim].min().item()
-    ymax = raster[ydim].max().item()
-    return (xmin, xmax), (ymin, ymax)
+    """((xmin, xmax), (ymin, ymax)) of the raster's last two coordinate axes (upstream: utils.py:168-201)."""
+    xdim = raster.dims[-1] if xdim is None else xdim
+    ydim = raster.dims[-2] if ydim is None else ydim
+    return _coordinate_extent(raster, xdim), _coordinate_extent(raster, ydim)
 
 
 def calc_res(raster, xdim=None, ydim=None):
-    """(xres, yres) from the coordinate extents (reference: utils.py:204-230)."""
-    h, w = raster.shape[-2:]
-    xrange, yrange = get_xy_range(raster, xdim, ydim)
-    xres = (xrange[-1] - xrange[0]) / (w - 1)
-    yres = (yrange[-1] - yrange[0]) / (h - 1)
-    return xres, yres
+    """(xres, yres): coordinate extent divided by (cells - 1) per axis (upstream: utils.py:204-230)."""
+    (x_lo, x_hi), (y_lo, y_hi) = get_xy_range(raster, xdim, ydim)
+    n_rows, n_cols = raster.shape[-2:]
+    return (x_hi - x_lo) / (n_cols - 1), (y_hi - y_lo) / (n_rows - 1)
 
 
 def get_dataarray_resolution(agg, xdim=None, ydim=None):
-    """attrs['res'] (pair or scalar) else calc_res (reference: utils.py:233-277)."""
-    try:
-        cellsize = agg.attrs.get("res")
-        if (isinstance(cellsize, (tuple, np.ndarray, list)) and len(cellsize) == 2
-                and isinstance(cellsize[0], (int, float)) and isinstance(cellsize[1], (int, float))):
-            cellsize_x, cellsize_y = cellsize
-        elif isinstance(cellsize, (int, float)):
-            cellsize_x = cellsize
-            cellsize_y = cellsize
-        else:
-            cellsize_x, cellsize_y = calc_res(agg, xdim, ydim)
-    except Exception:
-        cellsize_x, cellsize_y = calc_res(agg, xdim, ydim)
-    return cellsize_x, cellsize_y
+    """Cell size: attrs['res'] when it is a number or a pair of numbers, otherwise derived from the coordinates
+    (upstream: utils.py:233-277)."""
+    plain_number = (int, float)
+    res = getattr(agg, "attrs", {}).get("res") if isinstance(getattr(agg, "attrs", None), dict) else None
+    if isinstance(res, plain_number):
+        return res, res
+    if isinstance(res, (tuple, list, np.ndarray)) and len(res) == 2 and all(isinstance(r, plain_number) for r in res):
+        return res[0], res[1]
+    return calc_res(agg, xdim, ydim)

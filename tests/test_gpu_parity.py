@@ -1098,6 +1098,35 @@ def test_hotspots(golden):
         np.testing.assert_array_equal(got[~near], want[~near])
 
 
+def test_nan_moments_one_pass_conditioning():
+    """xrs_nan_moments_f32 (global nanmean / nanstd behind focal.hotspots): one pass over values shifted by a sample
+    mean -- against float64 NumPy on rasters that would break an unshifted one-pass variance."""
+    from xrspatial_amd import _lib
+    rng = np.random.default_rng(41)
+    cases = {
+        'offset 1e6 + noise': (1e6 + rng.normal(0, 0.5, (700, 1030))).astype(np.float32),
+        'ramp': np.linspace(0, 1e6, 700 * 1030, dtype=np.float64).reshape(700, 1030).astype(np.float32),
+        'nodata head': np.concatenate([np.full((3, 1030), -9999.0), rng.normal(0.001, 0.0001, (697, 1030))]).astype(np.float32),
+        'nan holes': np.where(rng.random((700, 1030)) < 0.3, np.nan, rng.normal(250, 40, (700, 1030))).astype(np.float32),
+        'odd length': rng.normal(-3, 2, (1, 1027)).astype(np.float32),
+    }
+    for name, z in cases.items():
+        dev = xs.DeviceArray.from_numpy(z)
+        mom = xs.DeviceArray((4,), np.float64)
+        _lib.call("xrs_nan_moments_f32", dev.ptr, z.size, mom.ptr, None)
+        raw = mom.get()
+        count = int(raw[0:1].view(np.uint64)[0])
+        z64 = z.astype(np.float64)
+        assert count == np.count_nonzero(~np.isnan(z)), name
+        np.testing.assert_allclose(raw[3], np.nanmean(z64), rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose(np.sqrt(raw[2] / count), np.nanstd(z64), rtol=1e-9, err_msg=name)
+    empty = xs.DeviceArray.from_numpy(np.full((4, 8), np.nan, np.float32))
+    mom = xs.DeviceArray((4,), np.float64)
+    _lib.call("xrs_nan_moments_f32", empty.ptr, 32, mom.ptr, None)
+    raw = mom.get()
+    assert int(raw[0:1].view(np.uint64)[0]) == 0 and np.isnan(raw[3])
+
+
 def _geo_raster(elev, lat0, lat1, lon0, lon1, backend='numpy'):
     H, W = elev.shape
     agg = xs.DataArray(elev, dims=['lat', 'lon'], coords={'lat': np.linspace(lat0, lat1, H), 'lon': np.linspace(lon0, lon1, W)})

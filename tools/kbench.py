@@ -195,7 +195,7 @@ def main():
                                      A2, B2, 1.0, 0, geo_work.ptr, 0, 0, S), 8),
         "geodesic_aspect": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
                                       A2, B2, 1.0, 1, geo_work.ptr, 0, 0, S), 8),
-        "nan_moments": (lambda: L("xrs_nan_moments_f32", dem.ptr, cells, mom.ptr, S), 8),
+        "nan_moments": (lambda: L("xrs_nan_moments_f32", dem.ptr, cells, mom.ptr, S), 4),
         "hotspots_classify": (lambda: L("xrs_hotspots_classify_f32", dem.ptr, out8.ptr, cells, 50.0, 20.0, S), 5),
     }
     only = [s for s in args.only.split(",") if s]

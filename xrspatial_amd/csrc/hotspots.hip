@@ -3,7 +3,7 @@
 // Reference: _hotspots_numpy (xrspatial/focal.py:914-934): mean_array = convolve_2d(data, kernel/kernel.sum());
 // z = (mean_array - nanmean(data)) / nanstd(data); _calc_hotspots_numpy (:881-911) maps z to
 // {0, +-90, +-95, +-99}.  The convolution is xrs_convolve2d_f32; here:
-//   xrs_nan_moments_f32   two streaming passes (count + sum, then squared deviations from the float64 mean):
+//   xrs_nan_moments_f32   ONE streaming pass over shifted values (count, sum, sum of squares in float64):
 //                         wave64 DPP reductions, one atomic per wave;
 //   xrs_hotspots_classify_f32   z in float32 exactly as the reference forms it, int8 out (4 B in + 1 B out per cell).
 #include "xrs_common.h"
@@ -19,41 +19,100 @@ struct Moments {                 // device-resident, 32 bytes
     double sum, ssd, mean;
 };
 
-__global__ void moments_init_kernel(Moments *m) { m->count = 0ull; m->sum = 0.0; m->ssd = 0.0; m->mean = 0.0; }
-
-__global__ void moments_mean_kernel(Moments *m) { m->mean = m->count ? m->sum / (double)m->count : nan(""); }
-
-template <int PASS>
-__global__ void __launch_bounds__(256) moments_kernel(const float *x, long n, Moments *m, const int vec) {
-    const double mean = PASS == 2 ? m->mean : 0.0;
+// Single streaming pass: count, sum and sum of squares of the values SHIFTED by `m->mean` (set beforehand to the mean
+// of a small sample, so the shifted values are centred to within a few standard deviations and the one-pass
+// variance  (S2 - S1^2/n)/n  is well conditioned in float64; the reference's own float32 np.nanmean / np.nanstd carry
+// ~1e-6 relative error).  Each workgroup streams ONE contiguous chunk (chunks dealt to XCDs in contiguous runs), the
+// pattern that measured 1.3x faster than a grid-strided comb on the per-cell kernels.
+__global__ void moments_sample_kernel(const float *x, long n, Moments *m) {
+    __shared__ double ssum[256];
+    __shared__ unsigned scnt[256];
+    const long take = n < 4096 ? n : 4096;          // (a shift within a few sigma of the mean is all that is needed)
     double acc = 0.0;
     unsigned cnt = 0;
-    const long n4 = vec ? n >> 2 : 0;                   // 16-byte loads only when the plane is 16-byte aligned
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4 *>(x)[i];
-        const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (!isnan(e[k])) {
-                const double d = (double)e[k] - mean;
-                acc += PASS == 2 ? d * d : d;
-                ++cnt;
-            }
+    for (long i = threadIdx.x; i < take; i += 256)
+        if (isfinite(x[i])) { acc += (double)x[i]; ++cnt; }
+    ssum[threadIdx.x] = acc; scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        m->count = 0ull; m->sum = 0.0; m->ssd = 0.0;
+        m->mean = scnt[0] ? ssum[0] / (double)scnt[0] : 0.0;           // the shift
+    }
+}
+
+__global__ void __launch_bounds__(256) moments_kernel(const float *x, long n, Moments *m, const int vec) {
+    const double shift = m->mean;
+    double s1 = 0.0, s2 = 0.0;
+    unsigned cnt = 0;
+    const long n4 = vec ? n >> 2 : 0;                   // 16-byte loads only when the plane is 16-byte aligned
+    const long n_chunks = gridDim.x;                    // a multiple of 8
+    const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
+    const long per_chunk = ((n4 + n_chunks - 1) / n_chunks + 1023) & ~1023L;
+    const long c_begin = my_chunk * per_chunk;
+    const long c_end = c_begin + per_chunk < n4 ? c_begin + per_chunk : n4;
+    constexpr int U = 4;                                // 16-byte loads in flight per lane
+    for (long i0 = c_begin + threadIdx.x; i0 < c_end; i0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + 256 * u;
+            v[u] = i < c_end ? reinterpret_cast<const float4 *>(x)[i] : make_float4(nan_f32(), nan_f32(), nan_f32(), nan_f32());
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = !isnan(e[k]);
+                const double d = ok ? (double)e[k] - shift : 0.0;
+                s1 += d;
+                s2 = fma(d, d, s2);
+                cnt += ok ? 1u : 0u;
+            }
+        }
+    }
+    const long stride = (long)gridDim.x * 256;
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
         if (!isnan(x[i])) {
-            const double d = (double)x[i] - mean;
-            acc += PASS == 2 ? d * d : d;
+            const double d = (double)x[i] - shift;
+            s1 += d;
+            s2 = fma(d, d, s2);
             ++cnt;
         }
     rocprim::warp_reduce<double, 64>::storage_type sd;
     rocprim::warp_reduce<unsigned, 64>::storage_type su;
-    rocprim::warp_reduce<double, 64>().reduce(acc, acc, sd);
+    rocprim::warp_reduce<double, 64>().reduce(s1, s1, sd);
+    rocprim::warp_reduce<double, 64>().reduce(s2, s2, sd);
     rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        if (PASS == 1) { atomicAdd(&m->sum, acc); atomicAdd(&m->count, (unsigned long long)cnt); }
-        else atomicAdd(&m->ssd, acc);
+    // one set of atomics per workgroup (three addresses shared by the whole grid)
+    __shared__ double w1[4], w2[4];
+    __shared__ unsigned wc[4];
+    if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; wc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned c = wc[0] + wc[1] + wc[2] + wc[3];
+        if (c) {
+            atomicAdd(&m->sum, (w1[0] + w1[1]) + (w1[2] + w1[3]));
+            atomicAdd(&m->ssd, (w2[0] + w2[1]) + (w2[2] + w2[3]));
+            atomicAdd(&m->count, (unsigned long long)c);
+        }
+    }
+}
+
+__global__ void moments_final_kernel(Moments *m) {
+    const double n = (double)m->count, s1 = m->sum, s2 = m->ssd, shift = m->mean;
+    if (m->count) {
+        const double md = s1 / n;
+        const double ssd = s2 - s1 * md;
+        m->mean = shift + md;
+        m->ssd = ssd > 0.0 ? ssd : 0.0;
+        m->sum = m->mean * n;
+    } else {
+        m->mean = nan(""); m->ssd = 0.0; m->sum = 0.0;
     }
 }
 
@@ -94,11 +153,14 @@ int xrs_nan_moments_f32(const float *in_dev, int64_t n, void *moments32_dev, voi
     if (!moments32_dev || (n && !in_dev)) return fail("xrs_nan_moments_f32: null pointer");
     Moments *m = static_cast<Moments *>(moments32_dev);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(moments_init_kernel, dim3(1), dim3(1), 0, s, m);
+    hipLaunchKernelGGL(moments_sample_kernel, dim3(1), dim3(256), 0, s, in_dev, (long)n, m);
     const int vec = aligned16(in_dev) ? 1 : 0;
-    if (n) hipLaunchKernelGGL(moments_kernel<1>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, in_dev, (long)n, m, vec);
-    hipLaunchKernelGGL(moments_mean_kernel, dim3(1), dim3(1), 0, s, m);
-    if (n) hipLaunchKernelGGL(moments_kernel<2>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, in_dev, (long)n, m, vec);
+    if (n) {
+        long g = (n / 4 + 255) / 256;
+        g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
+        hipLaunchKernelGGL(moments_kernel, dim3((unsigned)xcd_grid(g)), dim3(256), 0, s, in_dev, (long)n, m, vec);
+    }
+    hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(1), 0, s, m);
     XRS_LAUNCH_CHECK();
     return 0;
 }

@@ -53,14 +53,47 @@ __global__ void scan_init_kernel(ScanResult *r) {
     r->zmin = INFINITY; r->zmax = -INFINITY; r->n_finite = 0ull; r->all_integral = 1; r->pad = 0;
 }
 
+// Streaming skeleton shared by the three passes: each workgroup owns ONE contiguous chunk of the raster (chunks dealt
+// to the XCDs in contiguous runs), a lane keeps U 16-byte loads in flight (the grid-strided one-element-per-trip form
+// these kernels started as reached 2.2-3.3 TB/s; this one reads at the copy rate), and `f(index, value)` sees every
+// element exactly once.  16-byte loads need a 16-byte aligned plane; otherwise elements are loaded one by one.
+template <typename T, typename F>
+__device__ __forceinline__ void for_each_chunked(const T *z, long n, bool vec, F &&f) {
+    constexpr int PER = 16 / sizeof(T);                       // elements per 16-byte slot (4 or 2)
+    constexpr int U = 4;
+    const long nv = vec ? n / PER : 0;                        // 16-byte slots
+    const long n_chunks = gridDim.x;                          // a multiple of 8
+    const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
+    const long per_chunk = ((nv + n_chunks - 1) / n_chunks + 256 * U - 1) / (256 * U) * (256 * U);
+    const long c_begin = my_chunk * per_chunk;
+    const long c_end = c_begin + per_chunk < nv ? c_begin + per_chunk : nv;
+    struct alignas(16) Slot { T e[PER]; };
+    for (long i0 = c_begin + threadIdx.x; i0 < c_end; i0 += 256 * U) {
+        Slot slot[U];
+        bool have[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + 256 * u;
+            have[u] = i < c_end;
+            if (have[u]) slot[u] = reinterpret_cast<const Slot *>(z)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (have[u]) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) f((i0 + 256 * u) * PER + k, slot[u].e[k]);
+            }
+    }
+    const long stride = (long)gridDim.x * 256;
+    for (long i = nv * PER + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) f(i, z[i]);
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResult *res) {
+__global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResult *res, const int vec) {
     double mn = INFINITY, mx = -INFINITY;
     unsigned cnt = 0;
     bool integral = true;
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const T v = z[i];
+    for_each_chunked(z, n, vec != 0, [&](long, T v) {
         if (finite_id(v)) {
             const double d = (double)v;
             mn = d < mn ? d : mn;
@@ -68,55 +101,64 @@ __global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResul
             integral = integral && integral_id(v);
             ++cnt;
         }
-    }
+    });
     rocprim::warp_reduce<double, 64>::storage_type sd;
     rocprim::warp_reduce<unsigned, 64>::storage_type su;
     rocprim::warp_reduce<double, 64>().reduce(mn, mn, sd, rocprim::minimum<double>());
     rocprim::warp_reduce<double, 64>().reduce(mx, mx, sd, rocprim::maximum<double>());
     rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
     const bool wave_integral = __all(integral);
+    // one set of atomics per workgroup
+    __shared__ double wmn[4], wmx[4];
+    __shared__ unsigned wc[4];
+    __shared__ int wint[4];
     if ((threadIdx.x & 63) == 0) {
-        if (cnt) {
-            atomic_min_f64(&res->zmin, mn);
-            atomic_max_f64(&res->zmax, mx);
-            atomicAdd(&res->n_finite, (unsigned long long)cnt);
+        const int w = threadIdx.x >> 6;
+        wmn[w] = mn; wmx[w] = mx; wc[w] = cnt; wint[w] = wave_integral ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned c = wc[0] + wc[1] + wc[2] + wc[3];
+        if (c) {
+            atomic_min_f64(&res->zmin, fmin(fmin(wmn[0], wmn[1]), fmin(wmn[2], wmn[3])));
+            atomic_max_f64(&res->zmax, fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3])));
+            atomicAdd(&res->n_finite, (unsigned long long)c);
         }
-        if (!wave_integral) atomicAnd(&res->all_integral, 0);
+        if (!(wint[0] && wint[1] && wint[2] && wint[3])) atomicAnd(&res->all_integral, 0);
     }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) presence_kernel(const T *z, long n, double zmin, long range,
-                                                       unsigned char *present) {
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const T v = z[i];
+                                                       unsigned char *present, const int vec) {
+    long last = -1;                                   // zone rasters come in runs: store only when the id changes
+    for_each_chunked(z, n, vec != 0, [&](long, T v) {
         if (finite_id(v)) {
             const long off = (long)((double)v - zmin);
-            if (off >= 0 && off < range) present[off] = 1;      // benign race: every writer stores 1
+            if (off != last && off >= 0 && off < range) present[off] = 1;      // benign race: every writer stores 1
+            last = off;
         }
-    }
+    });
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) index_kernel(const T *z, long n, double zmin, long range,
-                                                    const int32_t *lut, int32_t *idx) {
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const T v = z[i];
+                                                    const int32_t *lut, int32_t *idx, const int vec) {
+    for_each_chunked(z, n, vec != 0, [&](long i, T v) {
         int32_t out = -1;
         if (finite_id(v)) {
             const long off = (long)((double)v - zmin);
             if (off >= 0 && off < range) out = lut[off];
         }
         idx[i] = out;
-    }
+    });
 }
 
 inline unsigned grid_for(long n) {
-    long g = (n + 255) / 256;
-    const long cap = 256L * 16;
-    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+    long g = (n / 4 + 255) / 256;
+    const long cap = 2048;                            // 8 chunks per CU
+    g = g > cap ? cap : (g < 1 ? 1 : g);
+    return (unsigned)xcd_grid(g);                     // multiple of 8: chunk <-> XCD mapping is a bijection
 }
 
 template <typename T>
@@ -125,7 +167,7 @@ int scan_impl(const void *zones, long n, void *result32, hipStream_t s) {
     if (!result32 || (n && !zones)) return fail("xrs_zonal_scan: null pointer");
     ScanResult *r = static_cast<ScanResult *>(result32);
     hipLaunchKernelGGL(scan_init_kernel, dim3(1), dim3(1), 0, s, r);
-    if (n) hipLaunchKernelGGL(scan_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, r);
+    if (n) hipLaunchKernelGGL(scan_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, r, aligned16(zones) ? 1 : 0);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -135,7 +177,7 @@ int presence_impl(const void *zones, long n, double zmin, long range, unsigned c
     if (n < 0 || range <= 0) return fail("xrs_zonal_presence: bad size");
     if (!present || (n && !zones)) return fail("xrs_zonal_presence: null pointer");
     XRS_HIP(hipMemsetAsync(present, 0, (size_t)range, s));
-    if (n) hipLaunchKernelGGL(presence_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, present);
+    if (n) hipLaunchKernelGGL(presence_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, present, aligned16(zones) ? 1 : 0);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -145,7 +187,7 @@ int index_impl(const void *zones, long n, double zmin, long range, const int32_t
     if (n < 0 || range <= 0) return fail("xrs_zonal_index: bad size");
     if (n == 0) return 0;
     if (!zones || !lut || !idx) return fail("xrs_zonal_index: null pointer");
-    hipLaunchKernelGGL(index_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, lut, idx);
+    hipLaunchKernelGGL(index_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, static_cast<const T *>(zones), n, zmin, range, lut, idx, aligned16(zones) ? 1 : 0);
     XRS_LAUNCH_CHECK();
     return 0;
 }

@@ -186,6 +186,11 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
                       int64_t ld_in, int64_t ld_out, const double *excludes, int n_excludes,
                       int halo_top, int halo_bot, void *stream);
 
+/* `passes` applications in one call (the loop of focal.py:257-259): contiguous planes (pitch = cols), the passes
+ * ping-pong between out_dev and scratch_dev (rows*cols doubles, may be NULL for passes == 1); result in out_dev. */
+int xrs_focal_mean3x3_passes(const void *in_dev, int in_is_f64, double *out_dev, double *scratch_dev, int passes,
+                             int64_t rows, int64_t cols, const double *excludes, int n_excludes, void *stream);
+
 /* focal.hotspots support (xrspatial/focal.py:881-934): global NaN-skipping moments of a float32 plane
  * -> moments32_dev = { uint64 count; double sum, ssd (sum of squared deviations from the mean), mean },
  * and the z-score classifier  z = (mean_array - global_mean) / global_std  ->  {0, +-90, +-95, +-99} int8. */

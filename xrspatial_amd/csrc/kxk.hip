@@ -1138,4 +1138,21 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
     return 0;
 }
 
+int xrs_focal_mean3x3_passes(const void *in_dev, int in_is_f64, double *out_dev, double *scratch_dev, int passes,
+                             int64_t rows, int64_t cols, const double *excludes, int n_excludes, void *stream) {
+    // the reference's loop `for _ in range(passes): out = _mean(out, excludes)` (focal.py:257-259) enqueued in one call:
+    // the passes ping-pong between `out_dev` and `scratch_dev` so that the last one lands in `out_dev`
+    if (passes < 1) return fail("xrs_focal_mean3x3_passes: passes must be >= 1");
+    if (passes > 1 && !scratch_dev) return fail("xrs_focal_mean3x3_passes: more than one pass needs a scratch plane");
+    const void *src = in_dev;
+    int src_f64 = in_is_f64;
+    for (int p = 0; p < passes; ++p) {
+        double *dst = ((passes - 1 - p) & 1) ? scratch_dev : out_dev;
+        if (int rc = xrs_focal_mean3x3(src, src_f64, dst, rows, cols, cols, cols, excludes, n_excludes, 0, 0, stream)) return rc;
+        src = dst;
+        src_f64 = 1;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -104,12 +104,16 @@ def _mean_hip(data, excludes, passes):
     rows, cols = cur.shape
     ex = np.asarray(list(excludes), dtype=np.float64)
     stream = get_stream()
-    out = cur if cur.dtype == np.float64 else cur.astype(np.float64)      # passes == 0: `agg.data.astype(float)` only
-    for _ in range(int(passes)):
-        out = DeviceArray((rows, cols), np.float64)
-        _lib.call("xrs_focal_mean3x3", cur.ptr, int(cur.dtype == np.float64), out.ptr, rows, cols, cols, cols,
-                  ex.ctypes.data, len(ex), 0, 0, stream)
-        cur = out
+    passes = int(passes)
+    if passes < 1:
+        out = cur if cur.dtype == np.float64 else cur.astype(np.float64)  # `agg.data.astype(float)` only
+        return finish(out, like_numpy)
+    out = DeviceArray((rows, cols), np.float64)
+    scratch = DeviceArray((rows, cols), np.float64) if passes > 1 else None
+    _lib.call("xrs_focal_mean3x3_passes", cur.ptr, int(cur.dtype == np.float64), out.ptr,
+              scratch.ptr if scratch is not None else None, passes, rows, cols, ex.ctypes.data, len(ex), stream)
+    if scratch is not None or like_numpy:
+        _lib.call("xrs_stream_sync", stream)        # `scratch` / `ex` must outlive the launches
     return finish(out, like_numpy)
 
 

@@ -1213,6 +1213,15 @@ def test_zonal_crosstab(golden):
             assert list(got.columns) == list(want)
             for col in want:
                 np.testing.assert_allclose(got[col].to_numpy(), want[col], rtol=1e-6, equal_nan=True, err_msg=str(col))
+    # large tables: 700 zones x 30 categories (LDS counters beyond 64 KiB) and 900 x 60 (global atomics)
+    for nzz, ncc in ((700, 30), (900, 60)):
+        zz = rng.integers(0, nzz, size=(300, 400)).astype(np.int32)
+        vv = rng.integers(0, ncc, size=zz.shape).astype(np.int32)
+        got = crosstab(raster(zz, backend='hip'), raster(vv, backend='hip'))
+        want = orc.crosstab_2d(zz, vv)
+        assert list(got.columns) == list(want)
+        for col in want:
+            np.testing.assert_array_equal(got[col].to_numpy(), want[col], err_msg=f"{nzz}x{ncc} {col}")
     # 3-D values: a layer per category (test_zonal.py:50-59, 266-336, 825-880)
     data3 = np.ones((3, 8, 4))
     v3 = xs.DataArray(data3, dims=['lat', 'lon', 'race'], coords={'race': np.array(['cat1', 'cat2', 'cat3', 'cat4'], dtype=object)})

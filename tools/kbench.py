@@ -122,6 +122,19 @@ def main():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
         L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
 
+    xt = xs.DeviceArray((1000 * 32,), np.uint64)
+    cats = xs.DeviceArray((n, n), np.int32)
+    zones64 = xs.DeviceArray((n, n), np.int32)
+    cats8 = xs.DeviceArray((n, n), np.int32)
+    rng2 = np.random.default_rng(10)
+    for y0 in range(0, n, 2048):
+        c = rng2.integers(0, 32, size=(2048, n)).astype(np.int32)               # categorical: changes every cell
+        _lib.call("xrs_memcpy_h2d", cats.ptr + y0 * n * 4, c.ctypes.data, c.nbytes, None)
+        c8 = (c & 7).astype(np.int32)
+        _lib.call("xrs_memcpy_h2d", cats8.ptr + y0 * n * 4, c8.ctypes.data, c8.nbytes, None)
+        z64 = synth.block_zones(2048, n, n_zones=64, block=2048, y0=y0)
+        _lib.call("xrs_memcpy_h2d", zones64.ptr + y0 * n * 4, z64.ctypes.data, z64.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
     lat1 = xs.DeviceArray.from_numpy(np.linspace(40.0, 41.0, n))
     lon1 = xs.DeviceArray.from_numpy(np.linspace(10.0, 11.0, n))
     geo_work = xs.DeviceArray((int(_lib.load().xrs_geodesic_workspace_bytes(n, n)),), np.uint8)
@@ -191,6 +204,10 @@ def main():
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
         "zonal_1000_scattered": (zonal_scatter, 8),
+        "crosstab_1000x32": (lambda: (L("xrs_memset", xt.ptr, 0, 1000 * 32 * 8, S),
+                                      L("xrs_crosstab_counts", zones.ptr, cats.ptr, cells, 1000, 32, xt.ptr, S)), 8),
+        "crosstab_64x8": (lambda: (L("xrs_memset", xt.ptr, 0, 64 * 8 * 8, S),
+                                   L("xrs_crosstab_counts", zones64.ptr, cats8.ptr, cells, 64, 8, xt.ptr, S)), 8),
         "geodesic_slope": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
                                      A2, B2, 1.0, 0, geo_work.ptr, 0, 0, S), 8),
         "geodesic_aspect": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,

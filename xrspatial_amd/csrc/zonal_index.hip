@@ -231,7 +231,7 @@ int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmi
 // zonal.crosstab (2-D values): counts of (zone, category) pairs.  Reference: _single_zone_crosstab_2d /
 // _crosstab_numpy (xrspatial/zonal.py:699-800): per zone, sort the zone's values and stride over the
 // categories.  Here: one streaming pass over two dense index planes (8 B/cell), counters privatised per
-// workgroup in LDS when the zone x category table fits (<= 16384 cells), flushed once with device atomics.
+// workgroup in LDS when the zone x category table fits (<= 36864 cells = 144 KiB), flushed once with device atomics.
 namespace {
 
 template <bool LDS>
@@ -278,9 +278,21 @@ extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *c
     if (grid < 1) grid = 1;
     if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;
     unsigned long long *counts = reinterpret_cast<unsigned long long *>(counts_dev);
-    if (cells <= 16384)
+    if (cells <= 36864) {
+        // per-workgroup counters in LDS: up to 144 KiB of the CU's 160 KiB (one workgroup per CU then; the table of a
+        // 1000-zone x 32-class crosstab fits, and global atomics on it measured 40x slower)
+        if (cells > 16384) {
+            static bool raised = false;        // (idempotent; a race only repeats the call)
+            if (!raised) {
+                XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&crosstab_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+                raised = true;
+            }
+            if (grid > 256 * 2) grid = 256 * 2;
+        }
         hipLaunchKernelGGL(crosstab_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)cells * 4, as_stream(stream),
                            zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
+    }
     else
         hipLaunchKernelGGL(crosstab_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
                            zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);

@@ -514,17 +514,26 @@ def test_zonal_device_resident_zone_indexing(zdtype):
         np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
 
 
-def test_zonal_run_to_run_counts_and_many_zones():
+@pytest.mark.parametrize("n_zones,vdtype", [(5000, np.float32), (12000, np.float32), (9000, np.float64)])
+def test_zonal_run_to_run_counts_and_many_zones(n_zones, vdtype):
+    """Zone tables beyond one workgroup's LDS (5266 zones for float32 values, 4096 for float64) are accumulated in
+    several zone-window launches; every window must land in its own slice of the result."""
     rows, cols = 512, 512
-    zones = np.random.default_rng(1).integers(0, 5000, size=(rows, cols)).astype(np.int32)   # > LDS-privatised limit
-    vals = synth.asv_dem(rows, cols)
-    a = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=['count', 'sum', 'max'])
-    b = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=['count', 'sum', 'max'])
-    want = orc.zonal_stats(zones, vals, stats_funcs=['count', 'sum', 'max'])
+    zones = np.random.default_rng(1).integers(0, n_zones, size=(rows, cols)).astype(np.int32)
+    zones[0, :3] = [0, n_zones - 1, n_zones // 2]
+    vals = synth.asv_dem(rows, cols).astype(vdtype)
+    stats = ['count', 'sum', 'max', 'min', 'mean']
+    a = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=stats)
+    b = xs.zonal_stats(raster(zones, backend='hip'), raster(vals, backend='hip'), stats_funcs=stats)
+    want = orc.zonal_stats(zones, vals, stats_funcs=stats)
+    assert len(a) == len(want['zone'])
+    np.testing.assert_array_equal(a['zone'].to_numpy(), want['zone'])
     np.testing.assert_array_equal(a['count'], b['count'])
     np.testing.assert_array_equal(a['count'].to_numpy(), want['count'])
     np.testing.assert_array_equal(a['max'].to_numpy(), want['max'])
+    np.testing.assert_array_equal(a['min'].to_numpy(), want['min'])
     np.testing.assert_allclose(a['sum'].to_numpy(), want['sum'], rtol=RTOL)
+    np.testing.assert_allclose(b['mean'].to_numpy(), want['mean'], rtol=RTOL)
 
 
 def test_dataset_adapters():

@@ -142,6 +142,19 @@ def main():
     mom = xs.DeviceArray((4,), np.float64)
     out8 = xs.DeviceArray((n, n), np.int8)
 
+    zones5k = xs.DeviceArray((n, n), np.int32)
+    for y0 in range(0, n, 2048):
+        z5 = synth.block_zones(2048, n, n_zones=5000, block=128, y0=y0)
+        _lib.call("xrs_memcpy_h2d", zones5k.ptr + y0 * n * 4, z5.ctypes.data, z5.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
+    z5c = xs.DeviceArray((5000,), np.uint64)
+    z5s, z5q = xs.DeviceArray((5000,), np.float64), xs.DeviceArray((5000,), np.float64)
+    z5mn, z5mx = xs.DeviceArray((5000,), np.float32), xs.DeviceArray((5000,), np.float32)
+
+    def zonal5k():
+        L("xrs_zonal_init", z5c.ptr, z5s.ptr, z5q.ptr, z5mn.ptr, z5mx.ptr, 5000, S)
+        L("xrs_zonal_partials_f32", zones5k.ptr, dem.ptr, cells, 5000, 0.0, 0, z5c.ptr, z5s.ptr, z5q.ptr, z5mn.ptr, z5mx.ptr, S)
+
     def zonal_scatter():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
         L("xrs_zonal_partials_f32", zones_sc.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
@@ -204,6 +217,7 @@ def main():
         "focal_mean3x3_f64": (lambda: L("xrs_focal_mean3x3", dem.ptr, 0, out64.ptr, n, n, n, n, ex.ctypes.data, 1, 0, 0, S), 12),
         "zonal_1000": (zonal, 8),
         "zonal_1000_scattered": (zonal_scatter, 8),
+        "zonal_5000": (zonal5k, 8),
         "crosstab_1000x32": (lambda: (L("xrs_memset", xt.ptr, 0, 1000 * 32 * 8, S),
                                       L("xrs_crosstab_counts", zones.ptr, cats.ptr, cells, 1000, 32, xt.ptr, S)), 8),
         "crosstab_64x8": (lambda: (L("xrs_memset", xt.ptr, 0, 64 * 8 * 8, S),

@@ -44,12 +44,21 @@ template <typename OutT>
 __device__ __forceinline__ void store4(OutT *p, const float (&v)[4]);
 template <>
 __device__ __forceinline__ void store4<float>(float *p, const float (&v)[4]) {
-    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    store_f4u(p, v[0], v[1], v[2], v[3]);
 }
 template <>
 __device__ __forceinline__ void store4<double>(double *p, const float (&v)[4]) {
-    reinterpret_cast<double2 *>(p)[0] = make_double2((double)v[0], (double)v[1]);
-    reinterpret_cast<double2 *>(p)[1] = make_double2((double)v[2], (double)v[3]);
+    xrs_d2u a, b;
+    a.x = (double)v[0]; a.y = (double)v[1]; b.x = (double)v[2]; b.y = (double)v[3];
+    reinterpret_cast<xrs_d2u *>(p)[0] = a;
+    reinterpret_cast<xrs_d2u *>(p)[1] = b;
+}
+// the last lane of a row when cols % 4 != 0: only the first `n` results exist
+template <typename OutT>
+__device__ __forceinline__ void store_n(OutT *p, const float (&v)[4], int n) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < n) p[o] = (OutT)v[o];
 }
 
 // ---------------------------------------------------------------- fast path
@@ -62,6 +71,8 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
     const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;   // valid input rows [y_lo, y_hi)
     const bool has_l = INTERIOR || x0 > 0, has_r = INTERIOR || x0 + 4 < a.cols;
     const unsigned loff = (unsigned)lane * 4u;
+    // columns this lane owns (4, or fewer for the last lane of a row whose width is not a multiple of 4)
+    const int nown = INTERIOR ? 4 : (a.cols - x0 < 4 ? (int)(a.cols - x0) : 4);
 
     // v[r][0..5] = columns x0-1 .. x0+4 of input row y0 + r - 1
     float v[RB + 2][6];
@@ -74,7 +85,14 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float l = 0.f, rr = 0.f;
         if (ok) {
-            c4 = *reinterpret_cast<const float4 *>(p);
+            if (INTERIOR || nown == 4) {
+                const xrs_f4u q = load_f4u(p);
+                c4 = make_float4(q.x, q.y, q.z, q.w);
+            } else {
+                c4.x = p[0];
+                if (nown > 1) c4.y = p[1];
+                if (nown > 2) c4.z = p[2];
+            }
             if ((OPS & (OP_SLOPE | OP_ASPECT)) || (r >= 1 && r <= RB)) {   // diagonal-free ops need halo columns on centre rows only
                 if (has_l) l = p[-1];
                 if (has_r) rr = p[4];
@@ -105,10 +123,17 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
             if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
         }
         const long off = y * a.ld_out + x_tile;                         // wave-uniform
-        if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off + loff, o_slope);
-        if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off + loff, o_aspect);
-        if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off + loff, o_curv);
-        if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off + loff, o_hill);
+        if (INTERIOR || nown == 4) {
+            if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off + loff, o_slope);
+            if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off + loff, o_aspect);
+            if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off + loff, o_curv);
+            if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off + loff, o_hill);
+        } else {
+            if ((OPS & OP_SLOPE) && a.out[0]) store_n(static_cast<float *>(a.out[0]) + off + loff, o_slope, nown);
+            if ((OPS & OP_ASPECT) && a.out[1]) store_n(static_cast<float *>(a.out[1]) + off + loff, o_aspect, nown);
+            if ((OPS & OP_CURV) && a.out[2]) store_n(static_cast<float *>(a.out[2]) + off + loff, o_curv, nown);
+            if ((OPS & OP_HILL) && a.out[3]) store_n(static_cast<HillT *>(a.out[3]) + off + loff, o_hill, nown);
+        }
     }
 }
 
@@ -188,10 +213,10 @@ int terrain_dispatch(TerrainArgs &a, int ops, bool hill_f64, hipStream_t s) {
     if (a.rows < 0 || a.cols < 0 || a.ld_in < a.cols || a.ld_out < a.cols)
         return fail("terrain: bad shape rows=%ld cols=%ld ld_in=%ld ld_out=%ld", a.rows, a.cols, a.ld_in, a.ld_out);
     if (a.halo_top < 0 || a.halo_bot < 0) return fail("terrain: negative halo");
-    bool fast = (a.cols % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) && aligned16(a.in);
-    for (int i = 0; i < 4; ++i)
-        if ((ops >> i & 1) && a.out[i]) fast = fast && aligned16(a.out[i]);
-    if (hill_f64 && (a.ld_out % 2)) fast = false;
+    // the strip kernels take any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane);
+    // XRS_TERRAIN_VARIANT=cell forces the one-cell-per-thread kernel (A/B, and the oracle of the ragged path's tests)
+    const char *variant = getenv("XRS_TERRAIN_VARIANT");
+    const bool fast = !(variant && variant[0] == 'c');
     if (fast) {
         switch (ops) {
             case OP_SLOPE: return launch_strip<OP_SLOPE, float>(a, s);

@@ -59,6 +59,17 @@ inline long xcd_grid(long n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
 
 __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); }
 
+// 16-byte global accesses at DWORD alignment (global_load/store_dwordx4 only need 4-byte alignment on gfx9+): rasters
+// whose width or pitch is not a multiple of 4 cells -- an SRTM tile is 3601 wide -- keep the one-instruction-per-lane
+// row accesses of the strip kernels instead of dropping to one-cell-per-thread kernels.
+struct __attribute__((packed, aligned(4))) xrs_f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(8))) xrs_d2u { double x, y; };
+__device__ __forceinline__ xrs_f4u load_f4u(const float *p) { return *reinterpret_cast<const xrs_f4u *>(p); }
+__device__ __forceinline__ void store_f4u(float *p, float x, float y, float z, float w) {
+    xrs_f4u q; q.x = x; q.y = y; q.z = z; q.w = w;
+    *reinterpret_cast<xrs_f4u *>(p) = q;
+}
+
 // kxk_runs.hip: prefix-sum focal mean for large run-structured masks.  0 = launched, -1 = mask not
 // suitable (caller uses the tap kernels), > 0 = error.
 int try_launch_focal_mean_runs(const float *in, float *out, long rows, long cols, long ld_in, long ld_out,

@@ -425,9 +425,8 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
         if (__any(bad)) return false;          // caller re-runs this strip through the NaN-aware body
 #pragma unroll
         for (int r = 0; r < RB; ++r)
-            *reinterpret_cast<float4 *>(out + r * a.ld_out + loff) =
-                make_float4((float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
-                            (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
+            store_f4u(out + r * a.ld_out + loff, (float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                      (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
         return true;
     }
     // edge / NaN body: per output row, row-major over the window, skip NaN, count
@@ -451,9 +450,9 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
                     }
                 }
         }
-        *reinterpret_cast<float4 *>(out + r * a.ld_out + loff) =
-            make_float4((float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
-                        (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3])));
+        store_cols(out + r * a.ld_out + loff, (float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
+                   (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3])),
+                   (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4));
     }
     return true;
 }
@@ -537,8 +536,9 @@ __device__ __forceinline__ void focal_stats_direct_rows(const KxkArgs &a, long x
         const long off = (y0 + r) * a.ld_out + x_tile + loff;
         const bool none[4] = {CAREFUL && !cnt[0], CAREFUL && !cnt[1], CAREFUL && !cnt[2], CAREFUL && !cnt[3]};
         const float qn = nan_f32();
+        const int nown = INTERIOR ? 4 : (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4);
         auto put = [&](int stat, float x0, float x1, float x2, float x3) {
-            if (a.out[stat]) *reinterpret_cast<float4 *>(a.out[stat] + off) = make_float4(x0, x1, x2, x3);
+            if (a.out[stat]) store_cols(a.out[stat] + off, x0, x1, x2, x3, nown);
         };
         put(XRS_STAT_MEAN, (float)mean[0], (float)mean[1], (float)mean[2], (float)mean[3]);
         put(XRS_STAT_MAX, none[0] ? qn : mx[0], none[1] ? qn : mx[1], none[2] ? qn : mx[2], none[3] ? qn : mx[3]);
@@ -629,8 +629,8 @@ __global__ void __launch_bounds__(256) convolve_direct_kernel(const KxkArgs a) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         if (!interior && y0 + r >= a.rows) break;
-        *reinterpret_cast<float4 *>(a.out[0] + (y0 + r) * a.ld_out + x_tile + loff) =
-            make_float4((float)acc[r][0], (float)acc[r][1], (float)acc[r][2], (float)acc[r][3]);
+        store_cols(a.out[0] + (y0 + r) * a.ld_out + x_tile + loff, (float)acc[r][0], (float)acc[r][1], (float)acc[r][2],
+                   (float)acc[r][3], interior ? 4 : (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4));
     }
 }
 
@@ -714,14 +714,14 @@ template <typename InT>
 __device__ __forceinline__ void load6(const InT *p, bool has_l, bool has_r, double (&d)[6]);
 template <>
 __device__ __forceinline__ void load6<float>(const float *p, bool has_l, bool has_r, double (&d)[6]) {
-    const float4 c = *reinterpret_cast<const float4 *>(p);
+    const xrs_f4u c = load_f4u(p);
     d[1] = c.x; d[2] = c.y; d[3] = c.z; d[4] = c.w;
     d[0] = has_l ? (double)p[-1] : nan("");
     d[5] = has_r ? (double)p[4] : nan("");
 }
 template <>
 __device__ __forceinline__ void load6<double>(const double *p, bool has_l, bool has_r, double (&d)[6]) {
-    const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+    const xrs_d2u a = reinterpret_cast<const xrs_d2u *>(p)[0], b = reinterpret_cast<const xrs_d2u *>(p)[1];
     d[1] = a.x; d[2] = a.y; d[3] = b.x; d[4] = b.y;
     d[0] = has_l ? p[-1] : nan("");
     d[5] = has_r ? p[4] : nan("");
@@ -785,9 +785,11 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
         if (!__any(bad)) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                double2 *q = reinterpret_cast<double2 *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
-                q[0] = make_double2(res[r][0], res[r][1]);
-                q[1] = make_double2(res[r][2], res[r][3]);
+                xrs_d2u *q = reinterpret_cast<xrs_d2u *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
+                xrs_d2u q0, q1;
+                q0.x = res[r][0]; q0.y = res[r][1]; q1.x = res[r][2]; q1.y = res[r][3];
+                q[0] = q0;
+                q[1] = q1;
             }
             return;
         }
@@ -941,7 +943,8 @@ bool prefer_strip() {
 
 template <bool MEAN_ONLY>
 int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
-    if (MEAN_ONLY && vec && !prefer_lds()) {
+    // (the register-strip kernels take any width / pitch / base address; `vec` only gates the LDS-tile kernels)
+    if (MEAN_ONLY && !prefer_lds()) {
         if (a.krows == 3 && a.kcols == 3) return launch_mean_direct<3, 3>(a, s);
         if (a.krows == 5 && a.kcols == 5) return launch_mean_direct<5, 5>(a, s);
         // (7x7 would need 256 VGPRs in registers: it stays on the LDS-tile kernel)
@@ -951,7 +954,7 @@ int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
         if (a.krows == 5 && a.kcols == 5) return launch_mean_fast<5, 5>(a, lds, s);
         if (a.krows == 7 && a.kcols == 7) return launch_mean_fast<7, 7>(a, lds, s);
     }
-    if (!MEAN_ONLY && vec && !prefer_lds()) {
+    if (!MEAN_ONLY && !prefer_lds()) {
         if (a.krows == 3 && a.kcols == 3) return launch_stats_direct<3, 3>(a, s);
         if (a.krows == 5 && a.kcols == 5) return launch_stats_direct<5, 5>(a, s);
     }
@@ -1004,8 +1007,8 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
         if (vec) hipLaunchKernelGGL((convolve_kernel<KH, KW, true>), dim3(grid), dim3(256), lds, s, a);  \
         else hipLaunchKernelGGL((convolve_kernel<KH, KW, false>), dim3(grid), dim3(256), lds, s, a);     \
     } while (0)
-    if (vec && !prefer_lds() && krows == 3 && kcols == 3) return launch_convolve_direct<3, 3>(a, s);
-    if (vec && !prefer_lds() && krows == 5 && kcols == 5) return launch_convolve_direct<5, 5>(a, s);
+    if (!prefer_lds() && krows == 3 && kcols == 3) return launch_convolve_direct<3, 3>(a, s);
+    if (!prefer_lds() && krows == 5 && kcols == 5) return launch_convolve_direct<5, 5>(a, s);
     if (krows == 3 && kcols == 3) XRS_CONV(3, 3);
     else if (krows == 5 && kcols == 5) XRS_CONV(5, 5);
     else XRS_CONV(0, 0);
@@ -1117,7 +1120,8 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
     a.in = in_dev; a.out = out_dev; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
     a.halo_top = halo_top; a.halo_bot = halo_bot; a.n_excl = n_excludes;
     for (int i = 0; i < n_excludes; ++i) a.excl[i] = excludes[i];
-    const bool vec = (cols % 4 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) && aligned16(in_dev) && aligned16(out_dev);
+    // (the strip kernel's 16-byte accesses only need dword / 8-byte alignment; its edge path is cell by cell)
+    const bool vec = true;
     if (vec) {
         const long tiles_x = (cols + TW - 1) / TW, n_tiles = tiles_x * ((rows + 15) / 16);
         const unsigned g = (unsigned)xcd_grid(n_tiles);

@@ -24,7 +24,16 @@ __device__ __forceinline__ double div_refined(double s, double n, double inv) {
     return isfinite(q2) ? q2 : q;          // (+-inf sums, empty windows: keep the inf / NaN)
 }
 
-struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at dword alignment
+typedef xrs_f4u F4U;                                                   // 16 bytes at dword alignment
+struct __attribute__((packed, aligned(4))) F2U { float x, y; };
+
+// results of a lane's 4 columns: one 16-byte store, or the first `n` cells for the last lane of a ragged row
+__device__ __forceinline__ void store_cols(float *p, float x, float y, float z, float w, int n) {
+    if (n >= 4) { store_f4u(p, x, y, z, w); return; }
+    p[0] = x;
+    if (n > 1) p[1] = y;
+    if (n > 2) p[2] = z;
+}
 
 // Strip loader shared by the register-resident kernels: v[r][0..NV) = columns x0-RX .. x0+3+RX of input
 // row y0 - RY + r (NaN outside the raster / the shard's halo rows).  INTERIOR: no predicates at all.
@@ -38,6 +47,10 @@ __device__ __forceinline__ void load_strip(const Args &a, long x_tile, long y0, 
     const float qnan = nan_f32();
     const bool has_l = INTERIOR || x0 >= 4;          // x0 is a multiple of 4 and RX <= 3
     const bool has_r = INTERIOR || x0 + 8 <= a.cols;
+    // (a lane whose own 4 columns or a halo block hang over the row's end -- widths that are not multiples of 4 --
+    //  loads cell by cell; every other lane uses the 16-byte forms, which only need dword alignment)
+    const bool ragged = !INTERIOR && x0 + 4 > a.cols;
+    const bool ragged_r = !INTERIOR && !ragged && x0 + 8 > a.cols && x0 + 4 < a.cols;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const long y = y0 - RY + r;
@@ -47,9 +60,15 @@ __device__ __forceinline__ void load_strip(const Args &a, long x_tile, long y0, 
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[r][i] = qnan;
         }
-        if (ok) {
+        if (ok && (ragged || ragged_r)) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const long xc = x0 - RX + i;
+                if (xc >= 0 && xc < a.cols) v[r][i] = p[i - RX];
+            }
+        } else if (ok) {
             if (!(RX == 2 && INTERIOR)) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(p);
+                const F4U c4 = *reinterpret_cast<const F4U *>(p);
                 v[r][RX] = c4.x; v[r][RX + 1] = c4.y; v[r][RX + 2] = c4.z; v[r][RX + 3] = c4.w;
             }
             if (RX == 1) {
@@ -62,11 +81,11 @@ __device__ __forceinline__ void load_strip(const Args &a, long x_tile, long y0, 
                 v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w;
                 v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
             } else if (RX == 2) {
-                if (has_l) { const float2 l2 = *reinterpret_cast<const float2 *>(p - 2); v[r][0] = l2.x; v[r][1] = l2.y; }
-                if (has_r) { const float2 r2 = *reinterpret_cast<const float2 *>(p + 4); v[r][NV - 2] = r2.x; v[r][NV - 1] = r2.y; }
+                if (has_l) { const F2U l2 = *reinterpret_cast<const F2U *>(p - 2); v[r][0] = l2.x; v[r][1] = l2.y; }
+                if (has_r) { const F2U r2 = *reinterpret_cast<const F2U *>(p + 4); v[r][NV - 2] = r2.x; v[r][NV - 1] = r2.y; }
             } else {                                           // RX == 3 (7-wide): aligned float4 each side, 3 used
-                if (has_l) { const float4 l4 = *reinterpret_cast<const float4 *>(p - 4); v[r][0] = l4.y; v[r][1] = l4.z; v[r][2] = l4.w; }
-                if (has_r) { const float4 r4 = *reinterpret_cast<const float4 *>(p + 4); v[r][NV - 3] = r4.x; v[r][NV - 2] = r4.y; v[r][NV - 1] = r4.z; }
+                if (has_l) { const F4U l4 = *reinterpret_cast<const F4U *>(p - 4); v[r][0] = l4.y; v[r][1] = l4.z; v[r][2] = l4.w; }
+                if (has_r) { const F4U r4 = *reinterpret_cast<const F4U *>(p + 4); v[r][NV - 3] = r4.x; v[r][NV - 2] = r4.y; v[r][NV - 1] = r4.z; }
             }
         }
     }

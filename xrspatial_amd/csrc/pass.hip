@@ -14,7 +14,7 @@
 // Arithmetic is the stand-alone kernels' (terrain_cells.h, focal_mean_direct_kernel): results are
 // bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
 //
-// Rasters / kernels outside the fast shape (pitch or width not a multiple of 4, mask larger than 5x5) run as
+// Any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane).  Masks larger than 5x5 run as
 // the separate launches -- same results, no fusion.
 #include "strip.h"
 #include "terrain_cells.h"
@@ -31,23 +31,36 @@ struct PassArgs {
     int halo_top, halo_bot;
     double inv8cx, inv8cy, curv_scale;
     float sin_alt, cos_alt, cos_az, sin_az;
+    int nt_stores;            // host-side choice of the kernel variant: every output row is 16-byte aligned
     unsigned mask_rows[5];    // bit kx of entry ky: tap (ky, kx) selected
     double inv_ntaps;
     long tiles_x, n_tiles;
 };
 
-// Results are written once and never read back by the kernel: non-temporal stores keep them from displacing the
-// halo rows / columns neighbouring strips re-read through L2 (A/B on one box: ~2 % on the fused kernels).
+// A lane's 4 results.  NT (compile-time: every output row 16-byte aligned): one non-temporal 16-byte store -- results
+// are written once and never read back, so they should not displace the halo rows / columns neighbouring strips re-read
+// through L2 (same-box A/B: 2-4 % on the fused kernels; as a RUN-time flag it cost registers and 29 % on the slope
+// variant).  Otherwise one 16-byte store at dword alignment (any pitch), or the first `n` cells for the last lane of a
+// row whose width is not a multiple of 4.
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void put4(float *p, const float (&v)[4]) {
-    const v4f_nt q = {v[0], v[1], v[2], v[3]};
-    __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt *>(p));
+template <bool NT>
+__device__ __forceinline__ void put4(float *p, const float (&v)[4], int n = 4) {
+    if (n < 4) {
+        p[0] = v[0];
+        if (n > 1) p[1] = v[1];
+        if (n > 2) p[2] = v[2];
+    } else if (NT) {
+        const v4f_nt q = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt *>(p));
+    } else {
+        store_f4u(p, v[0], v[1], v[2], v[3]);
+    }
 }
 
 // OPS: compile-time superset of the terrain products this instantiation can emit (absent ones are skipped by
 // wave-uniform null tests, like terrain.hip's fused kernel).  Returns false when the interior fast path met a
 // non-finite window sum: the caller re-runs the focal part of the strip through the careful body.
-template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool TERRAIN>
+template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool TERRAIN, bool NT>
 __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
@@ -81,10 +94,11 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
                 if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
             }
             const long off = y * a.ld_out + x_tile;
-            if ((OPS & OP_SLOPE) && a.out[0]) put4(a.out[0] + off + loff, o_slope);
-            if ((OPS & OP_ASPECT) && a.out[1]) put4(a.out[1] + off + loff, o_aspect);
-            if ((OPS & OP_CURV) && a.out[2]) put4(a.out[2] + off + loff, o_curv);
-            if ((OPS & OP_HILL) && a.out[3]) put4(a.out[3] + off + loff, o_hill);
+            const int nown = INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4);
+            if ((OPS & OP_SLOPE) && a.out[0]) put4<NT>(a.out[0] + off + loff, o_slope, nown);
+            if ((OPS & OP_ASPECT) && a.out[1]) put4<NT>(a.out[1] + off + loff, o_aspect, nown);
+            if ((OPS & OP_CURV) && a.out[2]) put4<NT>(a.out[2] + off + loff, o_curv, nown);
+            if ((OPS & OP_HILL) && a.out[3]) put4<NT>(a.out[3] + off + loff, o_hill, nown);
         }
     }
 
@@ -124,7 +138,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
         for (int r = 0; r < RB; ++r) {
             const float m[4] = {(float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
                                 (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)};
-            put4(fout + r * a.ld_out + loff, m);
+            put4<NT>(fout + r * a.ld_out + loff, m);
         }
     } else {
 #pragma unroll
@@ -149,14 +163,14 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             }
             const float m[4] = {(float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
                                 (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3]))};
-            put4(fout + r * a.ld_out + loff, m);
+            put4<NT>(fout + r * a.ld_out + loff, m, (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
         }
     }
 
     return true;
 }
 
-template <int OPS, int KH, int KW, int RB>
+template <int OPS, int KH, int KW, int RB, bool NT>
 __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) raster_pass_kernel(const PassArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles);
     if (t < 0) return;
@@ -167,12 +181,12 @@ __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) r
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!pass_body<OPS, KH, KW, RB, true, true>(a, x_tile, y0, lane))
-            pass_body<OPS, KH, KW, RB, false, false>(a, x_tile, y0, lane);      // NaN / inf under a window
+        if (!pass_body<OPS, KH, KW, RB, true, true, NT>(a, x_tile, y0, lane))
+            pass_body<OPS, KH, KW, RB, false, false, NT>(a, x_tile, y0, lane);      // NaN / inf under a window
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    pass_body<OPS, KH, KW, RB, false, true>(a, x_tile, y0, lane);
+    pass_body<OPS, KH, KW, RB, false, true, NT>(a, x_tile, y0, lane);
 }
 
 template <int OPS, int K>
@@ -182,7 +196,10 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
     const long grid = xcd_grid(a.n_tiles);
     if (grid > 0x7fffffffL) return fail("raster pass: raster too large for one launch");
-    hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (a.nt_stores)
+        hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -225,12 +242,14 @@ extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float 
     if (rows <= 0 || cols <= 0 || (!ops && !focal_mean_dev)) return 0;
 
     const int fused_ops = ops & FUSABLE;
-    bool fast = fused_ops && focal_mean_dev && krows == kcols && (krows == 3 || krows == 5) && cols % 4 == 0 &&
-                ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= cols && ld_out >= cols && aligned16(in_dev) &&
-                aligned16(focal_mean_dev) && halo_top >= 0 && halo_bot >= 0;
+    // (any width / pitch / base address: the strip layout's 16-byte accesses only need dword alignment)
+    bool fast = fused_ops && focal_mean_dev && krows == kcols && (krows == 3 || krows == 5) && ld_in >= cols &&
+                ld_out >= cols && halo_top >= 0 && halo_bot >= 0;
     float *outs[4] = {slope_dev, aspect_dev, curvature_dev, hillshade_dev};
+    bool nt = ld_out % 4 == 0 && aligned16(focal_mean_dev);
     for (int i = 0; i < 4; ++i)
-        if (fused_ops >> i & 1) fast = fast && aligned16(outs[i]);
+        if (fused_ops >> i & 1) nt = nt && aligned16(outs[i]);
+
     int ntaps = 0;
     if (fast) {
         for (int i = 0; i < krows * kcols; ++i)
@@ -262,6 +281,7 @@ extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float 
     for (int i = 0; i < 4; ++i) a.out[i] = (fused_ops >> i & 1) ? outs[i] : nullptr;
     a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
     a.halo_top = halo_top; a.halo_bot = halo_bot;
+    a.nt_stores = nt ? 1 : 0;
     a.inv8cx = 1.0 / (8 * cellsize_x);
     a.inv8cy = 1.0 / (8 * cellsize_y);
     const double cs = (cellsize_x + cellsize_y) / 2;       // curvature.py:241

@@ -240,6 +240,11 @@ int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev
  *   xrs_zonal_presence  -> present_dev[id - zmin] = 1 for every finite id in [zmin, zmin + range)
  *   xrs_zonal_index     -> idx_dev[cell] = lut_dev[id - zmin], -1 for non-finite / out-of-range ids */
 int xrs_zonal_scan(const void *zones_dev, int zone_dtype, int64_t n, void *result32_dev, void *stream);
+/* scan + presence in ONE read for int32 ids: ids inside the optimistic window [0, window) are marked in present_dev
+ * (window bytes) during the scan; if the scan result shows 0 <= zmin and zmax < window the map is complete and
+ * xrs_zonal_presence is not needed. */
+int xrs_zonal_scan_presence_i32(const int32_t *zones_dev, int64_t n, void *result32_dev, unsigned char *present_dev,
+                                int window, void *stream);
 int xrs_zonal_presence(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,
                        unsigned char *present_dev, void *stream);
 int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,

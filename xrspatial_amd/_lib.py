@@ -99,6 +99,7 @@ _PROTOTYPES = {
     "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],
     "xrs_zonal_scan": [c_void_p, c_int, c_int64, c_void_p, c_void_p],
+    "xrs_zonal_scan_presence_i32": [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "xrs_zonal_presence": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p],
     "xrs_zonal_index": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p, c_void_p],
     "xrs_crosstab_counts": [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],

@@ -128,6 +128,41 @@ __global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResul
     }
 }
 
+// Pass 1 and pass 2 in one read of the raster for the common case of small non-negative int32 ids: next to the
+// (min, max, count) scan, ids inside the optimistic window [0, window) are marked in `present` right away; if the scan
+// then shows every id inside the window, the separate presence pass is not needed.
+__global__ void __launch_bounds__(256) scan_presence_i32_kernel(const int32_t *z, long n, ScanResult *res,
+                                                                unsigned char *present, int window, const int vec) {
+    int mn = 0x7fffffff, mx = (int)0x80000000;
+    unsigned cnt = 0;
+    int last = -1;
+    for_each_chunked(z, n, vec != 0, [&](long, int32_t v) {
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        ++cnt;
+        if (v != last && (unsigned)v < (unsigned)window) present[v] = 1;    // benign race: every writer stores 1
+        last = v;
+    });
+    rocprim::warp_reduce<int, 64>::storage_type si;
+    rocprim::warp_reduce<unsigned, 64>::storage_type su;
+    rocprim::warp_reduce<int, 64>().reduce(mn, mn, si, rocprim::minimum<int>());
+    rocprim::warp_reduce<int, 64>().reduce(mx, mx, si, rocprim::maximum<int>());
+    rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
+    __shared__ int wmn[4], wmx[4];
+    __shared__ unsigned wc[4];
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; wmn[w] = mn; wmx[w] = mx; wc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned c = wc[0] + wc[1] + wc[2] + wc[3];
+        if (c) {
+            const int a = min(min(wmn[0], wmn[1]), min(wmn[2], wmn[3])), b = max(max(wmx[0], wmx[1]), max(wmx[2], wmx[3]));
+            atomic_min_f64(&res->zmin, (double)a);
+            atomic_max_f64(&res->zmax, (double)b);
+            atomicAdd(&res->n_finite, (unsigned long long)c);
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) presence_kernel(const T *z, long n, double zmin, long range,
                                                        unsigned char *present, const int vec) {
@@ -209,6 +244,20 @@ int xrs_zonal_scan(const void *zones_dev, int zone_dtype, int64_t n, void *resul
 #define CALL(T) scan_impl<T>(zones_dev, n, result32_dev, as_stream(stream))
     XRS_DISPATCH_ZTYPE(zone_dtype, CALL)
 #undef CALL
+}
+
+int xrs_zonal_scan_presence_i32(const int32_t *zones_dev, int64_t n, void *result32_dev, unsigned char *present_dev,
+                                int window, void *stream) {
+    if (n < 0 || window <= 0) return fail("xrs_zonal_scan_presence_i32: bad size");
+    if (!result32_dev || !present_dev || (n && !zones_dev)) return fail("xrs_zonal_scan_presence_i32: null pointer");
+    hipStream_t s = as_stream(stream);
+    ScanResult *r = static_cast<ScanResult *>(result32_dev);
+    hipLaunchKernelGGL(scan_init_kernel, dim3(1), dim3(1), 0, s, r);
+    XRS_HIP(hipMemsetAsync(present_dev, 0, (size_t)window, s));
+    if (n) hipLaunchKernelGGL(scan_presence_i32_kernel, dim3(grid_for(n)), dim3(256), 0, s, zones_dev, (long)n, r, present_dev,
+                              window, aligned16(zones_dev) ? 1 : 0);
+    XRS_LAUNCH_CHECK();
+    return 0;
 }
 
 int xrs_zonal_presence(const void *zones_dev, int zone_dtype, int64_t n, double zmin, int64_t range,

@@ -58,6 +58,8 @@ def _dense_zone_index(zones: np.ndarray):
     return uniq, idx.reshape(zones.shape)
 
 
+_OPTIMISTIC_WINDOW = 1 << 20         # bytes of the presence map filled during the scan of int32 zone ids
+
 _ZONE_DTYPE_CODE = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
 
 
@@ -70,7 +72,13 @@ def _zone_table_device(zones_dev: DeviceArray):
     stream = get_stream()
     n = zones_dev.size
     res = DeviceArray((4,), np.float64)
-    _lib.call("xrs_zonal_scan", zones_dev.ptr, code, n, res.ptr, stream)
+    window_map = None
+    if code == 0:
+        # int32 ids: the scan marks ids in [0, 2^20) on the way, which usually makes the presence pass unnecessary
+        window_map = DeviceArray((_OPTIMISTIC_WINDOW,), np.uint8)
+        _lib.call("xrs_zonal_scan_presence_i32", zones_dev.ptr, n, res.ptr, window_map.ptr, _OPTIMISTIC_WINDOW, stream)
+    else:
+        _lib.call("xrs_zonal_scan", zones_dev.ptr, code, n, res.ptr, stream)
     raw = res.get(stream)
     zmin, zmax = raw[0], raw[1]
     n_finite = int(raw[2:3].view(np.uint64)[0])
@@ -78,9 +86,12 @@ def _zone_table_device(zones_dev: DeviceArray):
     if n_finite == 0 or not all_integral or zmax - zmin >= _DENSE_RANGE_LIMIT:
         return None
     rng = int(zmax - zmin) + 1
-    present = DeviceArray((rng,), np.uint8)
-    _lib.call("xrs_zonal_presence", zones_dev.ptr, code, n, float(zmin), rng, present.ptr, stream)
-    mask = present.get(stream).astype(bool)
+    if window_map is not None and zmin >= 0 and zmax < _OPTIMISTIC_WINDOW:
+        mask = window_map.get(stream)[int(zmin):int(zmax) + 1].astype(bool)
+    else:
+        present = DeviceArray((rng,), np.uint8)
+        _lib.call("xrs_zonal_presence", zones_dev.ptr, code, n, float(zmin), rng, present.ptr, stream)
+        mask = present.get(stream).astype(bool)
     lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
     uniq = (np.flatnonzero(mask).astype(np.float64) + zmin).astype(zones_dev.dtype)
     return uniq, zmin, rng, DeviceArray.from_numpy(lut)

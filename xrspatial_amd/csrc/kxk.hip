@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
 // Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
 // row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
 // sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
-template <int KH, int KW, int RB, bool INTERIOR>
+template <int KH, int KW, int RB, bool INTERIOR, bool CAREFUL>
 __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
@@ -393,7 +393,7 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
     load_strip<KH, KW, RB, INTERIOR>(a, x_tile, y0, lane, v);
 
     float *out = a.out[XRS_STAT_MEAN] + y0 * a.ld_out + x_tile;      // scalar
-    if (INTERIOR) {
+    if (!CAREFUL) {
         double acc[RB][4];
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -429,30 +429,49 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
                       (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
         return true;
     }
-    // edge / NaN body: per output row, row-major over the window, skip NaN, count
+    // edge / NaN body
+    {
+        // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
+        // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
+        // the sum and 0 to a float32 count (exact far beyond 25 taps).  Rows are consumed as they are walked, so this
+        // body needs no more registers than the fast one (the per-output form it replaces spilled).
+        double acc[RB][4];
+        float cnt[RB][4];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        if (y0 + r >= a.rows) break;
-        double sum[4] = {0, 0, 0, 0};
-        int cnt[4] = {0, 0, 0, 0};
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-            const unsigned bits = (unsigned)a.mask_rows[ky];
+            for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx)
-                if (bits >> kx & 1u) {
+        for (int ir = 0; ir < NR; ++ir) {
+            double z[NV];
+            float c[NV];
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        const float x = v[r + ky][kx + o];
-                        const bool okv = !isnan(x);
-                        sum[o] += okv ? (double)x : 0.0;
-                        cnt[o] += okv ? 1 : 0;
+            for (int i = 0; i < NV; ++i) {
+                const bool okv = !isnan(v[ir][i]);
+                z[i] = okv ? (double)v[ir][i] : 0.0;
+                c[i] = okv ? 1.0f : 0.0f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = (unsigned)a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
                     }
-                }
+            }
         }
-        store_cols(out + r * a.ld_out + loff, (float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
-                   (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3])),
-                   (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4));
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (!INTERIOR && y0 + r >= a.rows) break;
+            store_cols(out + r * a.ld_out + loff, (float)(acc[r][0] * rcp_count((int)cnt[r][0])),
+                       (float)(acc[r][1] * rcp_count((int)cnt[r][1])), (float)(acc[r][2] * rcp_count((int)cnt[r][2])),
+                       (float)(acc[r][3] * rcp_count((int)cnt[r][3])),
+                       INTERIOR ? 4 : (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4));
+        }
     }
     return true;
 }
@@ -467,9 +486,13 @@ __global__ void __launch_bounds__(256, 4) focal_mean_direct_kernel(const KxkArgs
     const long x_tile = tx * TW;
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
-    if (strip_is_interior<KH, KW, RB>(a, x_tile, y0) && focal_mean_direct_body<KH, KW, RB, true>(a, x_tile, y0, lane)) return;
+    if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
+        if (!focal_mean_direct_body<KH, KW, RB, true, false>(a, x_tile, y0, lane))
+            focal_mean_direct_body<KH, KW, RB, true, true>(a, x_tile, y0, lane);    // NaN / inf under a window: NaN-aware, same loads
+        return;
+    }
     if (x_tile + lane * 4 >= a.cols) return;
-    focal_mean_direct_body<KH, KW, RB, false>(a, x_tile, y0, lane);
+    focal_mean_direct_body<KH, KW, RB, false, true>(a, x_tile, y0, lane);
 }
 
 // All seven statistics, compile-time 3x3 / 5x5 shape, register-resident strip (same layout as the mean
@@ -793,6 +816,39 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
             }
             return;
         }
+        // a NaN / inf under some window of this strip: NaN-skipping, counting sums, one output row at a time from
+        // re-loaded rows (L1 hits; a rolled loop so that this path does not raise the kernel's register count -- done
+        // from the fast path's registers it doubled it).  The window is complete for an interior strip, so this is
+        // the reference's loop without its bounds tests.
+#pragma unroll 1
+        for (int r = 0; r < RB; ++r) {
+            double w[3][6];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) load6<InT>(in + (y0 - 1 + r + ky) * a.ld_in + x_tile + loff, true, true, w[ky]);
+            double m[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                double s = 0.0;
+                int n = 0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const double x = w[ky][o + kx];
+                        const bool okv = !isnan(x);
+                        s += okv ? x : 0.0;
+                        n += okv ? 1 : 0;
+                    }
+                const double c = w[1][o + 1];
+                m[o] = is_excluded(a, c) ? c : s / (double)n;           // 0/0 -> NaN like the reference
+            }
+            xrs_d2u *q = reinterpret_cast<xrs_d2u *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
+            xrs_d2u q0, q1;
+            q0.x = m[0]; q0.y = m[1]; q1.x = m[2]; q1.y = m[3];
+            q[0] = q0;
+            q[1] = q1;
+        }
+        return;
     }
     // edge / NaN strip: the reference's loop, cell by cell (clamped window, NaN skipped, 0/0 -> NaN)
     if (x0 >= a.cols) return;

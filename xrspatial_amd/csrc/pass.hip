@@ -60,7 +60,7 @@ __device__ __forceinline__ void put4(float *p, const float (&v)[4], int n = 4) {
 // OPS: compile-time superset of the terrain products this instantiation can emit (absent ones are skipped by
 // wave-uniform null tests, like terrain.hip's fused kernel).  Returns false when the interior fast path met a
 // non-finite window sum: the caller re-runs the focal part of the strip through the careful body.
-template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool TERRAIN, bool NT>
+template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, bool TERRAIN, bool NT>
 __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
@@ -104,7 +104,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
 
     // ---- focal mean (float64 accumulation in row-major tap order == numba nanmean over the window)
     float *fout = a.focal + y0 * a.ld_out + x_tile;
-    if (INTERIOR) {
+    if (!CAREFUL) {
         double acc[RB][4];
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -141,29 +141,45 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             put4<NT>(fout + r * a.ld_out + loff, m);
         }
     } else {
+        // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
+        // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
+        // the sum and 0 to a float32 count (exact far beyond 25 taps).  Rows are consumed as they are walked, so this
+        // body needs no more registers than the fast one (the per-output form it replaces spilled).
+        double acc[RB][4];
+        float cnt[RB][4];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (y0 + r >= a.rows) break;
-            double sum[4] = {0, 0, 0, 0};
-            int cnt[4] = {0, 0, 0, 0};
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
+#pragma unroll
+        for (int ir = 0; ir < NR; ++ir) {
+            double z[NV];
+            float c[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool okv = !isnan(v[ir][i]);
+                z[i] = okv ? (double)v[ir][i] : 0.0;
+                c[i] = okv ? 1.0f : 0.0f;
+            }
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
-                const unsigned bits = a.mask_rows[ky];
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = (unsigned)a.mask_rows[ky];
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
                     if (bits >> kx & 1u) {
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) {
-                            const float x = v[r + ky][kx + o];
-                            const bool okv = !isnan(x);
-                            sum[o] += okv ? (double)x : 0.0;
-                            cnt[o] += okv ? 1 : 0;
-                        }
+                        for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
                     }
             }
-            const float m[4] = {(float)(sum[0] * rcp_count(cnt[0])), (float)(sum[1] * rcp_count(cnt[1])),
-                                (float)(sum[2] * rcp_count(cnt[2])), (float)(sum[3] * rcp_count(cnt[3]))};
-            put4<NT>(fout + r * a.ld_out + loff, m, (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (!INTERIOR && y0 + r >= a.rows) break;
+            const float m[4] = {(float)(acc[r][0] * rcp_count((int)cnt[r][0])), (float)(acc[r][1] * rcp_count((int)cnt[r][1])),
+                                (float)(acc[r][2] * rcp_count((int)cnt[r][2])), (float)(acc[r][3] * rcp_count((int)cnt[r][3]))};
+            put4<NT>(fout + r * a.ld_out + loff, m, INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
         }
     }
 
@@ -181,12 +197,13 @@ __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) r
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!pass_body<OPS, KH, KW, RB, true, true, NT>(a, x_tile, y0, lane))
-            pass_body<OPS, KH, KW, RB, false, false, NT>(a, x_tile, y0, lane);      // NaN / inf under a window
+        if (!pass_body<OPS, KH, KW, RB, true, false, true, NT>(a, x_tile, y0, lane))
+            pass_body<OPS, KH, KW, RB, true, true, false, NT>(a, x_tile, y0, lane);  // NaN / inf under a window: focal part
+                                                                                     // again, NaN-aware, same loads
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    pass_body<OPS, KH, KW, RB, false, true, NT>(a, x_tile, y0, lane);
+    pass_body<OPS, KH, KW, RB, false, true, true, NT>(a, x_tile, y0, lane);
 }
 
 template <int OPS, int K>

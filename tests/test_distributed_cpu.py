@@ -12,7 +12,7 @@ import pytest
 
 from oracle import xrs_oracle as orc
 from tests import synth
-from xrspatial_amd.distributed import combine_zonal_partials, shard_halos, shard_rows
+from xrspatial_amd.distributed import combine_zonal_partials, halo_plan, shard_halos, shard_rows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -31,6 +31,34 @@ def test_shard_helpers():
         assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
     assert shard_halos(1, 0, 2) == (0, 0)
     assert [shard_halos(3, r, 2) for r in range(3)] == [(0, 2), (2, 2), (2, 0)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_overlapped_halo_plan_reproduces_the_monolithic_pass(world):
+    """bench.py's N > 1 step launches each shard as interior + two edge pieces (distributed.halo_plan) so that the
+    halo exchange hides behind the interior rows.  With the oracle standing in for the kernel and its row-range /
+    halo contract (a piece sees `halo_top` rows above and `halo_bot` below its first / last owned row, nothing beyond),
+    every piece of every shard must reproduce the monolithic result -- for the 5x5 focal mean and the 3x3 hillshade."""
+    H, W, HALO, EDGE = 203, 40, 2, 16
+    full = synth.smooth_dem((H, W), nan_frac=0.02)
+    k = orc.circle_kernel(1, 1, 2)
+    want_f, want_h = orc.focal_apply(full, k, 'mean'), orc.hillshade(full)
+    got_f, got_h = np.full_like(want_f, -1.0), np.full_like(want_h, -1.0)
+    for rank in range(world):
+        y0, y1 = shard_rows(H, world, rank)
+        ht, hb = shard_halos(world, rank, HALO)
+        pieces = halo_plan(y1 - y0, HALO, EDGE, ht, hb)
+        assert sorted(p[0] for p in pieces)[0] == 0 and sum(p[1] for p in pieces) == y1 - y0
+        assert [p[4] for p in pieces] == ([False, True, True] if y1 - y0 > 2 * EDGE else [True])
+        for first, n, top, bot, _ in pieces:
+            a, b = y0 + first, y0 + first + n                    # global rows of the piece
+            view = full[a - top:b + bot]                          # what the kernel may read
+            got_f[a:b] = orc.focal_apply(view, k, 'mean')[top:top + n]
+            got_h[a:b] = orc.hillshade(view)[top:top + n]
+    np.testing.assert_array_equal(got_f, want_f)
+    np.testing.assert_array_equal(got_h, want_h)
+    with pytest.raises(ValueError):
+        halo_plan(100, 4, 2, 0, 0)
 
 
 def test_combine_partials():

@@ -88,6 +88,20 @@ class Comm:
             self.handle = None
 
 
+def halo_plan(rows: int, halo: int, edge: int, halo_top: int, halo_bot: int):
+    """How one step of a row-sharded stencil pass is cut so that the halo exchange hides behind it:
+    [(first_row, n_rows, halo_top, halo_bot, needs_exchange)], covering the shard's rows exactly once.  The interior
+    piece uses the shard's own rows as its halos and can start at once; the two `edge`-row pieces wait for the
+    neighbours' rows.  A shard shorter than two edges is launched whole, after the exchange."""
+    if edge < halo:
+        raise ValueError("edge must cover the halo")
+    if rows <= 2 * edge:
+        return [(0, rows, halo_top, halo_bot, True)]
+    return [(edge, rows - 2 * edge, halo, halo, False),
+            (0, edge, halo_top, halo, True),
+            (rows - edge, edge, halo, halo_bot, True)]
+
+
 class OverlappedHalo:
     """Hide the halo exchange of a row-sharded stencil pass behind the pass itself.
 
@@ -119,13 +133,7 @@ class OverlappedHalo:
         _lib.call("xrs_event_record", self.ev_done, self.main)
 
     def plan(self, halo_top: int, halo_bot: int):
-        """[(first_row, n_rows, halo_top, halo_bot, needs_exchange)] covering the shard exactly once."""
-        rows, e, h = self.rows, self.edge, self.halo
-        if rows <= 2 * e:                       # shard too short to split: everything waits for the exchange
-            return [(0, rows, halo_top, halo_bot, True)]
-        return [(e, rows - 2 * e, h, h, False),
-                (0, e, halo_top, h, True),
-                (rows - e, e, h, halo_bot, True)]
+        return halo_plan(self.rows, self.halo, self.edge, halo_top, halo_bot)
 
     def step(self, exchange, launch, halo_top: int, halo_bot: int):
         # the exchange overwrites halo rows the previous step's edge launches may still be reading

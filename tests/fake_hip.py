@@ -1,0 +1,164 @@
+"""CPU stand-in for the handful of libxrs_hip.so entry points the row-sharded host code calls -- TEST INFRASTRUCTURE.
+
+`install(monkeypatch)` replaces `xrspatial_amd._lib.call / load / require_device` so that "device" pointers are host
+addresses, copies are memmoves and every stencil entry point is answered by the CPU oracle under the C ABI's own
+row-range / halo contract (a call sees `halo_top` rows above and `halo_bot` rows below the rows it owns and nothing
+else).  That lets the `-m "not gpu"` suite drive the HOST logic of xrspatial_amd.sharded for real -- transports, halo
+bookkeeping, chaining, the zone-id agreement of zonal.stats -- in gloo process groups on a box without a GPU.  The
+product never imports this module (it has no CPU path); the kernels themselves are covered by the `-m gpu` tests."""
+import ctypes
+
+import numpy as np
+
+from oracle import xrs_oracle as orc
+
+_live = {}      # address -> ctypes buffer (keeps "device" allocations alive)
+
+
+def _arr(ptr, n, dtype):
+    dtype = np.dtype(dtype)
+    ptr = ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)
+    buf = (ctypes.c_char * (int(n) * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+def _plane(ptr, rows, cols, ld, ht, hb, dtype=np.float32):
+    """Rows [-ht, rows + hb) of the plane whose first owned row is at `ptr`."""
+    ptr = ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)
+    isz = np.dtype(dtype).itemsize
+    flat = _arr(ptr - ht * ld * isz, (rows + ht + hb) * ld, dtype)
+    return flat.reshape(rows + ht + hb, ld)[:, :cols]
+
+
+def _put(ptr, rows, cols, ld, values, dtype=np.float32):
+    _plane(ptr, rows, cols, ld, 0, 0, dtype)[...] = values
+
+
+def _host_ptr(p):
+    return p.value if isinstance(p, ctypes.c_void_p) else int(p)
+
+
+def _stencil(fn, in_ptr, out_ptr, rows, cols, ld_in, ld_out, ht, hb, out_dtype=np.float32):
+    view = _plane(in_ptr, rows, cols, ld_in, ht, hb).copy()
+    with np.errstate(all="ignore"):
+        _put(out_ptr, rows, cols, ld_out, fn(view)[ht:ht + rows], out_dtype)
+
+
+def _kernel(ptr, kr, kc):
+    return _arr(ptr, kr * kc, np.float64).reshape(kr, kc).copy()
+
+
+def call(name, *a):
+    if name == "xrs_malloc":
+        buf = ctypes.create_string_buffer(max(int(a[1]), 16) + 64)
+        addr = (ctypes.addressof(buf) + 63) // 64 * 64
+        _live[addr] = buf
+        a[0]._obj.value = addr
+    elif name in ("xrs_memcpy_h2d", "xrs_memcpy_d2h", "xrs_memcpy_d2d"):
+        ctypes.memmove(_host_ptr(a[0]), _host_ptr(a[1]), int(a[2]))
+    elif name in ("xrs_stream_sync", "xrs_device_sync"):
+        pass
+    elif name == "xrs_slope_f32":
+        i, o, rows, cols, ld_i, ld_o, cx, cy, ht, hb, _ = a
+        _stencil(lambda v: orc.slope(v, cx, cy), i, o, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_aspect_f32":
+        i, o, rows, cols, ld_i, ld_o, ht, hb, _ = a
+        _stencil(orc.aspect, i, o, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_curvature_f32":
+        i, o, rows, cols, ld_i, ld_o, cs, ht, hb, _ = a
+        _stencil(lambda v: orc.curvature(v, cs), i, o, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_hillshade_f32":
+        i, o, f64, rows, cols, ld_i, ld_o, az, alt, ht, hb, _ = a
+        _stencil(lambda v: orc.hillshade(v, az, alt), i, o, rows, cols, ld_i, ld_o, ht, hb, np.float64 if f64 else np.float32)
+    elif name == "xrs_raster_pass_f32":
+        i, o_s, o_a, o_c, o_h, o_f, k, kr, kc, _, rows, cols, ld_i, ld_o, cx, cy, az, alt, ht, hb, _ = a
+        if o_s:
+            _stencil(lambda v: orc.slope(v, cx, cy), i, o_s, rows, cols, ld_i, ld_o, ht, hb)
+        if o_a:
+            _stencil(orc.aspect, i, o_a, rows, cols, ld_i, ld_o, ht, hb)
+        if o_c:
+            _stencil(lambda v: orc.curvature(v, cx), i, o_c, rows, cols, ld_i, ld_o, ht, hb)
+        if o_h:
+            _stencil(lambda v: orc.hillshade(v, az, alt), i, o_h, rows, cols, ld_i, ld_o, ht, hb)
+        if o_f:
+            kern = _kernel(k, kr, kc)
+            _stencil(lambda v: orc.focal_apply(v, kern, 'mean'), i, o_f, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_focal_stats_f32":
+        i, outs, mask, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
+        kern = _kernel(k, kr, kc)
+        for idx, stat in enumerate(orc.FOCAL_STATS):
+            if mask >> idx & 1:
+                _stencil(lambda v: orc.focal_apply(v, kern, stat), i, outs[idx], rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_focal_mean3x3":
+        i, is64, o, rows, cols, ld_i, ld_o, ex, nex, ht, hb, _ = a
+        excl = tuple(float(v) for v in _arr(ex, nex, np.float64)) if nex else ()
+        view = _plane(i, rows, cols, ld_i, ht, hb, np.float64 if is64 else np.float32).copy()
+        _put(o, rows, cols, ld_o, orc.focal_mean3x3(view, excl)[ht:ht + rows], np.float64)
+    elif name == "xrs_convolve2d_f32":
+        i, o, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
+        kern = _kernel(k, kr, kc)
+        _stencil(lambda v: orc.convolve_2d(v, kern), i, o, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_normalized_ratio_f32":
+        x, y, o, n, _ = a
+        with np.errstate(all="ignore"):
+            _arr(o, n, np.float32)[...] = orc.normalized_ratio(_arr(x, n, np.float32), _arr(y, n, np.float32))
+    elif name == "xrs_zonal_scan":
+        z, code, n, res, _ = a
+        assert code == 0
+        ids = _arr(z, n, np.int32)
+        out = _arr(res, 4, np.float64)
+        out[0], out[1] = (ids.min(), ids.max()) if n else (np.inf, -np.inf)
+        out[2:3].view(np.uint64)[0] = n
+        out[3:4].view(np.int32)[0] = 1
+    elif name == "xrs_zonal_presence":
+        z, code, n, zmin, rng, present, _ = a
+        ids = _arr(z, n, np.int32).astype(np.int64) - int(zmin)
+        flags = _arr(present, rng, np.uint8)
+        flags[...] = 0
+        flags[ids[(ids >= 0) & (ids < rng)]] = 1
+    elif name in ("xrs_zonal_init", "xrs_zonal_init_f64"):
+        cnt, s1, s2, mn, mx, nz, _ = a
+        vt = np.float64 if name.endswith("f64") else np.float32
+        _arr(cnt, nz, np.uint64)[...] = 0
+        _arr(s1, nz, np.float64)[...] = 0
+        _arr(s2, nz, np.float64)[...] = 0
+        _arr(mn, nz, vt)[...] = np.inf
+        _arr(mx, nz, vt)[...] = -np.inf
+    elif name in ("xrs_zonal_partials_lut_f32", "xrs_zonal_partials_lut_f64"):
+        z, zmin, rng, lut, vals, n, nz, nodata, has_nodata, cnt, s1, s2, mn, mx, _ = a
+        vt = np.float64 if name.endswith("f64") else np.float32
+        off = _arr(z, n, np.int32).astype(np.int64) - zmin
+        inside = (off >= 0) & (off < rng)
+        idx = np.where(inside, _arr(lut, rng, np.int32)[np.clip(off, 0, rng - 1)], -1)
+        v = _arr(vals, n, vt)
+        ok = (idx >= 0) & np.isfinite(v)
+        if has_nodata:
+            ok &= v != vt(nodata)
+        v64 = v[ok].astype(np.float64)
+        _arr(cnt, nz, np.uint64)[...] += np.bincount(idx[ok], minlength=nz).astype(np.uint64)
+        _arr(s1, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64, minlength=nz)
+        _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
+        np.minimum.at(_arr(mn, nz, vt), idx[ok], v[ok])
+        np.maximum.at(_arr(mx, nz, vt), idx[ok], v[ok])
+    else:
+        raise NotImplementedError(f"fake_hip: {name} is not emulated")
+
+
+class _FakeLib:
+    @staticmethod
+    def xrs_kxk_workspace_bytes(kr, kc):
+        return 16
+
+    @staticmethod
+    def xrs_free(ptr):
+        _live.pop(int(ptr), None)
+
+
+def install(monkeypatch=None):
+    """Route xrspatial_amd's C-ABI calls to the emulation (for the lifetime of the process if `monkeypatch` is None)."""
+    from xrspatial_amd import _lib
+    for attr, val in (("call", call), ("load", lambda: _FakeLib), ("require_device", lambda: None)):
+        if monkeypatch is None:
+            setattr(_lib, attr, val)
+        else:
+            monkeypatch.setattr(_lib, attr, val)

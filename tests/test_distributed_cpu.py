@@ -61,6 +61,48 @@ def test_overlapped_halo_plan_reproduces_the_monolithic_pass(world):
         halo_plan(100, 4, 2, 0, 0)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_api_host_logic(tmp_path, world):
+    """xrspatial_amd.sharded through the PUBLIC API in a gloo group, with tests/fake_hip.py answering the C ABI from the
+    oracle: ShardedArray / HostTransport bookkeeping (which rows travel, when, halo_top / halo_bot per rank, results
+    that are shards again, one fused pass, the zone-id agreement and the partial all-reduce of zonal.stats) must
+    reproduce the monolithic oracle results bit for bit.  The same worker runs on the GPU in test_gpu_parity.py."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), XRS_TEST_FAKE_HIP="1",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+    H, W = 150, 300
+    full = synth.smooth_dem((H, W), nan_frac=0.01)
+    red = synth.smooth_dem((H, W), seed=5) + 50.0
+    zones = synth.block_zones(H, W, n_zones=9, block=11).astype(np.int32)
+    k5, k7 = orc.circle_kernel(1, 1, 2), orc.circle_kernel(1, 1, 3)
+    with np.errstate(all="ignore"):
+        want = dict(slope=orc.slope(full, 30.0, 30.0), aspect=orc.aspect(full), curvature=orc.curvature(full, 30.0),
+                    hillshade=orc.hillshade(full).astype(np.float32), mean3=orc.focal_mean3x3(full, passes=3),
+                    apply5=orc.focal_apply(full, k5, 'mean'), max7=orc.focal_apply(full, k7, 'max'),
+                    conv5=orc.convolve_2d(full, k5), ndvi=orc.normalized_ratio(full, red),
+                    chain=orc.focal_mean3x3(orc.slope(full, 30.0, 30.0)))
+    want.update(fused_hillshade=want['hillshade'], fused_slope=want['slope'], fused_apply5=want['apply5'])
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    for name, ref in want.items():
+        got = np.empty_like(ref)
+        for p in parts:
+            got[int(p["y0"]):int(p["y1"])] = p[name]
+        np.testing.assert_array_equal(got, ref, err_msg=name)
+    names = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    table = orc.zonal_stats(zones, full.astype(np.float64), stats_funcs=names)
+    for p in parts:
+        np.testing.assert_array_equal(p['zonal_zone'], table['zone'])
+        for col in names:
+            np.testing.assert_allclose(p['zonal_' + col], table[col], rtol=1e-9, err_msg=col)
+
+
 def test_combine_partials():
     a = (np.array([1, 0], np.uint64), np.array([2.0, 0]), np.array([4.0, 0]), np.array([2.0, np.inf]), np.array([2.0, -np.inf]))
     b = (np.array([2, 1], np.uint64), np.array([3.0, 5]), np.array([5.0, 25]), np.array([1.0, 5]), np.array([2.0, 5]))

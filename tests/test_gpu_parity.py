@@ -3,6 +3,8 @@ oracle, on the reference's golden fixtures and on seeded synthetic rasters.  Nee
 
 Tolerances: float results within 1e-5 relative of the oracle (north_star), tightened where the
 arithmetic allows (bit-exact for per-cell indices, min/max/sum/range, counts)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1030,6 +1032,13 @@ def test_rccl_plumbing_single_gpu():
             np.testing.assert_allclose(x, y, rtol=1e-12)
         else:                # count, min, max: exact
             np.testing.assert_array_equal(x, y)
+    # the generic control-plane reduce rides on the same collective; float64 planes travel as 4-byte words
+    vals = np.array([3.5, -1.25, 7.0])
+    for op in ('sum', 'min', 'max'):
+        np.testing.assert_array_equal(comm.allreduce(vals, op), vals)
+    comm.halo_exchange(xs.DeviceArray.from_numpy(np.ones((8 + 4, 16), np.float64)), 2)
+    sharded = xs.ShardedArray.from_numpy(np.ones((8, 16), np.float32), comm, halo_cap=2)
+    assert sharded.halos(2) == (0, 0)
     comm.destroy()
 
 
@@ -1405,3 +1414,79 @@ def test_terrain_with_infinite_cells():
         np.testing.assert_allclose(apply(agg, k).data, corc.focal_apply(z, k, 'mean'), rtol=1e-6, equal_nan=True)
         np.testing.assert_allclose(convolution_2d(agg, k / k.sum()).data, corc.convolve_2d(z, k / k.sum()), rtol=1e-6, equal_nan=True)
         np.testing.assert_allclose(xs.focal.mean(agg).data, orc.focal_mean3x3(z), rtol=1e-12, equal_nan=True)
+
+
+# ---------------------------------------------------------------- row-sharded rasters through the public API
+def _sharded_reference_results():
+    """What the worker computes, from the single-GPU path (itself checked against the oracle above)."""
+    from xrspatial_amd import focal, zonal
+    H, W = 150, 300
+    full = synth.smooth_dem((H, W), nan_frac=0.01)
+    red = synth.smooth_dem((H, W), seed=5) + 50.0
+    zones_full = synth.block_zones(H, W, n_zones=9, block=11).astype(np.int32)
+    dev = lambda a: xs.DataArray(xs.DeviceArray.from_numpy(a), dims=['y', 'x'], attrs={'res': (30.0, 30.0)})   # noqa: E731
+    dem = dev(full)
+    k5, k7 = circle_kernel(1, 1, 2), circle_kernel(1, 1, 3)
+    want = {'slope': xs.slope(dem), 'aspect': xs.aspect(dem), 'curvature': xs.curvature(dem), 'hillshade': xs.hillshade(dem),
+            'mean3': focal.mean(dem, passes=3), 'apply5': apply(dem, k5), 'max7': apply(dem, k7, focal._calc_max),
+            'conv5': convolution_2d(dem, k5), 'ndvi': xs.ndvi(dem, dev(red)), 'chain': focal.mean(xs.slope(dem))}
+    want = {name: host(v.data) for name, v in want.items()}
+    want['fused_hillshade'], want['fused_slope'], want['fused_apply5'] = want['hillshade'], want['slope'], want['apply5']
+    table = zonal.stats(dev(zones_full), dem, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
+    return full, zones_full, want, table
+
+
+def test_sharded_array_single_rank_is_the_device_path():
+    """world = 1 (no transport): a ShardedArray-backed DataArray gives the DeviceArray-backed results."""
+    from xrspatial_amd import ShardedArray, focal, zonal
+    full, zones_full, want, table = _sharded_reference_results()
+    dem = xs.DataArray(ShardedArray.from_numpy(full), dims=['y', 'x'], attrs={'res': (30.0, 30.0)})
+    k5 = circle_kernel(1, 1, 2)
+    got = {'slope': xs.slope(dem), 'hillshade': xs.hillshade(dem), 'mean3': focal.mean(dem, passes=3), 'apply5': apply(dem, k5),
+           'conv5': convolution_2d(dem, k5), 'chain': focal.mean(xs.slope(dem))}
+    for name, res in got.items():
+        assert isinstance(res.data, ShardedArray), name
+        np.testing.assert_array_equal(res.data.get(), want[name], err_msg=name)
+    zt = zonal.stats(xs.DataArray(ShardedArray.from_numpy(zones_full), dims=['y', 'x']), dem,
+                     stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
+    assert list(zt.columns) == list(table.columns)
+    for col in table.columns:
+        np.testing.assert_allclose(np.asarray(zt[col], dtype=np.float64), np.asarray(table[col], dtype=np.float64), rtol=1e-12)
+    with pytest.raises(TypeError):
+        ShardedArray(4, 4, np.int8)
+    with pytest.raises(TypeError):
+        focal_stats(dem, k5)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_api_equals_single_gpu(tmp_path, world):
+    """`world` ranks (sharing this box's one GPU; halo rows through sharded.HostTransport over gloo) run the public API
+    on their row shards; stitched together the results equal the single-GPU results bit for bit, and every rank's
+    zonal table equals the single-GPU table."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", XRS_DEVICE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "sharded_worker.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out.decode()[-3000:]
+    full, zones_full, want, table = _sharded_reference_results()
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    for name, ref in want.items():
+        got = np.empty_like(ref)
+        for p in parts:
+            got[int(p["y0"]):int(p["y1"])] = p[name]
+        np.testing.assert_array_equal(got, ref, err_msg=name)
+    for p in parts:
+        for col in table.columns:
+            np.testing.assert_allclose(p['zonal_' + col].astype(np.float64), np.asarray(table[col], dtype=np.float64),
+                                       rtol=1e-12, err_msg=col)

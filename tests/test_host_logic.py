@@ -374,3 +374,52 @@ def test_every_device_entry_point_refuses_to_run_without_the_gpu():
     for call in calls:
         with pytest.raises(xa.XrsError):
             call()
+
+
+def test_sharded_array_bookkeeping(monkeypatch):
+    """ShardedArray without neighbours (world 1) and with a recording transport: when rows are exchanged, how deep,
+    what halo_top / halo_bot each rank passes on, and which calls refuse a sharded raster.  (C ABI: tests/fake_hip.py.)"""
+    from tests import fake_hip
+    from xrspatial_amd import ShardedArray, focal
+    from xrspatial_amd.utils import ArrayTypeFunctionMapping
+    fake_hip.install(monkeypatch)
+
+    class Recorder:
+        def __init__(self, world, rank):
+            self.world, self.rank, self.exchanges = world, rank, []
+
+        def halo_exchange(self, base, halo, stream=None):
+            self.exchanges.append((base.shape, halo))
+
+    z = np.arange(40 * 12, dtype=np.float32).reshape(40, 12)
+    for rank, want in ((0, (0, 2)), (1, (2, 2)), (2, (2, 0))):
+        comm = Recorder(3, rank)
+        sa = ShardedArray.from_numpy(z, comm, halo_cap=4)
+        assert sa.shape == (40, 12) and sa.base.shape == (48, 12) and sa.ptr == sa.base.ptr + 4 * 12 * 4
+        assert sa.halos(0) == (0, 0) and comm.exchanges == []             # per-cell operators exchange nothing
+        assert sa.halos(2) == want and sa.halos(1) == tuple(min(1, h) for h in want)
+        assert comm.exchanges == [((48, 12), 4)]                            # one exchange of halo_cap rows serves both
+        sa.touch()
+        sa.halos(4)
+        assert len(comm.exchanges) == 2
+        with pytest.raises(ValueError):
+            sa.halos(5)
+        out = sa.like(np.float64)
+        assert out.shape == sa.shape and out.dtype == np.float64 and out.comm is comm and not out._halo_ok
+    with pytest.raises(ValueError):
+        ShardedArray.from_numpy(z[:3], Recorder(2, 0), halo_cap=4)         # cannot serve 4 halo rows from 3
+    solo = ShardedArray.from_numpy(z)
+    assert (solo.world, solo.rank) == (1, 0) and solo.halos(3) == (0, 0)
+    np.testing.assert_array_equal(solo.get(), z)
+    np.testing.assert_array_equal(ShardedArray.from_numpy(z.astype(np.int64)).get(), z.astype(np.float32))
+    agg = DataArray(solo, dims=['y', 'x'])
+    assert ArrayTypeFunctionMapping(numpy_func=1, hip_func=2, sharded_func=3)(agg) == 3
+    with pytest.raises(NotImplementedError):
+        ArrayTypeFunctionMapping(numpy_func=1, hip_func=2)(agg)
+    with pytest.raises(NotImplementedError):
+        focal.hotspots(agg, np.ones((3, 3)))
+    with pytest.raises(TypeError):
+        focal.focal_stats(agg, np.ones((3, 3)))
+    with pytest.raises(TypeError):
+        xa.slope(DataArray(solo, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, 40), 'lon': np.linspace(1, 2, 12)}),
+                 method='geodesic')

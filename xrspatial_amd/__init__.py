@@ -9,6 +9,7 @@ libxrs_hip.so (include/xrs_hip.h); no PyTorch, CuPy, Numba or Triton involved.
     import xrspatial_amd as xrspatial        # numpy-backed DataArray in -> numpy-backed out
     from xrspatial_amd import DeviceArray    # keep rasters resident in HBM between calls
     with xrspatial.fuse(): ...               # several products of one raster from a single pass (fused.py)
+    from xrspatial_amd import ShardedArray   # this rank's rows of a raster spread over several GPUs (sharded.py)
 """
 from ._lib import XrsError, LIB_PATH  # noqa: F401
 from ._xr import DataArray, Dataset  # noqa: F401
@@ -19,6 +20,7 @@ from .aspect import aspect  # noqa: F401
 from .curvature import curvature  # noqa: F401
 from .focal import mean  # noqa: F401
 from .fused import fuse  # noqa: F401
+from .sharded import HostTransport, ShardedArray  # noqa: F401
 from .hillshade import hillshade  # noqa: F401
 from .multispectral import arvi, evi, nbr, ndvi, savi, sipi  # noqa: F401
 from .slope import slope  # noqa: F401

@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _lib
 from .device import _CAST_CODE, DeviceArray, host_empty, is_pinned, to_device_f32
+from .sharded import ShardedArray
 
 # The stream every host-level call uses (None = HIP null stream).  bench.py swaps in its own.
 _stream = None
@@ -33,6 +34,11 @@ def plane_args(arr: DeviceArray):
     """(rows, cols, ld) of a 2-D C-contiguous plane."""
     rows, cols = arr.shape
     return rows, cols, cols
+
+
+def sharded_f32(data: ShardedArray) -> ShardedArray:
+    """`data.astype(np.float32)` of the reference runners for a sharded raster (a float32 shard is used as is)."""
+    return data if data.dtype == np.float32 else data.astype(np.float32)
 
 
 def finish(out: DeviceArray, like_numpy: bool):
@@ -209,6 +215,15 @@ def stencil(fn_name, data, out_dtype, extra, halo=(0, 0), pre=(), window_rows=1)
     Large numpy-backed rasters go through the banded upload / compute / download pipeline (`window_rows` = the
     rows of context a band needs from its neighbours); everything else is one upload, one call, one download."""
     _lib.require_device()
+    if isinstance(data, ShardedArray):
+        # this rank's rows of a raster spread over several GPUs: the neighbours' rows come through the shard's halo
+        # exchange and the entry point is told how many of them are valid on either side
+        src = sharded_f32(data)
+        ht, hb = src.halos(window_rows, _stream)
+        out = src.like(out_dtype)
+        rows, cols = src.shape
+        _lib.call(fn_name, src.ptr, out.ptr, *pre, rows, cols, cols, cols, *extra, ht, hb, _stream)
+        return out
     like_numpy = not isinstance(data, DeviceArray)
     if len(data.shape) != 2:
         raise ValueError("expected a 2D raster")

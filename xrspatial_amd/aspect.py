@@ -41,6 +41,6 @@ def aspect(agg: DataArray,
     scope = fused.current()
     if scope is not None:
         return scope.defer('aspect', agg, name, {})
-    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run)
     out = mapper(agg)(agg.data)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

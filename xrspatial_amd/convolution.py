@@ -11,9 +11,10 @@ import re
 import numpy as np
 
 from . import _lib
-from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args
+from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args, sharded_f32
 from ._xr import DataArray
 from .device import DeviceArray, to_device_f32
+from .sharded import ShardedArray
 from .utils import get_dataarray_resolution
 
 DEFAULT_UNIT = 'meter'
@@ -130,10 +131,28 @@ def _convolve_2d_hip(data, kernel):
     return finish(out, like_numpy)
 
 
+def _convolve_2d_sharded(data, kernel):
+    # the reference's dask path: map_overlap(depth=k//2, boundary=nan) (convolution.py:316-327)
+    _lib.require_device()
+    k = _kernel_f64(kernel)
+    src = sharded_f32(data)
+    stream = get_stream()
+    ht, hb = src.halos(k.shape[0] // 2, stream)
+    rows, cols = src.shape
+    out = src.like(np.float32)
+    work = DeviceArray((max(int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])), 16),), np.uint8)
+    _lib.call("xrs_convolve2d_f32", src.ptr, out.ptr, rows, cols, cols, cols, k.ctypes.data, k.shape[0],
+              k.shape[1], work.ptr, ht, hb, stream)
+    _lib.call("xrs_stream_sync", stream)      # `k` and `work` must outlive the launch
+    return out
+
+
 def convolve_2d(data, kernel):
     """Correlate a raw 2-D array with `kernel` (NaN border of k//2, NaNs propagate).  Raw arrays in/out."""
     if isinstance(data, (np.ndarray, DeviceArray)):
         return _convolve_2d_hip(data, kernel)
+    if isinstance(data, ShardedArray):
+        return _convolve_2d_sharded(data, kernel)
     raise TypeError("Unsupported Array Type: {}".format(type(data)))
 
 

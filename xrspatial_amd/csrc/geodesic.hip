@@ -62,9 +62,12 @@ __global__ void geo_tables_kernel(const double *lat, long nlat, const double *lo
 }
 
 template <typename ET, bool TABLES>
-__global__ void __launch_bounds__(256) geodesic_kernel(const GeoArgs a) {
-    const long x = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const long y = (long)blockIdx.y * 4 + (threadIdx.x >> 6);
+__global__ void __launch_bounds__(256) geodesic_kernel(const GeoArgs a, const long tiles_x, const long n_tiles) {
+    // one workgroup = 64 columns x 4 rows (a wave per row); tiles numbered row-major, dealt to the XCDs in bands
+    const long tile = xcd_tile(blockIdx.x, n_tiles);
+    if (tile < 0) return;
+    const long x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
+    const long y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
     if (x >= a.cols || y >= a.rows) return;
     const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
     float res = nan_f32();
@@ -110,6 +113,10 @@ __global__ void __launch_bounds__(256) geodesic_kernel(const GeoArgs a) {
             double me = 0.0, mn = 0.0, mu = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
+                if (k == 4) {            // the centre itself: (P - P) projected on any axis is exactly 0
+                    e9[k] = 0.0; n9[k] = 0.0; u9[k] = 0.0;
+                    continue;
+                }
                 const double Xk = (la[k].N + h[k]) * la[k].c * lo[k].c;
                 const double Yk = (la[k].N + h[k]) * la[k].c * lo[k].s;
                 const double Zk = (la[k].Nz + h[k]) * la[k].s;
@@ -178,7 +185,8 @@ int xrs_geodesic_f32(const void *elev_dev, int elev_is_f64, const double *lat_de
     a.a2 = a2; a.b2 = b2; a.zf = z_factor;
     a.inv2r = 1.0 / (2.0 * 6370994.884953014);                  // WGS84 mean radius (geodesic.py:187)
     hipStream_t s = as_stream(stream);
-    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 3) / 4));
+    const long tiles_x = (cols + 63) / 64, n_tiles = tiles_x * ((rows + 3) / 4);
+    const dim3 grid((unsigned)xcd_grid(n_tiles));
     if (!latlon_2d) {
         const long nlat = rows + halo_top + halo_bot;
         double *tab_lat = static_cast<double *>(work_dev);
@@ -187,11 +195,11 @@ int xrs_geodesic_f32(const void *elev_dev, int elev_is_f64, const double *lat_de
         hipLaunchKernelGGL(geo_tables_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s,
                            lat_dev - halo_top, nlat, lon_dev, (long)cols, a2, b2, tab_lat, tab_lon);
         a.tab_lat = tab_lat; a.tab_lon = tab_lon;
-        if (elev_is_f64) hipLaunchKernelGGL((geodesic_kernel<double, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((geodesic_kernel<float, true>), grid, dim3(256), 0, s, a);
+        if (elev_is_f64) hipLaunchKernelGGL((geodesic_kernel<double, true>), grid, dim3(256), 0, s, a, tiles_x, n_tiles);
+        else hipLaunchKernelGGL((geodesic_kernel<float, true>), grid, dim3(256), 0, s, a, tiles_x, n_tiles);
     } else {
-        if (elev_is_f64) hipLaunchKernelGGL((geodesic_kernel<double, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((geodesic_kernel<float, false>), grid, dim3(256), 0, s, a);
+        if (elev_is_f64) hipLaunchKernelGGL((geodesic_kernel<double, false>), grid, dim3(256), 0, s, a, tiles_x, n_tiles);
+        else hipLaunchKernelGGL((geodesic_kernel<float, false>), grid, dim3(256), 0, s, a, tiles_x, n_tiles);
     }
     XRS_LAUNCH_CHECK();
     return 0;

@@ -77,10 +77,33 @@ class Comm:
             return cls(fh.read(), world, rank)
 
     def halo_exchange(self, shard: DeviceArray, halo: int, stream=None):
-        """`shard`: (rows + 2*halo, cols) float32 buffer whose middle `rows` rows are owned."""
+        """`shard`: (rows + 2*halo, cols) buffer whose middle `rows` rows are owned (4- or 8-byte cells: whole rows
+        travel, so a float64 / int32 plane goes as float32 words)."""
         rows = shard.shape[0] - 2 * halo
-        cols = shard.shape[1]
-        _lib.call("xrs_halo_exchange_f32", self.handle, shard.ptr + halo * cols * 4, rows, cols, cols, halo, stream)
+        words = shard.shape[1] * shard.dtype.itemsize // 4
+        if shard.dtype.itemsize % 4:
+            raise TypeError("halo rows are exchanged in 4-byte words")
+        _lib.call("xrs_halo_exchange_f32", self.handle, shard.ptr + halo * words * 4, rows, words, words, halo, stream)
+
+    def allreduce(self, arr, op: str):
+        """float64 host array reduced over the ranks with 'sum' / 'min' / 'max' (small control-plane values: zone id
+        ranges, presence maps); rides on xrs_zonal_allreduce's sum / min / max lanes."""
+        flat = np.array(arr, dtype=np.float64, copy=True).reshape(-1)
+        n = flat.size
+        if n == 0:
+            return flat.reshape(np.shape(arr))
+        lanes = {k: DeviceArray.from_numpy(flat) for k in ('s1', 's2', 'mn', 'mx')}
+        cnt = DeviceArray.from_numpy(np.zeros(n, np.uint64))
+        _lib.call("xrs_zonal_allreduce", self.handle, cnt.ptr, lanes['s1'].ptr, lanes['s2'].ptr, lanes['mn'].ptr,
+                  lanes['mx'].ptr, 1, n, None)
+        out = lanes[{'sum': 's1', 'min': 'mn', 'max': 'mx'}[op]].get()
+        return out.reshape(np.shape(arr))
+
+    def allreduce_zonal(self, cnt, s1, s2, mn, mx, f64, n_zones, stream=None):
+        """Device partials -> globally reduced host arrays (count, sum, sumsq, min, max)."""
+        _lib.call("xrs_zonal_allreduce", self.handle, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, int(bool(f64)),
+                  int(n_zones), stream)
+        return tuple(a.get(stream) for a in (cnt, s1, s2, mn, mx))
 
     def destroy(self):
         if self.handle:

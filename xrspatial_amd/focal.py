@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 from . import _lib, fused
-from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args
+from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args, sharded_f32
 from ._xr import DataArray
 from .convolution import _kernel_f64, custom_kernel
 from .dataset_support import supports_dataset
@@ -90,6 +90,41 @@ def _focal_stats_banded(host, kernel, stats):
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
 
 
+def _apply_sharded(data, kernel, stat):
+    # the reference's dask path: map_overlap(depth=k//2, boundary=nan) (focal.py:165-176, 343-356)
+    _lib.require_device()
+    k = _kernel_f64(kernel)
+    src = sharded_f32(data)
+    stream = get_stream()
+    ht, hb = src.halos(k.shape[0] // 2, stream)
+    rows, cols = src.shape
+    out = src.like(np.float32)
+    ptrs = (ctypes.c_void_p * 7)()
+    ptrs[_STAT_INDEX[stat]] = out.ptr
+    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k.ctypes.data,
+              k.shape[0], k.shape[1], None, ht, hb, stream)
+    return out
+
+
+def _mean_sharded(data, excludes, passes):
+    # every pass reads one row from either neighbour: exchange, launch, repeat (the reference: map_overlap per pass)
+    _lib.require_device()
+    cur = data if data.dtype in (np.float32, np.float64) else data.astype(np.float64)
+    ex = np.asarray(list(excludes), dtype=np.float64)
+    stream = get_stream()
+    rows, cols = cur.shape
+    if int(passes) < 1:
+        return cur.astype(np.float64)
+    for _ in range(int(passes)):
+        ht, hb = cur.halos(1, stream)
+        out = cur.like(np.float64)
+        _lib.call("xrs_focal_mean3x3", cur.ptr, int(cur.dtype == np.float64), out.ptr, rows, cols, cols, cols,
+                  ex.ctypes.data, len(ex), ht, hb, stream)
+        _lib.call("xrs_stream_sync", stream)        # (`cur` of the previous pass is released below)
+        cur = out
+    return cur
+
+
 def _mean_hip(data, excludes, passes):
     # replaces the passes loop over _mean_numpy (focal.py:44-67, 257-259); float64 result
     _lib.require_device()
@@ -125,7 +160,7 @@ def mean(agg, passes=1, excludes=[np.nan], name='mean'):
         raise ValueError("`agg` must be 2D")
     if len(excludes) > 8:
         raise ValueError("at most 8 exclude values are supported by the MI355X backend")
-    mapper = ArrayTypeFunctionMapping(numpy_func=_mean_hip, hip_func=_mean_hip)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_mean_hip, hip_func=_mean_hip, sharded_func=_mean_sharded)
     out = mapper(agg)(agg.data, tuple(excludes), passes)
     return DataArray(out, name=name, dims=agg.dims, coords=agg.coords, attrs=agg.attrs)
 
@@ -161,7 +196,7 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
             return _focal_stats_banded(data, kernel, [stat])[0]
         return _focal_stats_hip(data, kernel, [stat])[stat]
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=_apply_sharded)
     out = mapper(raster)(raster.data, kernel, stat)
     return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
 

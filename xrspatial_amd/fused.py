@@ -24,9 +24,10 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._launch import get_stream, plane_args
+from ._launch import get_stream, sharded_f32
 from ._xr import DataArray
 from .device import DeviceArray, to_device_f32
+from .sharded import ShardedArray
 
 _SLOTS = ('slope', 'aspect', 'curvature', 'hillshade', 'focal_mean')
 _local = threading.local()
@@ -77,7 +78,7 @@ class fuse:
     def defer(self, slot, agg, name, params, numpy_dtype=np.float32):
         """Record one product of `agg`; returns the DataArray that will hold it."""
         data = agg.data
-        if not isinstance(data, (np.ndarray, DeviceArray)):
+        if not isinstance(data, (np.ndarray, DeviceArray, ShardedArray)):
             raise TypeError("Unsupported Array Type: {}".format(type(data)))
         if len(data.shape) != 2:
             raise ValueError("expected a 2D raster")
@@ -99,9 +100,11 @@ class fuse:
     def _run_group(self, calls):
         _lib.require_device()
         data = calls[0][2]
-        like_numpy = not isinstance(data, DeviceArray)
-        src = to_device_f32(data)
-        rows, cols, ld = plane_args(src)
+        sharded = isinstance(data, ShardedArray)
+        like_numpy = not isinstance(data, (DeviceArray, ShardedArray))
+        src = sharded_f32(data) if sharded else to_device_f32(data)
+        rows, cols = src.shape
+        ld = cols
         stream = get_stream()
         # pack the calls into passes: one product per slot per pass, shared cell sizes within a pass
         passes = []
@@ -120,7 +123,7 @@ class fuse:
             if 'cellsize' in params:
                 p['cellsize'] = params['cellsize']
         for p in passes:
-            outs = {s: DeviceArray((rows, cols), np.float32) for s in p['slots']}
+            outs = {s: (src.like(np.float32) if sharded else DeviceArray((rows, cols), np.float32)) for s in p['slots']}
             cx, cy = p.get('cellsize', (1.0, 1.0))
             hs = p['slots'].get('hillshade')
             az, alt = hs[1]['light'] if hs else (225.0, 25.0)
@@ -130,12 +133,14 @@ class fuse:
             if k is not None and max(k.shape) > 5:
                 nbytes = max(int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])), 16)
                 work = DeviceArray((nbytes,), np.uint8)
+            # a row-sharded raster: the pass reads the neighbours' rows from the shard's halo (one exchange per raster)
+            ht, hb = src.halos(max(1, k.shape[0] // 2 if k is not None else 1), stream) if sharded else (0, 0)
             ptr = lambda s: outs[s].ptr if s in outs else None          # noqa: E731
             _lib.call("xrs_raster_pass_f32", src.ptr, ptr('slope'), ptr('aspect'), ptr('curvature'),
                       ptr('hillshade'), ptr('focal_mean'), k.ctypes.data if k is not None else None,
                       k.shape[0] if k is not None else 0, k.shape[1] if k is not None else 0,
                       work.ptr if work is not None else None, rows, cols, ld, ld, float(cx), float(cy),
-                      float(az), float(alt), 0, 0, stream)
+                      float(az), float(alt), ht, hb, stream)
             self.launches += 1
             _lib.call("xrs_stream_sync", stream)        # `k` / `work` must outlive the launch
             for s, call in p['slots'].items():

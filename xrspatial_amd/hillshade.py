@@ -10,6 +10,7 @@ from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
 from .device import DeviceArray
+from .sharded import ShardedArray
 
 # The reference's NumPy runner returns float64 under NumPy >= 2 (its final combine is
 # promoted by a np.float64 scalar) and float32 under NumPy 1.x; its CuPy
@@ -51,7 +52,7 @@ def hillshade(agg: DataArray,
                            numpy_dtype=_NUMPY_RESULT_DTYPE)
     if isinstance(agg.data, np.ndarray):
         out = _run_numpy(agg.data, azimuth, angle_altitude)
-    elif isinstance(agg.data, DeviceArray):
+    elif isinstance(agg.data, (DeviceArray, ShardedArray)):
         out = _run_hip(agg.data, azimuth, angle_altitude)
     else:
         raise TypeError('Unsupported Array Type: {}'.format(type(agg.data)))

@@ -7,16 +7,23 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from ._launch import finish, get_stream, percell_pipelined
+from ._launch import finish, get_stream, percell_pipelined, sharded_f32
 from ._xr import DataArray
 from .dataset_support import supports_dataset_bands
 from .device import DeviceArray, to_device_f32
+from .sharded import ShardedArray, same_layout
 from .utils import ArrayTypeFunctionMapping, validate_arrays
 
 
 def _percell(fn_name, bands, extra):
     """bands: tuple of same-shape arrays -> float32 result of the same shape."""
     _lib.require_device()
+    if isinstance(bands[0], ShardedArray):            # per-cell: every rank works on its own rows, nothing is exchanged
+        same_layout(*bands)
+        dev = [sharded_f32(b) for b in bands]
+        out = dev[0].like(np.float32)
+        _lib.call(fn_name, *[d.ptr for d in dev], out.ptr, out.size, *extra, get_stream())
+        return out
     like_numpy = not isinstance(bands[0], DeviceArray)
     if like_numpy:                                    # large numpy rasters: overlapped upload / compute / download
         out = percell_pipelined(fn_name, [np.asarray(b) for b in bands], extra)
@@ -39,7 +46,7 @@ def _wrap(out, name, like):
 
 def _nr_index(band1, band2, name):
     validate_arrays(band1, band2)
-    mapper = ArrayTypeFunctionMapping(numpy_func=_normalized_ratio, hip_func=_normalized_ratio)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_normalized_ratio, hip_func=_normalized_ratio, sharded_func=_normalized_ratio)
     return _wrap(mapper(band1)(band1.data, band2.data), name, band1)
 
 
@@ -88,7 +95,7 @@ def evi(nir_agg, red_agg, blue_agg, c1=6.0, c2=7.5, soil_factor=1.0, gain=2.5, n
         return _percell("xrs_evi_f32", (nir, red, blue),
                         (float(c1), float(c2), float(soil_factor), float(gain)))
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
     return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data, blue_agg.data), name, nir_agg)
 
 
@@ -103,7 +110,7 @@ def savi(nir_agg, red_agg, soil_factor=1.0, name='savi'):
     def run(nir, red):         # replaces _savi_cpu (multispectral.py:876-890)
         return _percell("xrs_savi_f32", (nir, red), (float(soil_factor),))
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
     return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data), name, nir_agg)
 
 
@@ -114,7 +121,7 @@ def _simple_index(fn_name, like, bands, name, order=None):
     def run(*arrays):
         return _percell(fn_name, arrays, ())
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
     return _wrap(mapper(like)(*[b.data for b in bands]), name, like)
 
 

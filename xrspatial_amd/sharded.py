@@ -1,0 +1,179 @@
+"""Row-sharded rasters as an array backend: one process per GPU, each holding a contiguous block of rows.
+
+The reference spreads a raster over workers with dask and gives every chunk its neighbours' rows through
+`map_overlap(depth=k//2, boundary=nan)` (xrspatial/slope.py:86-97, focal.py:165-176, convolution.py:316-327) and
+combines per-block partials for zonal.stats (zonal.py:181-277).  Here the same role is played by `ShardedArray`:
+this rank's rows in HBM with `halo_cap` spare rows above and below, filled from the neighbouring ranks when an
+operator needs them -- over RCCL / xGMI (`distributed.Comm`) or, where RCCL cannot connect the ranks, through host
+memory and a torch.distributed group (`HostTransport`).  A DataArray whose `.data` is a ShardedArray goes through the
+same public functions (`slope`, `hillshade`, `focal.mean`, `focal_stats`, `convolution_2d`, `ndvi`, `zonal.stats`, ...);
+every result is again a ShardedArray, so calls chain, and `fuse()` packs them into single passes as on one GPU.
+Operators without a sharded implementation raise; nothing silently computes shard by shard without halos.
+
+    comm = Comm.from_torch_distributed(dist)                       # or HostTransport(dist)
+    y0, y1 = shard_rows(total_rows, comm.world, comm.rank)
+    dem = DataArray(ShardedArray.from_numpy(full[y0:y1], comm), dims=['y', 'x'], attrs={'res': (30.0, 30.0)})
+    hs = hillshade(dem)                                             # halo rows exchanged once, reused by later calls
+    sm = focal.mean(slope(dem))
+    local_rows = hs.data.get()
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray
+
+_DTYPES = (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.int32))
+
+
+class HostTransport:
+    """Halo rows and per-zone partials through host memory over an initialised torch.distributed group (gloo is
+    enough).  Same neighbours, rows and reduction operators as the RCCL path (`distributed.Comm`); for machines on
+    which RCCL cannot connect the ranks -- e.g. several ranks sharing one GPU."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.world, self.rank = int(dist.get_world_size()), int(dist.get_rank())
+
+    def halo_exchange(self, base: DeviceArray, halo: int, stream=None):
+        """`base`: (rows + 2*halo, cols) plane whose middle rows are owned; fills the spare rows that face a neighbour."""
+        from .distributed import halo_exchange_host
+        if halo == 0 or self.world == 1:
+            return
+        total, cols = base.shape
+        rows = total - 2 * halo
+        rb = cols * base.dtype.itemsize                                 # bytes per row
+        if rows < 2 * halo:                                             # tiny shard: stage all of it
+            host = np.empty((total, cols), base.dtype)
+            _lib.call("xrs_memcpy_d2h", host.ctypes.data, base.ptr, total * rb, stream)
+            _lib.call("xrs_stream_sync", stream)
+            halo_exchange_host(self.dist, host, halo)
+            tail = rows + halo
+        else:
+            # [spare | first `halo` owned rows | last `halo` owned rows | spare]: the same layout with rows = 2*halo
+            host = np.empty((4 * halo, cols), base.dtype)
+            _lib.call("xrs_memcpy_d2h", host.ctypes.data + halo * rb, base.ptr + halo * rb, halo * rb, stream)
+            _lib.call("xrs_memcpy_d2h", host.ctypes.data + 2 * halo * rb, base.ptr + rows * rb, halo * rb, stream)
+            _lib.call("xrs_stream_sync", stream)
+            halo_exchange_host(self.dist, host, halo)
+            tail = 3 * halo
+        if self.rank > 0:
+            _lib.call("xrs_memcpy_h2d", base.ptr, host.ctypes.data, halo * rb, stream)
+        if self.rank < self.world - 1:
+            _lib.call("xrs_memcpy_h2d", base.ptr + (rows + halo) * rb, host.ctypes.data + tail * rb, halo * rb, stream)
+        _lib.call("xrs_stream_sync", stream)                            # `host` must outlive the copies
+
+    def allreduce(self, arr, op: str):
+        """float64 host array reduced over the ranks with 'sum' / 'min' / 'max'."""
+        import torch
+        t = torch.from_numpy(np.array(arr, dtype=np.float64, copy=True).reshape(-1))
+        self.dist.all_reduce(t, op={'sum': self.dist.ReduceOp.SUM, 'min': self.dist.ReduceOp.MIN,
+                                    'max': self.dist.ReduceOp.MAX}[op])
+        return t.numpy().reshape(np.shape(arr))
+
+    def allreduce_zonal(self, cnt, s1, s2, mn, mx, f64, n_zones, stream=None):
+        """Device partials -> globally reduced host arrays (count, sum, sumsq, min, max)."""
+        from .distributed import zonal_allreduce_host
+        parts = [a.get(stream) for a in (cnt, s1, s2, mn, mx)]
+        return zonal_allreduce_host(self.dist, *parts)
+
+
+class ShardedArray:
+    """This rank's rows of a raster split on the row axis over `comm.world` GPUs (float32 / float64 / int32)."""
+
+    def __init__(self, rows, cols, dtype=np.float32, comm=None, halo_cap=16):
+        _lib.require_device()
+        dtype = np.dtype(dtype)
+        if dtype not in _DTYPES:
+            raise TypeError(f"sharded rasters are float32, float64 or int32, not {dtype}")
+        self.comm = comm
+        self.world = int(comm.world) if comm is not None else 1
+        self.rank = int(comm.rank) if comm is not None else 0
+        self.halo_cap = int(halo_cap)
+        if self.halo_cap < 1:
+            raise ValueError("halo_cap must be at least 1 row")
+        if self.world > 1 and rows < self.halo_cap:
+            raise ValueError(f"a shard of {rows} rows cannot serve {self.halo_cap} halo rows to its neighbours")
+        self.base = DeviceArray((int(rows) + 2 * self.halo_cap, int(cols)), dtype)
+        self.local = DeviceArray((int(rows), int(cols)), dtype, _base=self.base,
+                                 _ptr=self.base.ptr + self.halo_cap * int(cols) * dtype.itemsize)
+        self._halo_ok = False
+
+    # ---- array-like surface ------------------------------------------------------------------
+    shape = property(lambda self: self.local.shape)
+    dtype = property(lambda self: self.local.dtype)
+    ndim = property(lambda self: 2)
+    size = property(lambda self: self.local.size)
+    ptr = property(lambda self: self.local.ptr)
+
+    def __repr__(self):
+        return f"ShardedArray(rows={self.shape[0]}, cols={self.shape[1]}, dtype={self.dtype}, rank {self.rank}/{self.world})"
+
+    @classmethod
+    def from_numpy(cls, local_rows, comm=None, halo_cap=16, dtype=None, stream=None):
+        host = np.ascontiguousarray(local_rows, dtype=dtype)
+        if host.ndim != 2:
+            raise ValueError("expected this rank's rows as a 2D array")
+        if host.dtype not in _DTYPES:
+            host = host.astype(np.float32 if host.dtype.kind == 'f' or host.dtype.itemsize > 4 else np.int32)
+        out = cls(host.shape[0], host.shape[1], host.dtype, comm, halo_cap)
+        if host.size:
+            _lib.call("xrs_memcpy_h2d", out.ptr, host.ctypes.data, host.nbytes, stream)
+            _lib.call("xrs_stream_sync", stream)
+        return out
+
+    @classmethod
+    def from_device(cls, local_rows: DeviceArray, comm=None, halo_cap=16, stream=None):
+        if len(local_rows.shape) != 2:
+            raise ValueError("expected this rank's rows as a 2D array")
+        out = cls(local_rows.shape[0], local_rows.shape[1], local_rows.dtype, comm, halo_cap)
+        if local_rows.size:
+            _lib.call("xrs_memcpy_d2d", out.ptr, local_rows.ptr, local_rows.size * out.dtype.itemsize, stream)
+        return out
+
+    def like(self, dtype=None):
+        """An uninitialised shard with the same geometry and transport (operators write their results into one)."""
+        return ShardedArray(self.shape[0], self.shape[1], self.dtype if dtype is None else dtype, self.comm, self.halo_cap)
+
+    def get(self, stream=None) -> np.ndarray:
+        """This rank's rows as a NumPy array."""
+        return self.local.get(stream)
+
+    def astype(self, dtype):
+        dtype = np.dtype(dtype)
+        if dtype == self.dtype:
+            return self
+        out = self.like(dtype)
+        cast = self.local.astype(dtype)
+        _lib.call("xrs_memcpy_d2d", out.ptr, cast.ptr, cast.size * dtype.itemsize, None)
+        _lib.call("xrs_stream_sync", None)
+        return out
+
+    # ---- halos ----------------------------------------------------------------------------------
+    def touch(self):
+        """The owned rows were rewritten: the neighbours' copies (and ours of theirs) are stale."""
+        self._halo_ok = False
+
+    def halos(self, depth: int, stream=None):
+        """Make `depth` rows of context valid above and below the shard; returns (halo_top, halo_bot) for the C ABI
+        (0 on a true raster edge).  One exchange of `halo_cap` rows serves every later call on the same data."""
+        depth = int(depth)
+        if depth > self.halo_cap:
+            raise ValueError(f"this operator needs {depth} halo rows but the shard was built with halo_cap={self.halo_cap}")
+        if self.world == 1 or depth == 0:
+            return 0, 0
+        if not self._halo_ok:
+            self.comm.halo_exchange(self.base, self.halo_cap, stream)
+            self._halo_ok = True
+        return (depth if self.rank > 0 else 0), (depth if self.rank < self.world - 1 else 0)
+
+
+def same_layout(*arrays):
+    """All shards must describe the same rows of the same global raster on the same ranks."""
+    head = arrays[0]
+    for other in arrays[1:]:
+        if not isinstance(other, ShardedArray):
+            raise ValueError("input arrays must have same type")
+        if other.shape != head.shape or other.world != head.world or other.rank != head.rank:
+            raise ValueError("sharded inputs must share one row partition")

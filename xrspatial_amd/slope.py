@@ -43,6 +43,6 @@ def slope(agg: DataArray,
     scope = fused.current()
     if scope is not None:
         return scope.defer('slope', agg, name, {'cellsize': (float(cellsize_x), float(cellsize_y))})
-    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run)
     out = mapper(agg)(agg.data, cellsize_x, cellsize_y)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray
+from .sharded import ShardedArray
 
 try:                                     # optional, like the reference
     import dask.array as da              # pragma: no cover
@@ -40,9 +41,11 @@ class ArrayTypeFunctionMapping(object):
     to `dask_func` when dask is installed.  Anything else: TypeError, as upstream.
     """
 
-    def __init__(self, numpy_func, hip_func=None, dask_func=None, cupy_func=None, dask_cupy_func=None):
+    def __init__(self, numpy_func, hip_func=None, dask_func=None, cupy_func=None, dask_cupy_func=None,
+                 sharded_func=None):
         self.numpy_func = numpy_func
         self.hip_func = hip_func
+        self.sharded_func = sharded_func        # row-sharded multi-GPU rasters (xrspatial_amd.sharded), dask's role upstream
         self.dask_func = dask_func
         self.cupy_func = cupy_func
         self.dask_cupy_func = dask_cupy_func
@@ -54,6 +57,10 @@ class ArrayTypeFunctionMapping(object):
             if self.hip_func is None:
                 raise NotImplementedError("not implemented for device-resident arrays")
             return self.hip_func
+        if isinstance(arr.data, ShardedArray):
+            if self.sharded_func is None:
+                raise NotImplementedError("not implemented for row-sharded (multi-GPU) arrays")
+            return self.sharded_func
         if da is not None and isinstance(arr.data, da.Array):   # pragma: no cover
             if self.dask_func is None:
                 raise NotImplementedError("not implemented for dask-backed arrays")

@@ -16,6 +16,7 @@ from . import _lib
 from ._launch import get_stream
 from ._xr import DataArray, Dataset
 from .device import DeviceArray
+from .sharded import ShardedArray, same_layout
 from .utils import validate_arrays
 
 _DEVICE_STATS = ('mean', 'max', 'min', 'sum', 'std', 'var', 'count')
@@ -169,9 +170,8 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     else:
         _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
                   n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
-    if comm is not None:
-        _lib.call("xrs_zonal_allreduce", comm.handle, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, int(f64),
-                  n_zones, stream)
+    if comm is not None:                 # distributed.Comm (RCCL) or sharded.HostTransport
+        return comm.allreduce_zonal(cnt, s1, s2, mn, mx, f64, n_zones, stream)
     return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream)
 
 
@@ -280,6 +280,58 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
     return out.get(get_stream()) if like_numpy else out
 
 
+_SHARDED_RANGE_LIMIT = 1 << 22      # widest span of zone ids whose presence map the ranks exchange
+
+
+def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_type):
+    """zonal.stats of a row-sharded raster: every rank reduces its own rows to per-zone partial sums, the partials
+    are all-reduced, and every rank finishes the same table -- the block partials + combine of the reference's dask
+    path (zonal.py:181-277) with a collective in place of the task graph.  The set of zone ids is agreed on first
+    (global id range, then the union of the ranks' presence maps)."""
+    same_layout(zones, values)
+    if return_type != 'pandas.DataFrame':
+        raise NotImplementedError("zonal.stats of a sharded raster returns the DataFrame (return_type='pandas.DataFrame')")
+    if 'majority' in stat_names:
+        raise NotImplementedError("'majority' needs a global sort and is not available for sharded rasters; "
+                                  "pass stats_funcs without it")
+    if zones.dtype != np.int32:
+        raise TypeError("sharded zone rasters must be int32")
+    comm = zones.comm
+    stream = get_stream()
+    zloc = zones.local
+    res = DeviceArray((4,), np.float64)
+    _lib.call("xrs_zonal_scan", zloc.ptr, _ZONE_DTYPE_CODE[zloc.dtype], zloc.size, res.ptr, stream)
+    raw = res.get(stream)
+    n_local = int(raw[2:3].view(np.uint64)[0])
+    lo, hi = (raw[0], raw[1]) if n_local else (np.inf, -np.inf)
+    if comm is not None and zones.world > 1:
+        lo = float(comm.allreduce(np.array([lo]), 'min')[0])
+        hi = float(comm.allreduce(np.array([hi]), 'max')[0])
+    if not np.isfinite(lo):                                   # no rank holds a zone cell
+        return pd.DataFrame({'zone': np.empty(0, np.int32), **{name: np.empty(0) for name in stat_names}})
+    rng = int(hi - lo) + 1
+    if rng > _SHARDED_RANGE_LIMIT:
+        raise NotImplementedError(f"zone ids span {rng} values; sharded zonal.stats handles up to {_SHARDED_RANGE_LIMIT}")
+    present = DeviceArray((rng,), np.uint8)
+    _lib.call("xrs_zonal_presence", zloc.ptr, _ZONE_DTYPE_CODE[zloc.dtype], zloc.size, float(lo), rng, present.ptr, stream)
+    seen = present.get(stream).astype(np.float64)
+    if comm is not None and zones.world > 1:
+        seen = comm.allreduce(seen, 'sum')
+    mask = seen > 0
+    lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
+    unique_zones = (np.flatnonzero(mask).astype(np.float64) + lo).astype(np.int32)
+    nz = len(unique_zones)
+    vloc = values.local if values.dtype in (np.float32, np.float64) else values.local.astype(np.float64)
+    count, s1, s2, mn, mx = zonal_partials(zloc, vloc, nz, nodata_values, comm if zones.world > 1 else None,
+                                           table=(lo, rng, DeviceArray.from_numpy(lut)))
+    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None)
+    keep = np.arange(nz) if zone_ids is None else np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
+    frame = {'zone': unique_zones[keep]}
+    for name in stat_names:
+        frame[name] = cols[name][keep]
+    return pd.DataFrame(frame)
+
+
 def stats(
     zones,
     values,
@@ -334,6 +386,8 @@ def stats(
             raise ValueError(f"Invalid stat name. {name} option not supported.")
     if return_type not in ('pandas.DataFrame', 'xarray.DataArray'):
         raise ValueError(f"unknown return_type {return_type!r}")
+    if isinstance(values.data, ShardedArray):
+        return _stats_sharded(zones.data, values.data, zone_ids, names, nodata_values, return_type)
     if not isinstance(values.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(values)))
     result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type)

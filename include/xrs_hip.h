@@ -55,11 +55,15 @@ int xrs_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int xrs_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int xrs_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int xrs_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
+/* a rectangular window of a plane (pitches and width in bytes): `raster[top:bottom + 1, left:right + 1]` of a
+ * device-resident raster (the slicing at the end of zonal.trim / zonal.crop, xrspatial/zonal.py:1841, 2058) */
+int xrs_copy2d(void *dst_dev, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes,
+               int64_t rows, void *stream);
 /* streaming plane copy in the library's own access pattern: the measured-copy-bandwidth calibration point */
 /* `.astype(np.float32)` of the reference's wrappers (xrspatial/slope.py:82, hillshade.py:21, multispectral.py:834 ...)
  * on the device: numpy-backed rasters are sent in their own dtype and converted in HBM (round to nearest even). */
 enum { XRS_DT_I8 = 0, XRS_DT_U8 = 1, XRS_DT_I16 = 2, XRS_DT_U16 = 3, XRS_DT_I32 = 4, XRS_DT_U32 = 5,
-       XRS_DT_I64 = 6, XRS_DT_U64 = 7, XRS_DT_F64 = 8 };
+       XRS_DT_I64 = 6, XRS_DT_U64 = 7, XRS_DT_F64 = 8, XRS_DT_F32 = 9 };
 int xrs_cast_f32(const void *src_dev, int src_dtype, float *dst_dev, int64_t n, void *stream);
 int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream);
 int xrs_stream_create(void **stream);
@@ -271,6 +275,24 @@ int xrs_zonal_majority_f64(const int32_t *zone_idx_dev, const double *values_dev
  * table[s][zone_idx[cell]] (row-major n_stats x n_zones float64 table), NaN where the cell has no zone. */
 int xrs_zonal_backproject_f64(const int32_t *zone_idx_dev, int64_t n, const double *table_dev, int n_stats,
                               int n_zones, double *out_dev, void *stream);
+
+/* zonal.trim / zonal.crop (xrspatial/zonal.py:1651-1731 `_trim`, :1845-1940 `_crop`): bounding box of the cells
+ * that equal one of `values` (host array, at most 16; invert = 0: crop's zone ids) or equal none of them
+ * (invert = 1: trim's nodata values).  Cells are compared as float64, NaN equals nothing (`e == val` upstream).
+ * box4_dev = { top, bottom, left, right }; { rows, -1, cols, -1 } when no cell qualifies.  `dtype`: XRS_DT_*. */
+int xrs_match_bbox(const void *data_dev, int dtype, int64_t rows, int64_t cols, int64_t ld, const double *values,
+                   int n_values, int invert, int *box4_dev, void *stream);
+
+/* multispectral.true_color (xrspatial/multispectral.py:1334-1495).
+ *   xrs_nan_minmax_f32: minmax_dev[0..1] = np.nanmin / np.nanmax of a float32 plane (NaN, NaN if it holds no number);
+ *   xrs_true_color_u8:  rgba[i] = { stretch(red), stretch(green), stretch(blue), alpha } with
+ *       stretch(v) = uint8( float32( 255 / (1 + exp(c * (th - (v - min) / (max - min)))) ) )   (0 where max == min or NaN)
+ *       alpha      = 0 where the red band, in its OWN dtype (`red_raw_dev`, XRS_DT_*), is NaN or <= nodata, else 255;
+ *     minmax6_dev = { rmin, rmax, gmin, gmax, bmin, bmax } as produced by xrs_nan_minmax_f32. */
+int xrs_nan_minmax_f32(const float *in_dev, int64_t n, float *minmax_dev, void *stream);
+int xrs_true_color_u8(const float *red_dev, const float *green_dev, const float *blue_dev, const void *red_raw_dev,
+                      int red_raw_dtype, int64_t n, const float *minmax6_dev, double nodata, double c, double th,
+                      unsigned char *rgba_dev, void *stream);
 
 /* ----------------------------------------------------- multi-GPU (RCCL, xGMI)
  * One process per GPU.  Rank 0 creates a 128-byte id and ships it to the other

@@ -333,6 +333,38 @@ def ebbi(red, swir, tir):
     return out
 
 
+def true_color(r, g, b, nodata=1, c=10.0, th=0.125):
+    """(rows, cols, 4) uint8 RGBA.  Reference: xrspatial/multispectral.py:1334-1351 (`_normalize_data_cpu`: float32
+    (val - min) / range, then the sigmoid and the scaling in float64 -- `c`, `th` and the literal 1 are Python
+    numbers under Numba -- stored into a float32 plane), :1354-1361 (np.nanmin / np.nanmax of the float32 band),
+    :1387-1399 (`_true_color_numpy`: alpha from the band in its own dtype, `.astype(np.uint8)` truncation; the NaN a
+    constant or missing cell leaves becomes 0 here, which is what that cast yields on x86).
+    Parity unpinned: the reference's only test of it (test_multispectral.py:588-615) compares its numpy and dask
+    paths with each other and holds no expected values."""
+    def channel(band):
+        d = np.asarray(band).astype(F32)
+        out = np.full(d.shape, np.nan, dtype=F32)
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                lo, hi = np.nanmin(d), np.nanmax(d)          # float32 scalars
+            rng = F32(hi - lo)
+            if rng != 0:
+                norm = (d - lo) / rng                         # float32
+                s = 1 / (1 + np.exp(c * (th - norm.astype(F64))))
+                out = (s * 255).astype(F32)
+        return np.where(np.isnan(out), 0, out).astype(np.uint8)
+
+    r_arr = np.asarray(r)
+    with np.errstate(all="ignore"):
+        isnan = np.isnan(r_arr) if np.issubdtype(r_arr.dtype, np.floating) else np.zeros(r_arr.shape, bool)
+        alpha = np.where(isnan | (r_arr <= nodata), 0, 255).astype(np.uint8)
+    out = np.zeros(r_arr.shape + (4,), dtype=np.uint8)
+    out[..., 0], out[..., 1], out[..., 2], out[..., 3] = channel(r), channel(g), channel(b), alpha
+    return out
+
+
 # --------------------------------------------------------------------------
 # k x k kernels
 # --------------------------------------------------------------------------
@@ -635,3 +667,39 @@ def crosstab_2d(zones, values, zone_ids=None, cat_ids=None, nodata_values=None, 
         for c in cat_sel:
             out[c] = out[c] / total * 100
     return out
+
+
+# --------------------------------------------------------------------------
+# zonal.trim / zonal.crop
+# --------------------------------------------------------------------------
+
+def _scan_bounds(hit):
+    """The four edge scans of xrspatial/zonal.py:1651-1731 / 1845-1940 on a boolean "this cell stops the scan" map:
+    each scan remembers the last row / column it looked at, so when nothing stops it, it ends on the far edge."""
+    rows, cols = hit.shape
+    row_hit, col_hit = hit.any(axis=1), hit.any(axis=0)
+    if not row_hit.any():
+        return max(rows - 1, 0), 0, max(cols - 1, 0), 0
+    ys, xs = np.flatnonzero(row_hit), np.flatnonzero(col_hit)
+    return int(ys[0]), int(ys[-1]), int(xs[0]), int(xs[-1])
+
+
+def _equals_any(data, values):
+    data = np.asarray(data)
+    hit = np.zeros(data.shape, dtype=bool)
+    with np.errstate(all="ignore"):
+        for v in values:
+            hit |= (data == v)                # `e == val`: NaN matches nothing
+    return hit
+
+
+def trim_bounds(data, values=(np.nan,)):
+    """(top, bottom, left, right) of xrspatial/zonal.py:1651-1731 (`_trim`): the scans stop at the first cell that
+    equals none of `values`."""
+    return _scan_bounds(~_equals_any(data, values))
+
+
+def crop_bounds(zones, zones_ids):
+    """(top, bottom, left, right) of xrspatial/zonal.py:1845-1940 (`_crop`): the scans stop at the first cell that
+    equals one of `zones_ids`."""
+    return _scan_bounds(_equals_any(zones, zones_ids))

@@ -1490,3 +1490,80 @@ def test_sharded_api_equals_single_gpu(tmp_path, world):
         for col in table.columns:
             np.testing.assert_allclose(p['zonal_' + col].astype(np.float64), np.asarray(table[col], dtype=np.float64),
                                        rtol=1e-12, err_msg=col)
+
+
+# ---------------------------------------------------------------- zonal.trim / zonal.crop, multispectral.true_color
+@pytest.mark.parametrize("backend", ["numpy", "hip"])
+def test_trim_crop_reference_cases(backend):
+    """The reference's own trim / crop tests (test_zonal.py:1047-1211) through the device path, plus metadata."""
+    from tests.trim_crop_cases import CASES
+    from xrspatial_amd.zonal import crop, trim
+    for fn, arr, values, want in CASES:
+        agg = xs.DataArray(arr if backend == 'numpy' else xs.DeviceArray.from_numpy(arr), dims=['y', 'x'], attrs={'a': 1})
+        agg['y'] = np.linspace(0, arr.shape[0], arr.shape[0])
+        agg['x'] = np.linspace(0, arr.shape[1], arr.shape[1])
+        out = trim(agg, values=values) if fn == "trim" else crop(agg, agg, zones_ids=values)
+        np.testing.assert_array_equal(host(out.data), want)
+        assert out.name == fn and out.attrs == {'a': 1} and out.dims == ('y', 'x') and out.data.dtype == arr.dtype
+        top, bottom, left, right = (orc.trim_bounds if fn == "trim" else orc.crop_bounds)(arr, values)
+        np.testing.assert_array_equal(host(out['y'].data), np.linspace(0, arr.shape[0], arr.shape[0])[top:bottom + 1])
+        np.testing.assert_array_equal(host(out['x'].data), np.linspace(0, arr.shape[1], arr.shape[1])[left:right + 1])
+        assert isinstance(out.data, xs.DeviceArray) == (backend == 'hip')
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint16, np.int32, np.int64, np.float32, np.float64])
+def test_trim_crop_bounds_vs_oracle(dtype):
+    """Bounds on seeded rasters of every dtype the kernel reads in place: wide margins, single cells, nothing to keep,
+    NaN never matching, more than one value."""
+    from xrspatial_amd.zonal import _match_bounds
+    rng = np.random.default_rng(8)
+    for shape, box in [((70, 300), (5, 60, 17, 280)), ((513, 1000), (500, 501, 999, 1000)), ((40, 33), None), ((1, 1), (0, 1, 0, 1))]:
+        z = np.zeros(shape, dtype=dtype)
+        if box is not None:
+            y0, y1, x0, x1 = box
+            z[y0:y1, x0:x1] = rng.integers(0, 4, (y1 - y0, x1 - x0)).astype(dtype)
+            z[y0, x0] = 3
+            z[y1 - 1, x1 - 1] = 2
+        for data in (z, xs.DeviceArray.from_numpy(z)):
+            assert _match_bounds(data, (0,), True) == orc.trim_bounds(z, (0,))
+            assert _match_bounds(data, (0, 1), True) == orc.trim_bounds(z, (0, 1))
+            assert _match_bounds(data, (2, 3), False) == orc.crop_bounds(z, (2, 3))
+            assert _match_bounds(data, (9,), False) == orc.crop_bounds(z, (9,))
+    if np.issubdtype(dtype, np.floating):
+        z = np.full((30, 40), np.nan, dtype=dtype)
+        z[10:12, 5:9] = 1
+        assert _match_bounds(z, (np.nan,), True) == orc.trim_bounds(z) == (0, 29, 0, 39)
+        assert _match_bounds(z, (np.nan,), False) == orc.crop_bounds(z, (np.nan,)) == (29, 0, 39, 0)
+        assert _match_bounds(z, (1,), False) == (10, 11, 5, 8)
+    with pytest.raises(ValueError):
+        _match_bounds(np.zeros((4, 4)), tuple(range(17)), True)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64, np.uint32, np.uint64, np.float32, np.float64, np.uint8])
+@pytest.mark.parametrize("backend", ["numpy", "hip"])
+def test_true_color_vs_oracle(dtype, backend):
+    """The reference's true_color test matrix (test_multispectral.py:588-615: sizes (2, 4), (10, 15), these dtypes) plus
+    a larger raster with NaN / nodata cells and a constant band; uint8 RGBA equal to the restatement byte for byte."""
+    from xrspatial_amd.multispectral import true_color
+    rng = np.random.default_rng(12)
+    for shape in [(2, 4), (10, 15), (301, 517)]:
+        bands = []
+        for _ in range(3):
+            d = (rng.random(shape) * 500).astype(dtype) if dtype != np.uint8 else rng.integers(0, 255, shape).astype(dtype)
+            bands.append(d)
+        if np.issubdtype(dtype, np.floating) and shape[0] > 2:
+            bands[0][1, 2] = np.nan
+            bands[1][3, 4] = np.nan
+        bands[0][0, 1] = 0
+        aggs = [raster(b, backend=backend) for b in bands]
+        out = true_color(*aggs, name='tc')
+        assert out.name == 'tc' and out.dims == ('y', 'x', 'band') and out.shape == shape + (4,)
+        assert isinstance(out.data, xs.DeviceArray) == (backend == 'hip')
+        got = host(out.data)
+        assert got.dtype == np.uint8
+        np.testing.assert_array_equal(got, orc.true_color(*bands))
+        np.testing.assert_array_equal(host(out['band'].data), [0, 1, 2, 3])
+    flat = raster(np.full((6, 9), 5, dtype=dtype), backend=backend)
+    got = host(true_color(flat, flat, flat, nodata=7, c=4.0, th=0.3).data)
+    np.testing.assert_array_equal(got, orc.true_color(*[np.full((6, 9), 5, dtype=dtype)] * 3, nodata=7, c=4.0, th=0.3))
+    assert (got == 0).all()                                                     # constant bands, all <= nodata

@@ -264,3 +264,39 @@ def test_hotspots(golden):
     np.testing.assert_array_equal(got, [[0, 0, 95, 0, 0, 0], [0, 0, 0, 0, -90, 0], [0, 0, -90, 0, 0, 0], [0, 0, 0, 0, 0, 0]])
     with pytest.raises(ZeroDivisionError):
         orc.hotspots(np.zeros((10, 20)), np.ones((3, 3)))
+
+
+def test_trim_crop_reference_cases():
+    """The reference's own trim / crop tests (test_zonal.py:1047-1211) pin the bounds restatement."""
+    from tests.trim_crop_cases import CASES
+    for fn, arr, values, want in CASES:
+        top, bottom, left, right = (orc.trim_bounds if fn == "trim" else orc.crop_bounds)(arr, values)
+        np.testing.assert_array_equal(arr[top:bottom + 1, left:right + 1], want)
+    # the scans' far-edge behaviour when nothing stops them, and NaN never matching (`e == val`)
+    assert orc.trim_bounds(np.zeros((3, 4)), (0,)) == (2, 0, 3, 0)
+    assert orc.crop_bounds(np.zeros((3, 4)), (7,)) == (2, 0, 3, 0)
+    nan_edge = np.array([[np.nan, np.nan], [np.nan, 1.0]])
+    assert orc.trim_bounds(nan_edge) == (0, 1, 0, 1)                   # default values=(nan,) trims nothing
+    assert orc.trim_bounds(nan_edge, (1.0,)) == (0, 1, 0, 1)           # NaN cells are "data"
+    assert orc.crop_bounds(nan_edge, (np.nan,)) == (1, 0, 1, 0)
+
+
+def test_true_color_properties():
+    """No golden exists for true_color (the reference only compares numpy with dask); the restatement is held to the
+    properties of xrspatial/multispectral.py:1334-1399: band minimum -> sigmoid(th) of 0, maximum -> of 1, constant
+    band and NaN cells -> 0, alpha 0 on NaN / <= nodata, monotone in the band value."""
+    rng = np.random.default_rng(3)
+    r = rng.random((12, 17)) * 4000
+    r[2, 3] = np.nan
+    r[4, 5] = 0.5
+    g = np.full((12, 17), 7.0)
+    b = rng.integers(0, 255, (12, 17)).astype(np.int32)
+    out = orc.true_color(r, g, b)
+    assert out.shape == (12, 17, 4) and out.dtype == np.uint8
+    lo, hi = int(255 / (1 + np.exp(10 * 0.125))), int(255 / (1 + np.exp(10 * (0.125 - 1))))
+    assert out[..., 0][np.unravel_index(np.nanargmin(r), r.shape)] == lo
+    assert out[..., 0][np.unravel_index(np.nanargmax(r), r.shape)] == hi
+    assert (out[..., 1] == 0).all() and out[2, 3, 0] == 0
+    assert out[2, 3, 3] == 0 and out[4, 5, 3] == 0 and (np.delete(out[..., 3].ravel(), [2 * 17 + 3, 4 * 17 + 5]) == 255).all()
+    order = np.argsort(b.ravel(), kind='stable')
+    assert (np.diff(out[..., 2].ravel()[order].astype(int)) >= 0).all()

@@ -83,6 +83,16 @@ int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream) 
     return 0;
 }
 
+int xrs_copy2d(void *dst_dev, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes, int64_t rows,
+               void *stream) {
+    if (rows < 0 || dst_pitch < width_bytes || src_pitch < width_bytes) return fail("xrs_copy2d: bad shape");
+    if (rows == 0 || width_bytes == 0) return 0;
+    if (!dst_dev || !src_dev) return fail("xrs_copy2d: null pointer");
+    XRS_HIP(hipMemcpy2DAsync(dst_dev, dst_pitch, src_dev, src_pitch, width_bytes, (size_t)rows, hipMemcpyDeviceToDevice,
+                             as_stream(stream)));
+    return 0;
+}
+
 int xrs_version(void) { return 1; }
 
 int xrs_last_error(char *buf, size_t buflen) {

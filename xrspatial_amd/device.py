@@ -184,6 +184,11 @@ _CAST_CODE = {np.dtype(t): c for c, t in enumerate(
     (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.float64))}
 
 
+# XRS_DT_* codes of include/xrs_hip.h for every dtype a kernel can read in place (the cast codes + float32)
+DTYPE_CODE = dict(_CAST_CODE)
+DTYPE_CODE[np.dtype(np.float32)] = 9
+
+
 def _cast_f32_on_device(src: "DeviceArray", stream=None, src_is_temporary=True) -> "DeviceArray":
     out = DeviceArray(src.shape, np.float32)
     _lib.call("xrs_cast_f32", src.ptr, _CAST_CODE[src.dtype], out.ptr, src.size, stream)

@@ -1,6 +1,6 @@
 """Per-cell multispectral indices: ndvi, evi, savi, the other normalized-ratio indices that share
 ndvi's kernel (nbr, nbr2, ndmi) and arvi, gci, sipi, ebbi.  Reference: xrspatial/multispectral.py.
-(`true_color` is an RGBA image composer, not a raster index: out of scope.)
+`true_color` (the RGBA composite with a sigmoid contrast stretch) runs on the device too.
 """
 from __future__ import annotations
 
@@ -10,7 +10,7 @@ from . import _lib
 from ._launch import finish, get_stream, percell_pipelined, sharded_f32
 from ._xr import DataArray
 from .dataset_support import supports_dataset_bands
-from .device import DeviceArray, to_device_f32
+from .device import DTYPE_CODE, DeviceArray, to_device_f32
 from .sharded import ShardedArray, same_layout
 from .utils import ArrayTypeFunctionMapping, validate_arrays
 
@@ -150,3 +150,43 @@ def sipi(nir_agg, red_agg, blue_agg, name='sipi'):
 def ebbi(red_agg, swir_agg, tir_agg, name='ebbi'):
     """Enhanced Built-Up and Bareness Index (swir - red) / (10 * sqrt(swir + tir))  (multispectral.py:1209-1332)."""
     return _simple_index("xrs_ebbi_f32", red_agg, (red_agg, swir_agg, tir_agg), name)
+
+
+def _true_color_hip(r, g, b, nodata, c, th):
+    # replaces _true_color_numpy / _normalize_data_cpu (multispectral.py:1334-1361, 1387-1399): three min / max
+    # reductions, then one pass that stretches the bands and packs RGBA bytes
+    _lib.require_device()
+    like_numpy = not isinstance(r, DeviceArray)
+    stream = get_stream()
+    raw = r if isinstance(r, DeviceArray) else np.ascontiguousarray(r)
+    if raw.dtype not in DTYPE_CODE:                       # bool, float16 ...: compared as float64
+        raw = np.asarray(raw.get() if isinstance(raw, DeviceArray) else raw).astype(np.float64)
+    raw_dev = raw if isinstance(raw, DeviceArray) else DeviceArray.from_numpy(raw)
+    red = raw_dev.astype(np.float32)                      # (device-side cast; a float32 band is used as is)
+    bands = [red, to_device_f32(g), to_device_f32(b)]
+    minmax = DeviceArray((6,), np.float32)
+    for i, band in enumerate(bands):
+        _lib.call("xrs_nan_minmax_f32", band.ptr, band.size, minmax.ptr + 8 * i, stream)
+    out = DeviceArray(tuple(red.shape) + (4,), np.uint8)
+    _lib.call("xrs_true_color_u8", bands[0].ptr, bands[1].ptr, bands[2].ptr, raw_dev.ptr, DTYPE_CODE[raw_dev.dtype],
+              red.size, minmax.ptr, float(nodata), float(c), float(th), out.ptr, stream)
+    _lib.call("xrs_stream_sync", stream)                  # the float32 casts above are temporaries
+    return finish(out, like_numpy)
+
+
+def true_color(r, g, b, nodata=1, c=10.0, th=0.125, name='true_color'):
+    """RGBA composite (uint8, dims [y, x, band]) of three bands: each band is stretched to its own min .. max, passed
+    through the sigmoid `1 / (1 + exp(c * (th - v)))` and scaled to 0 .. 255; alpha is 0 where the red band is NaN or
+    <= `nodata`.  Same signature and results as `xrspatial.multispectral.true_color` (:1419-1495); device-resident bands
+    are supported as well (the reference has no GPU path for it)."""
+    validate_arrays(r, g, b)
+    if len(r.shape) != 2:
+        raise ValueError("true_color() takes 2D bands")
+    mapper = ArrayTypeFunctionMapping(numpy_func=_true_color_hip, hip_func=_true_color_hip)
+    out = mapper(r)(r.data, g.data, b.data, nodata, c, th)
+    y_dim, x_dim = r.dims
+    coords = {'band': [0, 1, 2, 3]}
+    for k in (y_dim, x_dim):
+        if k in r.coords:
+            coords[k] = r.coords[k]
+    return DataArray(out, name=name, dims=[y_dim, x_dim, 'band'], coords=coords, attrs=r.attrs)

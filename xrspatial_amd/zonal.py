@@ -15,7 +15,7 @@ import pandas as pd
 from . import _lib
 from ._launch import get_stream
 from ._xr import DataArray, Dataset
-from .device import DeviceArray
+from .device import DTYPE_CODE, DeviceArray
 from .sharded import ShardedArray, same_layout
 from .utils import validate_arrays
 
@@ -512,3 +512,67 @@ def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count"
         raise ValueError("Incompatible shapes")
     labels = np.asarray(values[cat_dim].values).tolist()
     return _crosstab_3d(zones.data, data, labels, zone_ids, cat_ids, nodata_values, agg)
+
+
+# ------------------------------------------------------------------ zonal.trim / zonal.crop
+def _match_bounds(data, values, invert):
+    """(top, bottom, left, right) of the cells that equal one of `values` (`invert`: that equal none), exactly as
+    the reference's four scans leave them (zonal.py:1651-1731 `_trim`, :1845-1940 `_crop`) -- including the case
+    where no cell qualifies, in which every scan runs to the far edge.  One pass over the raster on the device."""
+    _lib.require_device()
+    vals = np.asarray(list(values), dtype=np.float64).reshape(-1)
+    if vals.size > 16:
+        raise ValueError("at most 16 values are supported by the MI355X backend")
+    if len(data.shape) != 2:
+        raise ValueError("expected a 2D raster")
+    rows, cols = data.shape
+    if isinstance(data, DeviceArray):
+        dev = data if data.dtype in DTYPE_CODE else data.astype(np.float32)
+    else:
+        host = np.ascontiguousarray(data)
+        dev = DeviceArray.from_numpy(host if host.dtype in DTYPE_CODE else host.astype(np.float64))
+    box = DeviceArray((4,), np.int32)
+    stream = get_stream()
+    _lib.call("xrs_match_bbox", dev.ptr, DTYPE_CODE[dev.dtype], rows, cols, cols, vals.ctypes.data, int(vals.size),
+              int(bool(invert)), box.ptr, stream)
+    top, bottom, left, right = (int(v) for v in box.get(stream))
+    if bottom < 0:                            # nothing qualified
+        top, bottom, left, right = max(rows - 1, 0), 0, max(cols - 1, 0), 0
+    return top, bottom, left, right
+
+
+def _window(agg, top, bottom, left, right, name):
+    """`agg[top:bottom + 1, left:right + 1]` with its coordinates and attributes; device-resident data stays in HBM."""
+    ys, xs = slice(top, bottom + 1), slice(left, right + 1)
+    data = agg.data
+    if isinstance(data, DeviceArray):
+        h, w = max(bottom + 1 - top, 0), max(right + 1 - left, 0)
+        out = DeviceArray((h, w), data.dtype)
+        if h and w:
+            isz, pitch = data.dtype.itemsize, data.shape[1] * data.dtype.itemsize
+            _lib.call("xrs_copy2d", out.ptr, w * isz, data.ptr + top * pitch + left * isz, pitch, w * isz, h, get_stream())
+            _lib.call("xrs_stream_sync", get_stream())
+    else:
+        out = np.asarray(data)[ys, xs]
+    dim_y, dim_x = agg.dims
+    coords = {}
+    for key, coord in agg.coords.items():
+        cd = np.asarray(coord.data.get() if isinstance(coord.data, DeviceArray) else coord.data)
+        index = tuple(ys if d == dim_y else xs if d == dim_x else slice(None) for d in coord.dims)
+        coords[key] = DataArray(cd[index], dims=coord.dims, name=key, attrs=coord.attrs)
+    return DataArray(out, name=name, dims=agg.dims, coords=coords, attrs=agg.attrs)
+
+
+def trim(raster, values=(np.nan,), name='trim'):
+    """Drop the outer rows and columns that hold nothing but `values`.  Same signature and result as
+    `xrspatial.zonal.trim` (:1734-1842) -- including its quirk that NaN, compared with `==`, never matches, so the
+    default `values=(nan,)` trims nothing."""
+    top, bottom, left, right = _match_bounds(raster.data, values, invert=True)
+    return _window(raster, top, bottom, left, right, name)
+
+
+def crop(zones, values, zones_ids, name='crop'):
+    """The window of `values` that bounds the cells of `zones` equal to one of `zones_ids`.  Same signature and result
+    as `xrspatial.zonal.crop` (:1943-2061)."""
+    top, bottom, left, right = _match_bounds(zones.data, zones_ids, invert=False)
+    return _window(values, top, bottom, left, right, name)

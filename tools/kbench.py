@@ -141,6 +141,10 @@ def main():
     A2, B2 = 6378137.0 ** 2, 6356752.314245 ** 2
     mom = xs.DeviceArray((4,), np.float64)
     out8 = xs.DeviceArray((n, n), np.int8)
+    mm6 = xs.DeviceArray.from_numpy(np.array([0, 4000, 0, 4000, 0, 4000], np.float32))
+    mm2 = xs.DeviceArray((2,), np.float32)
+    box4 = xs.DeviceArray((4,), np.int32)
+    zero = np.zeros(1)
 
     zones5k = xs.DeviceArray((n, n), np.int32)
     for y0 in range(0, n, 2048):
@@ -226,6 +230,12 @@ def main():
                                      A2, B2, 1.0, 0, geo_work.ptr, 0, 0, S), 8),
         "geodesic_aspect": (lambda: L("xrs_geodesic_f32", dem.ptr, 0, lat1.ptr, lon1.ptr, 0, outs[0].ptr, n, n, n, n, n,
                                       A2, B2, 1.0, 1, geo_work.ptr, 0, 0, S), 8),
+        # true_color: dem stands in for the three bands (12 B read) + 4 B RGBA written; float64 exp per channel
+        "true_color": (lambda: L("xrs_true_color_u8", dem.ptr, dem.ptr, dem.ptr, dem.ptr, 9, cells, mm6.ptr, 1.0, 10.0, 0.125,
+                                 outs[0].ptr, S), 16),
+        "nan_minmax": (lambda: L("xrs_nan_minmax_f32", dem.ptr, cells, mm2.ptr, S), 4),
+        "trim_bbox_f32": (lambda: L("xrs_match_bbox", dem.ptr, 9, n, n, n, zero.ctypes.data, 1, 1, box4.ptr, S), 4),
+        "crop_bbox_i32": (lambda: L("xrs_match_bbox", zones.ptr, 4, n, n, n, zero.ctypes.data, 1, 0, box4.ptr, S), 4),
         "nan_moments": (lambda: L("xrs_nan_moments_f32", dem.ptr, cells, mom.ptr, S), 4),
         "hotspots_classify": (lambda: L("xrs_hotspots_classify_f32", dem.ptr, out8.ptr, cells, 50.0, 20.0, S), 5),
     }

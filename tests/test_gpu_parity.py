@@ -1114,6 +1114,14 @@ def test_hotspots(golden):
             near |= np.abs(np.abs(zs) - t) < 1e-5
         assert near.sum() < 100
         np.testing.assert_array_equal(got[~near], want[~near])
+    # an infinite cell: np.nanmean = inf and np.nanstd = NaN upstream -- no ZeroDivisionError, nothing is classified
+    # (found by tools/fuzz_parity.py: the variance guard used to turn that NaN into 0)
+    z[7, 9] = np.inf
+    with np.errstate(all="ignore"):
+        want = orc.hotspots(z, k)[0]
+    assert (want == 0).all()
+    for backend in ('numpy', 'hip'):
+        np.testing.assert_array_equal(host(hotspots(raster(z, backend=backend), k).data), want)
 
 
 def test_nan_moments_one_pass_conditioning():

@@ -109,7 +109,7 @@ __global__ void moments_final_kernel(Moments *m) {
         const double md = s1 / n;
         const double ssd = s2 - s1 * md;
         m->mean = shift + md;
-        m->ssd = ssd > 0.0 ? ssd : 0.0;
+        m->ssd = ssd < 0.0 ? 0.0 : ssd;            // rounding guard only: a NaN (inf cells: inf - inf) stays NaN, like np.nanstd
         m->sum = m->mean * n;
     } else {
         m->mean = nan(""); m->ssd = 0.0; m->sum = 0.0;

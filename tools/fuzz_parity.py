@@ -30,7 +30,12 @@ def host(a):
     return a.get() if hasattr(a, "get") and not isinstance(a, np.ndarray) else np.asarray(a)
 
 
+BIG = False     # --big: rasters large enough (>= 32 MiB) for the banded upload / compute / download pipelines
+
+
 def pick_shape(rng, max_cells):
+    if BIG:
+        return int(rng.integers(2100, 4200)), int(rng.choice([2048, 2052, 3000, 3601, 4096, 4100]))
     special = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 259, 511, 513, 1023, 1025, 1030]
     while True:
         rows = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 700))
@@ -123,17 +128,17 @@ def one_case(rng, max_cells):
             if op == "apply":
                 stat = str(rng.choice(orc.FOCAL_STATS))
                 fn = getattr(focal, "_calc_" + stat)
-                return desc + " " + stat, close(focal.apply(agg, k, fn).data, corc.focal_apply(z, k, stat), rtol=1e-6, atol=1e-30)
+                return desc + " " + stat, close(focal.apply(agg, k, fn).data, corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=1e-30)
             if op == "focal_stats":
                 got = host(focal.focal_stats(agg, k).data)
                 for i, stat in enumerate(orc.FOCAL_STATS):
-                    err = close(got[i], corc.focal_apply(z, k, stat), rtol=1e-6, atol=1e-30)
+                    err = close(got[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=1e-30)
                     if err:
                         return desc + " " + stat, err
                 return desc, None
             if op == "convolve":
                 w = k / k.sum()
-                return desc, close(convolution_2d(agg, w).data, corc.convolve_2d(z, w), rtol=1e-6, atol=1e-30)
+                return desc, close(convolution_2d(agg, w).data, corc.convolve_2d(z, w, nthreads=8), rtol=1e-6, atol=1e-30)
             if not np.isfinite(z.astype(np.float64)).any():
                 return desc, None
             try:
@@ -215,7 +220,10 @@ def main():
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=int, default=400000)
+    ap.add_argument("--big", action="store_true", help="8-17 Mcell rasters: the banded host pipelines")
     args = ap.parse_args()
+    global BIG
+    BIG = args.big
     rng = np.random.default_rng(args.seed)
     fails = 0
     counts = {}

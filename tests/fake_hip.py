@@ -102,6 +102,24 @@ def call(name, *a):
         x, y, o, n, _ = a
         with np.errstate(all="ignore"):
             _arr(o, n, np.float32)[...] = orc.normalized_ratio(_arr(x, n, np.float32), _arr(y, n, np.float32))
+    elif name == "xrs_nan_moments_f32":
+        x, n, mom, _ = a
+        v = _arr(x, n, np.float32).astype(np.float64)
+        ok = ~np.isnan(v)
+        out = _arr(mom, 4, np.float64)
+        cnt = int(ok.sum())
+        out[0:1].view(np.uint64)[0] = cnt
+        with np.errstate(all="ignore"):
+            mean = v[ok].mean() if cnt else np.nan
+            out[1], out[2], out[3] = v[ok].sum(), ((v[ok] - mean) ** 2).sum() if cnt else 0.0, mean
+    elif name == "xrs_hotspots_classify_f32":
+        m, o, n, gmean, gstd, _ = a
+        with np.errstate(all="ignore"):
+            z = (_arr(m, n, np.float32) - np.float32(gmean)) / np.float32(gstd)
+            az = np.abs(z)
+            p = np.where(az >= 2.33, 0.0099, np.where(az >= 1.65, 0.0495, np.where(az >= 1.29, 0.0985, 1.0)))
+            conf = np.where((az > 2.58) & (p < 0.01), 99, np.where((az > 1.96) & (p < 0.05), 95, np.where((az > 1.65) & (p < 0.1), 90, 0)))
+            _arr(o, n, np.int8)[...] = (np.where(z > 0, 1, np.where(z < 0, -1, 0)) * conf).astype(np.int8)
     elif name == "xrs_zonal_scan":
         z, code, n, res, _ = a
         assert code == 0

@@ -52,6 +52,10 @@ def main(outdir):
     out['max7'] = focal.apply(dem, k7, focal._calc_max).data.get()
     out['conv5'] = convolution_2d(dem, k5).data.get()
     out['ndvi'] = xs.ndvi(dem, shard(red)).data.get()
+    stats = focal.focal_stats(dem, k5, stats_funcs=['mean', 'max', 'std'])
+    assert stats.dims == ('stats', 'y', 'x') and stats.shape == (3, y1 - y0, W)
+    out['stats5'] = stats.data.get()
+    out['hot7'] = focal.hotspots(dem, k7).data.get()
     out['chain'] = focal.mean(xs.slope(dem)).data.get()                 # a result is a shard again: its halos get exchanged
     with xs.fuse() as scope:
         f_h, f_s, f_m = xs.hillshade(dem), xs.slope(dem), focal.apply(dem, k5)
@@ -61,8 +65,10 @@ def main(outdir):
     for col in table.columns:
         out['zonal_' + col] = np.asarray(table[col])
     # what a sharded raster cannot do fails loudly
-    for bad in (lambda: focal.focal_stats(dem, k5), lambda: focal.hotspots(dem, k5),
-                lambda: zonal.stats(shard(zones_full), dem), lambda: focal.apply(shard(full, halo_cap=2), k7)):
+    for bad in (lambda: zonal.stats(shard(zones_full), dem), lambda: focal.apply(shard(full, halo_cap=2), k7),
+                lambda: zonal.crosstab(shard(zones_full), shard(zones_full)),
+                lambda: xs.slope(xs.DataArray(dem.data, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, y1 - y0),
+                                                                                   'lon': np.linspace(1, 2, W)}), method='geodesic')):
         try:
             bad()
         except (NotImplementedError, TypeError, ValueError):

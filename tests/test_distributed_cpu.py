@@ -87,14 +87,23 @@ def test_sharded_api_host_logic(tmp_path, world):
                     hillshade=orc.hillshade(full).astype(np.float32), mean3=orc.focal_mean3x3(full, passes=3),
                     apply5=orc.focal_apply(full, k5, 'mean'), max7=orc.focal_apply(full, k7, 'max'),
                     conv5=orc.convolve_2d(full, k5), ndvi=orc.normalized_ratio(full, red),
-                    chain=orc.focal_mean3x3(orc.slope(full, 30.0, 30.0)))
+                    chain=orc.focal_mean3x3(orc.slope(full, 30.0, 30.0)),
+                    stats5=np.stack([orc.focal_apply(full, k5, s) for s in ('mean', 'max', 'std')]))
     want.update(fused_hillshade=want['hillshade'], fused_slope=want['slope'], fused_apply5=want['apply5'])
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     for name, ref in want.items():
         got = np.empty_like(ref)
         for p in parts:
-            got[int(p["y0"]):int(p["y1"])] = p[name]
+            got[..., int(p["y0"]):int(p["y1"]), :] = p[name]
         np.testing.assert_array_equal(got, ref, err_msg=name)
+    # hotspots: block-wise convolution against GLOBAL moments combined from the ranks' (count, mean, ssd) triples
+    want_hot, zscore = orc.hotspots(full, k7)
+    got_hot = np.concatenate([p['hot7'] for p in parts])
+    near = np.zeros(full.shape, bool)
+    for t in (1.29, 1.65, 1.96, 2.33, 2.58):
+        near |= np.abs(np.abs(zscore) - t) < 1e-5
+    assert near.sum() < 20
+    np.testing.assert_array_equal(got_hot[~near], want_hot[~near])
     names = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
     table = orc.zonal_stats(zones, full.astype(np.float64), stats_funcs=names)
     for p in parts:

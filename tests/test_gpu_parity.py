@@ -1437,7 +1437,8 @@ def _sharded_reference_results():
     k5, k7 = circle_kernel(1, 1, 2), circle_kernel(1, 1, 3)
     want = {'slope': xs.slope(dem), 'aspect': xs.aspect(dem), 'curvature': xs.curvature(dem), 'hillshade': xs.hillshade(dem),
             'mean3': focal.mean(dem, passes=3), 'apply5': apply(dem, k5), 'max7': apply(dem, k7, focal._calc_max),
-            'conv5': convolution_2d(dem, k5), 'ndvi': xs.ndvi(dem, dev(red)), 'chain': focal.mean(xs.slope(dem))}
+            'conv5': convolution_2d(dem, k5), 'ndvi': xs.ndvi(dem, dev(red)), 'chain': focal.mean(xs.slope(dem)),
+            'stats5': focal_stats(dem, k5, stats_funcs=['mean', 'max', 'std']), 'hot7': focal.hotspots(dem, k7)}
     want = {name: host(v.data) for name, v in want.items()}
     want['fused_hillshade'], want['fused_slope'], want['fused_apply5'] = want['hillshade'], want['slope'], want['apply5']
     table = zonal.stats(dev(zones_full), dem, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
@@ -1461,9 +1462,10 @@ def test_sharded_array_single_rank_is_the_device_path():
     for col in table.columns:
         np.testing.assert_allclose(np.asarray(zt[col], dtype=np.float64), np.asarray(table[col], dtype=np.float64), rtol=1e-12)
     with pytest.raises(TypeError):
-        ShardedArray(4, 4, np.int8)
-    with pytest.raises(TypeError):
-        focal_stats(dem, k5)
+        ShardedArray(4, 4, np.int16)
+    stack = focal_stats(dem, k5).data
+    assert stack.shape == (7,) + full.shape and isinstance(stack[0], ShardedArray)
+    np.testing.assert_array_equal(stack.get(), host(focal_stats(xs.DataArray(xs.DeviceArray.from_numpy(full), dims=['y', 'x']), k5).data))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -1492,8 +1494,11 @@ def test_sharded_api_equals_single_gpu(tmp_path, world):
     for name, ref in want.items():
         got = np.empty_like(ref)
         for p in parts:
-            got[int(p["y0"]):int(p["y1"])] = p[name]
-        np.testing.assert_array_equal(got, ref, err_msg=name)
+            got[..., int(p["y0"]):int(p["y1"]), :] = p[name]
+        if name == 'hot7':       # (global moments combined from per-rank triples: the z-score may differ in the last ulp)
+            assert (got != ref).sum() <= 2, name
+        else:
+            np.testing.assert_array_equal(got, ref, err_msg=name)
     for p in parts:
         for col in table.columns:
             np.testing.assert_allclose(p['zonal_' + col].astype(np.float64), np.asarray(table[col], dtype=np.float64),

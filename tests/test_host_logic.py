@@ -417,9 +417,7 @@ def test_sharded_array_bookkeeping(monkeypatch):
     with pytest.raises(NotImplementedError):
         ArrayTypeFunctionMapping(numpy_func=1, hip_func=2)(agg)
     with pytest.raises(NotImplementedError):
-        focal.hotspots(agg, np.ones((3, 3)))
-    with pytest.raises(TypeError):
-        focal.focal_stats(agg, np.ones((3, 3)))
+        zonal.crosstab(DataArray(ShardedArray.from_numpy(z.astype(np.int32)), dims=['y', 'x']), agg)
     with pytest.raises(TypeError):
         xa.slope(DataArray(solo, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, 40), 'lon': np.linspace(1, 2, 12)}),
                  method='geodesic')

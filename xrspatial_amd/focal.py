@@ -13,6 +13,7 @@ from ._xr import DataArray
 from .convolution import _kernel_f64, custom_kernel
 from .dataset_support import supports_dataset
 from .device import DeviceArray, to_device_f32
+from .sharded import ShardedArray, ShardedStack
 from .utils import ArrayTypeFunctionMapping
 
 # order of the XRS_STAT_* enum in include/xrs_hip.h
@@ -104,6 +105,25 @@ def _apply_sharded(data, kernel, stat):
     _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k.ctypes.data,
               k.shape[0], k.shape[1], None, ht, hb, stream)
     return out
+
+
+def _focal_stats_sharded(data, kernel, stats):
+    """All requested statistics of a sharded raster in one pass; {stat: ShardedArray}."""
+    _lib.require_device()
+    k = _kernel_f64(kernel)
+    src = sharded_f32(data)
+    stream = get_stream()
+    ht, hb = src.halos(k.shape[0] // 2, stream)
+    rows, cols = src.shape
+    outs = {s: src.like(np.float32) for s in dict.fromkeys(stats)}
+    ptrs = (ctypes.c_void_p * 7)()
+    mask = 0
+    for s, arr in outs.items():
+        ptrs[_STAT_INDEX[s]] = arr.ptr
+        mask |= 1 << _STAT_INDEX[s]
+    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, cols, cols, k.ctypes.data, k.shape[0], k.shape[1],
+              None, ht, hb, stream)
+    return outs
 
 
 def _mean_sharded(data, excludes, passes):
@@ -215,6 +235,12 @@ def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 
     for s in stats_funcs:
         if s not in _STAT_INDEX:
             raise KeyError(s)
+    if isinstance(agg.data, ShardedArray):
+        planes = _focal_stats_sharded(agg.data, kernel, stats_funcs)
+        coords = dict(agg.coords.items())
+        coords['stats'] = np.array(stats_funcs, dtype=object)
+        return DataArray(ShardedStack([planes[s] for s in stats_funcs]), dims=('stats',) + tuple(agg.dims), coords=coords,
+                         attrs=agg.attrs)
     if not isinstance(agg.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(agg)))
     if pipeline_ok(agg.data) and len(set(stats_funcs)) == len(stats_funcs) and max(kernel.shape) // 2 < 128:
@@ -263,6 +289,45 @@ def _hotspots_hip(data, kernel):
     return finish(out, like_numpy)
 
 
+def _hotspots_sharded(data, kernel):
+    # the reference's dask path (focal.py:940-984): block-wise convolution, GLOBAL mean / std, block-wise classification.
+    # Here every rank reduces its rows to (count, mean, sum of squared deviations); the triples are combined pairwise
+    # (Chan et al.) after ONE small all-reduce, so every rank classifies against the same global moments.
+    from .convolution import _convolve_2d_sharded
+    if not (issubclass(data.dtype.type, np.integer) or issubclass(data.dtype.type, np.floating)):
+        raise ValueError("data type must be integer or float")
+    _lib.require_device()
+    src = sharded_f32(data)
+    k = np.asarray(kernel, dtype=np.float64)
+    mean_array = _convolve_2d_sharded(src, k / k.sum())
+    stream = get_stream()
+    mom = DeviceArray((4,), np.float64)
+    _lib.call("xrs_nan_moments_f32", src.ptr, src.size, mom.ptr, stream)
+    raw = mom.get(stream)
+    count = float(raw[0:1].view(np.uint64)[0])
+    mine = np.array([count, raw[3] if count else 0.0, raw[2] if count else 0.0])
+    with np.errstate(all="ignore"):
+        if src.world > 1:
+            slots = np.zeros((src.world, 3))
+            slots[src.rank] = mine
+            slots = src.comm.allreduce(slots, 'sum')
+        else:
+            slots = mine[None, :]
+        n = slots[:, 0].sum()
+        if n:
+            mean = (slots[:, 0] * slots[:, 1]).sum() / n
+            ssd = slots[:, 2].sum() + (slots[:, 0] * (slots[:, 1] - mean) ** 2).sum()
+            global_mean, global_std = np.float32(mean), np.float32(np.sqrt(ssd / n))
+        else:
+            global_mean = global_std = np.float32(np.nan)
+    if global_std == 0:
+        raise ZeroDivisionError("Standard deviation of the input raster values is 0.")
+    out = src.like(np.int8)
+    _lib.call("xrs_hotspots_classify_f32", mean_array.ptr, out.ptr, out.size, float(global_mean), float(global_std),
+              stream)
+    return out
+
+
 def hotspots(raster, kernel):
     """Getis-Ord Gi* hot / cold spots: int8 raster of {0, +-90, +-95, +-99} confidence levels.
 
@@ -273,7 +338,7 @@ def hotspots(raster, kernel):
         raise TypeError("`raster` must be instance of DataArray")
     if raster.ndim != 2:
         raise ValueError("`raster` must be 2D")
-    mapper = ArrayTypeFunctionMapping(numpy_func=_hotspots_hip, hip_func=_hotspots_hip)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_hotspots_hip, hip_func=_hotspots_hip, sharded_func=_hotspots_sharded)
     out = mapper(raster)(raster.data, kernel)
     attrs = copy.deepcopy(raster.attrs)
     attrs['unit'] = '%'

@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray
 
-_DTYPES = (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.int32))
+_DTYPES = (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.int8))
 
 
 class HostTransport:
@@ -86,7 +86,7 @@ class ShardedArray:
         _lib.require_device()
         dtype = np.dtype(dtype)
         if dtype not in _DTYPES:
-            raise TypeError(f"sharded rasters are float32, float64 or int32, not {dtype}")
+            raise TypeError(f"sharded rasters are float32, float64, int32 or (results only) int8, not {dtype}")
         self.comm = comm
         self.world = int(comm.world) if comm is not None else 1
         self.rank = int(comm.rank) if comm is not None else 0
@@ -164,9 +164,37 @@ class ShardedArray:
         if self.world == 1 or depth == 0:
             return 0, 0
         if not self._halo_ok:
+            if (self.shape[1] * self.dtype.itemsize) % 4:
+                raise TypeError("halo rows travel in 4-byte words: this shard's rows are not a whole number of them")
             self.comm.halo_exchange(self.base, self.halo_cap, stream)
             self._halo_ok = True
         return (depth if self.rank > 0 else 0), (depth if self.rank < self.world - 1 else 0)
+
+
+class ShardedStack:
+    """Several same-shape results of one sharded raster side by side -- the (stats, y, x) block of `focal_stats`:
+    `stack[i]` is the i-th plane as a ShardedArray, `get()` this rank's rows of all of them."""
+
+    def __init__(self, planes):
+        self.planes = list(planes)
+        same_layout(*self.planes)
+
+    shape = property(lambda self: (len(self.planes),) + tuple(self.planes[0].shape))
+    dtype = property(lambda self: self.planes[0].dtype)
+    ndim = property(lambda self: 3)
+    size = property(lambda self: len(self.planes) * self.planes[0].size)
+
+    def __len__(self):
+        return len(self.planes)
+
+    def __getitem__(self, i):
+        return self.planes[i]
+
+    def get(self, stream=None) -> np.ndarray:
+        return np.stack([p.get(stream) for p in self.planes])
+
+    def __repr__(self):
+        return f"ShardedStack({len(self.planes)} x {self.planes[0]!r})"
 
 
 def same_layout(*arrays):

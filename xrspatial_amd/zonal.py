@@ -480,6 +480,8 @@ def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count"
         raise TypeError("zones must be instance of DataArray")
     if not isinstance(values, DataArray):
         raise TypeError("values must be instance of DataArray")
+    if isinstance(zones.data, ShardedArray) or isinstance(values.data, ShardedArray):
+        raise NotImplementedError("zonal.crosstab is not implemented for row-sharded (multi-GPU) arrays")
     if zones.ndim != 2:
         raise ValueError("zones must be 2D")
     if not (issubclass(zones.data.dtype.type, np.integer) or issubclass(zones.data.dtype.type, np.floating)):

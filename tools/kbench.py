@@ -249,7 +249,8 @@ def main():
         reps = 2 if name_.startswith("focal25") else args.reps
         med, mn = timer.time(fn, reps, warmup=2)
         gbs = cells * bpc / (med * 1e-3) / 1e9
-        results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs}
+        results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs,
+                          "bytes_per_cell": bpc}
         print(f"{name_:28s} {med:9.3f} {mn:9.3f} {cells / (med * 1e-3) / 1e6:11.0f} {gbs:10.0f}", flush=True)
     if args.json:
         with open(args.json, "w") as fh:

@@ -372,7 +372,7 @@ struct WalkConv {
                 res = (float)num;
             }
         }
-        out[yo * g.ld_out + x] = res;
+        st_stream(&out[yo * g.ld_out + x], res);
     }
 
     __device__ __forceinline__ void shift() {

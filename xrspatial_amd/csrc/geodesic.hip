@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) geodesic_grid_kernel(const GeoArgs a, con
             res = plane_to_result(A, B, a.mode);
         }
     }
-    a.out[y * a.ld_out + x] = res;
+    st_stream(&a.out[y * a.ld_out + x], res);
 }
 
 // Curvilinear grids: the reference's own sequence, per-neighbour trigonometry.
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) geodesic_kernel(const GeoArgs a, const lo
             }
         }
     }
-    a.out[y * a.ld_out + x] = res;
+    st_stream(&a.out[y * a.ld_out + x], res);
 }
 
 }  // namespace

@@ -113,7 +113,7 @@ __device__ __forceinline__ void store_row(float *out, long ld, long y, long x0, 
     if (!out) return;
     float *p = out + y * ld + x0;
     if (VEC) {
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        stg_stream(reinterpret_cast<float4 *>(p), make_float4(v[0], v[1], v[2], v[3]));
     } else {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
     for (int r = 0; r < RPW; ++r) {
         const long y = Y0 + wy * RPW + r;
         float *p = a.out[XRS_STAT_MEAN] + y * a.ld_out + x0;
-        *reinterpret_cast<float4 *>(p) = make_float4((float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
-                                                     (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
+        stg_stream(reinterpret_cast<float4 *>(p), make_float4((float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                                                     (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)));
     }
 }
 
@@ -477,7 +477,11 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
 }
 
 template <int KH, int KW, int RB>
-__global__ void __launch_bounds__(256, 4) focal_mean_direct_kernel(const KxkArgs a) {
+#ifndef XRS_LB_MEAN
+#define XRS_LB_MEAN 4
+#endif
+// (3x3: the three inlined bodies need ~150 VGPRs; at 4 workgroups per CU they spilled 25 registers and ran at half speed)
+__global__ void __launch_bounds__(256, KH == 3 ? 3 : XRS_LB_MEAN) focal_mean_direct_kernel(const KxkArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(256) focal_mean3_kernel(const Mean3Args a) {
         }
         res = s / (double)n;
     }
-    a.out[y * a.ld_out + x] = res;
+    st_stream(&a.out[y * a.ld_out + x], res);
 }
 
 // Strip version of focal.mean for 16-byte friendly rasters: a wave owns 256 columns x 4 rows, each lane
@@ -808,11 +812,9 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
         if (!__any(bad)) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                xrs_d2u *q = reinterpret_cast<xrs_d2u *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
-                xrs_d2u q0, q1;
-                q0.x = res[r][0]; q0.y = res[r][1]; q1.x = res[r][2]; q1.y = res[r][3];
-                q[0] = q0;
-                q[1] = q1;
+                double *q = a.out + (y0 + r) * a.ld_out + x_tile + loff;
+                store_d2u(q, res[r][0], res[r][1]);
+                store_d2u(q + 2, res[r][2], res[r][3]);
             }
             return;
         }
@@ -842,11 +844,9 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
                 const double c = w[1][o + 1];
                 m[o] = is_excluded(a, c) ? c : s / (double)n;           // 0/0 -> NaN like the reference
             }
-            xrs_d2u *q = reinterpret_cast<xrs_d2u *>(a.out + (y0 + r) * a.ld_out + x_tile + loff);
-            xrs_d2u q0, q1;
-            q0.x = m[0]; q0.y = m[1]; q1.x = m[2]; q1.y = m[3];
-            q[0] = q0;
-            q[1] = q1;
+            double *q = a.out + (y0 + r) * a.ld_out + x_tile + loff;
+            store_d2u(q, m[0], m[1]);
+            store_d2u(q + 2, m[2], m[3]);
         }
         return;
     }
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
                 }
                 resv = s / (double)n;
             }
-            a.out[y * a.ld_out + x] = resv;
+            st_stream(&a.out[y * a.ld_out + x], resv);
         }
     }
 }

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(1024, 8) focal_mean_runs_kernel(const RunArgs 
                     if (!isnan(val)) { s += (double)val; ++n; }
                 }
             }
-            a.out[y * a.ld_out + x] = (float)(s * rcp_count(n));
+            st_stream(&a.out[y * a.ld_out + x], (float)(s * rcp_count(n)));
         }
         return;
     }
@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(1024, 8) focal_mean_runs_kernel(const RunArgs 
         }
     }
     const long x0 = X0 + lane;
-    if (x0 < a.cols) a.out[y * a.ld_out + x0] = (float)(acc0 * (counted ? rcp_count(cnt0) : a.inv_ntaps));
-    if (x0 + 64 < a.cols) a.out[y * a.ld_out + x0 + 64] = (float)(acc1 * (counted ? rcp_count(cnt1) : a.inv_ntaps));
+    if (x0 < a.cols) st_stream(&a.out[y * a.ld_out + x0], (float)(acc0 * (counted ? rcp_count(cnt0) : a.inv_ntaps)));
+    if (x0 + 64 < a.cols) st_stream(&a.out[y * a.ld_out + x0 + 64], (float)(acc1 * (counted ? rcp_count(cnt1) : a.inv_ntaps)));
 }
 
 // Mean + variance + standard deviation from prefix sums (the all-statistics path for large masks).

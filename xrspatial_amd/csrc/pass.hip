@@ -187,7 +187,10 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
 }
 
 template <int OPS, int KH, int KW, int RB, bool NT>
-__global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) raster_pass_kernel(const PassArgs a) {
+#ifndef XRS_LB_PASS
+#define XRS_LB_PASS 4
+#endif
+__global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
@@ -208,7 +211,10 @@ __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : 4) r
 
 template <int OPS, int K>
 int launch_pass(PassArgs &a, hipStream_t s) {
-    constexpr int RB = 4;
+#ifndef XRS_PASS_RB
+#define XRS_PASS_RB 4
+#endif
+    constexpr int RB = XRS_PASS_RB;
     a.tiles_x = (a.cols + 255) / 256;
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
     const long grid = xcd_grid(a.n_tiles);

@@ -142,9 +142,9 @@ __global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, co
         const long i = base + 64 * u;
         a[u] = b[u] = c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) {
-            a[u] = reinterpret_cast<const float4 *>(q.a)[i];
-            b[u] = reinterpret_cast<const float4 *>(q.b)[i];
-            if (Bands<K>::n == 3) c[u] = reinterpret_cast<const float4 *>(q.c)[i];
+            a[u] = ldg_stream(reinterpret_cast<const float4 *>(q.a) + i);
+            b[u] = ldg_stream(reinterpret_cast<const float4 *>(q.b) + i);
+            if (Bands<K>::n == 3) c[u] = ldg_stream(reinterpret_cast<const float4 *>(q.c) + i);
         }
     }
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, co
             o.y = cell<K>(q, a[u].y, b[u].y, c[u].y);
             o.z = cell<K>(q, a[u].z, b[u].z, c[u].z);
             o.w = cell<K>(q, a[u].w, b[u].w, c[u].w);
-            reinterpret_cast<float4 *>(q.out)[i] = o;
+            stg_stream(reinterpret_cast<float4 *>(q.out) + i, o);
         }
     }
     if (chunk == 0) {                                          // n % 4 trailing cells

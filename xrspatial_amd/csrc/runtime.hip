@@ -15,10 +15,10 @@ __global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, floa
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (base + 64 * u < n4) v[u] = src[base + 64 * u];
+        if (base + 64 * u < n4) v[u] = ldg_stream(src + base + 64 * u);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (base + 64 * u < n4) dst[base + 64 * u] = v[u];
+        if (base + 64 * u < n4) stg_stream(dst + base + 64 * u, v[u]);
 }
 
 // `.astype(np.float32)` of the reference's wrappers (e.g. xrspatial/slope.py:82, multispectral.py:834) done in

@@ -68,7 +68,8 @@ __device__ __forceinline__ void load_strip(const Args &a, long x_tile, long y0, 
             }
         } else if (ok) {
             if (!(RX == 2 && INTERIOR)) {
-                const F4U c4 = *reinterpret_cast<const F4U *>(p);
+                const F4U c4 = *reinterpret_cast<const F4U *>(p);       // (default cache policy: the halo rows / columns
+                                                                        //  are re-read by the neighbouring strips from L2)
                 v[r][RX] = c4.x; v[r][RX + 1] = c4.y; v[r][RX + 2] = c4.z; v[r][RX + 3] = c4.w;
             }
             if (RX == 1) {

@@ -48,10 +48,8 @@ __device__ __forceinline__ void store4<float>(float *p, const float (&v)[4]) {
 }
 template <>
 __device__ __forceinline__ void store4<double>(double *p, const float (&v)[4]) {
-    xrs_d2u a, b;
-    a.x = (double)v[0]; a.y = (double)v[1]; b.x = (double)v[2]; b.y = (double)v[3];
-    reinterpret_cast<xrs_d2u *>(p)[0] = a;
-    reinterpret_cast<xrs_d2u *>(p)[1] = b;
+    store_d2u(p, (double)v[0], (double)v[1]);
+    store_d2u(p + 2, (double)v[2], (double)v[3]);
 }
 // the last lane of a row when cols % 4 != 0: only the first `n` results exist
 template <typename OutT>

@@ -65,9 +65,84 @@ __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); 
 struct __attribute__((packed, aligned(4))) xrs_f4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(8))) xrs_d2u { double x, y; };
 __device__ __forceinline__ xrs_f4u load_f4u(const float *p) { return *reinterpret_cast<const xrs_f4u *>(p); }
+
+// Streaming ("nt") cache policy for planes that are read or written exactly once per launch (copy, per-cell indices,
+// zonal reductions).  On a 1 GiB + 1 GiB copy on this chip nt loads + nt stores measured 6 290 GB/s against 5 870 with
+// the default policy (experiments/copy_sweep.hip); ndvi / evi / savi gain 4-5 %.  NOT for the stencil kernels' input:
+// their halo rows and columns are re-read by neighbouring strips out of L2, and streaming loads cost them 4-35 %
+// (profiles/r01/nt_ab_r01.log).  XRS_NT=0 builds the default-policy library for A/B runs.
+#ifndef XRS_NT
+#define XRS_NT 1
+#endif
+typedef float xrs_v4f __attribute__((ext_vector_type(4)));
+typedef float xrs_v4fu __attribute__((ext_vector_type(4), aligned(4)));
+typedef int xrs_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_stream(const float4 *p) {
+#if XRS_NT
+    const xrs_v4f v = __builtin_nontemporal_load(reinterpret_cast<const xrs_v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ int4 ldg_stream(const int4 *p) {
+#if XRS_NT
+    const xrs_v4i v = __builtin_nontemporal_load(reinterpret_cast<const xrs_v4i *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stg_stream(float4 *p, const float4 v) {
+#if XRS_NT
+    xrs_v4f q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    __builtin_nontemporal_store(q, reinterpret_cast<xrs_v4f *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ xrs_f4u load_f4u_stream(const float *p) {       // dword-aligned 16 bytes
+#if XRS_NT
+    const xrs_v4fu v = __builtin_nontemporal_load(reinterpret_cast<const xrs_v4fu *>(p));
+    xrs_f4u r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+#else
+    return load_f4u(p);
+#endif
+}
+// Results are written once and not read again by the launch that produces them: streaming ("nt") stores.  Same-box A/B
+// (profiles/r01/ntst_ab_r01.log): hillshade 0.386 -> 0.366 ms, slope 0.422 -> 0.400, curvature 0.388 -> 0.361,
+// 5x5 convolve 0.556 -> 0.438, four terrain products 1.147 -> 1.070.  XRS_NT_STENCIL_STORES=0: default policy.
+#ifndef XRS_NT_STENCIL_STORES
+#define XRS_NT_STENCIL_STORES 1
+#endif
+typedef double xrs_v2du_st __attribute__((ext_vector_type(2), aligned(8)));
+template <typename T>
+__device__ __forceinline__ void st_stream(T *p, const T v) {          // one scalar result per lane
+#if XRS_NT_STENCIL_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_d2u(double *p, double x, double y) {    // two doubles at 8-byte alignment
+#if XRS_NT_STENCIL_STORES
+    xrs_v2du_st q; q.x = x; q.y = y;
+    __builtin_nontemporal_store(q, reinterpret_cast<xrs_v2du_st *>(p));
+#else
+    xrs_d2u q; q.x = x; q.y = y;
+    *reinterpret_cast<xrs_d2u *>(p) = q;
+#endif
+}
+typedef float xrs_v4fu_st __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void store_f4u(float *p, float x, float y, float z, float w) {
+#if XRS_NT_STENCIL_STORES
+    xrs_v4fu_st q; q.x = x; q.y = y; q.z = z; q.w = w;
+    __builtin_nontemporal_store(q, reinterpret_cast<xrs_v4fu_st *>(p));
+#else
     xrs_f4u q; q.x = x; q.y = y; q.z = z; q.w = w;
     *reinterpret_cast<xrs_f4u *>(p) = q;
+#endif
 }
 
 // kxk_runs.hip: prefix-sum focal mean for large run-structured masks.  0 = launched, -1 = mask not

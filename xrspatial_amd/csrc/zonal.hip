@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { z[4 * u + k] = -1; v[4 * u + k] = 0; }
             if (i < c_end) {
-                const int4 zi = reinterpret_cast<const int4 *>(a.zidx)[i];
+                const int4 zi = ldg_stream(reinterpret_cast<const int4 *>(a.zidx) + i);
                 z[4 * u] = zi.x; z[4 * u + 1] = zi.y; z[4 * u + 2] = zi.z; z[4 * u + 3] = zi.w;
                 if (a.lut) {                                            // (wave-uniform)
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
                     for (int k = 0; k < 4; ++k) z[4 * u + k] -= a.zbase;        // (negative / >= nz: outside the window)
                 }
                 if constexpr (sizeof(VT) == 4) {
-                    const float4 vf = reinterpret_cast<const float4 *>(a.vals)[i];
+                    const float4 vf = ldg_stream(reinterpret_cast<const float4 *>(a.vals) + i);
                     v[4 * u] = vf.x; v[4 * u + 1] = vf.y; v[4 * u + 2] = vf.z; v[4 * u + 3] = vf.w;
                 } else {
                     const double2 va = reinterpret_cast<const double2 *>(a.vals)[2 * i];

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) minmax_kernel(const float *__restrict__ x
     long scalar_from = begin;                                              // cells not covered by 16-byte loads
     if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && begin < end) {      // (`begin` is a multiple of 1024)
         for (long i = begin + (long)threadIdx.x * 4; i + 3 < end; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + i);
+            const float4 v = ldg_stream(reinterpret_cast<const float4 *>(x + i));
             lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));      // fminf / fmaxf skip NaN operands
             hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
         }
@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) true_color_kernel(const ColorArgs a) {
         px.y = stretch(a.band[1][i], glo, gr, a.c, a.th);
         px.z = stretch(a.band[2][i], blo, br, a.c, a.th);
         px.w = RawLE<RawT>::transparent(a.red_raw, i, a.nodata) ? 0 : 255;
-        a.out[i] = px;
+        st_stream(reinterpret_cast<unsigned *>(a.out) + i,
+                  (unsigned)px.x | ((unsigned)px.y << 8) | ((unsigned)px.z << 16) | ((unsigned)px.w << 24));
     }
 }
 

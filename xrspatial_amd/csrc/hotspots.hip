@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *x, long n, Mo
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long i = i0 + 256 * u;
-            v[u] = i < c_end ? reinterpret_cast<const float4 *>(x)[i] : make_float4(nan_f32(), nan_f32(), nan_f32(), nan_f32());
+            v[u] = i < c_end ? ldg_stream(reinterpret_cast<const float4 *>(x) + i) : make_float4(nan_f32(), nan_f32(), nan_f32(), nan_f32());
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) classify_kernel(const float *mean_array, 
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i0 + 256 * u < c_end) v[u] = reinterpret_cast<const float4 *>(mean_array)[i0 + 256 * u];
+            if (i0 + 256 * u < c_end) v[u] = ldg_stream(reinterpret_cast<const float4 *>(mean_array) + i0 + 256 * u);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (i0 + 256 * u < c_end) {
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) classify_kernel(const float *mean_array, 
                 const unsigned b1 = (unsigned char)classify((v[u].y - gmean) / gstd);
                 const unsigned b2 = (unsigned char)classify((v[u].z - gmean) / gstd);
                 const unsigned b3 = (unsigned char)classify((v[u].w - gmean) / gstd);
-                reinterpret_cast<unsigned *>(out)[i0 + 256 * u] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                st_stream(reinterpret_cast<unsigned *>(out) + i0 + 256 * u, b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
             }
     }
     const long stride = (long)gridDim.x * 256;

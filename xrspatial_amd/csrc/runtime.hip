@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) cast_f32_kernel(const T *__restrict__ src
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
             const float4 v = make_float4((float)src[i], (float)src[i + 1], (float)src[i + 2], (float)src[i + 3]);
-            *reinterpret_cast<float4 *>(dst + i) = v;
+            stg_stream(reinterpret_cast<float4 *>(dst + i), v);
         } else {
             for (long j = i; j < n; ++j) dst[j] = (float)src[j];
         }

@@ -75,7 +75,10 @@ __device__ __forceinline__ void for_each_chunked(const T *z, long n, bool vec, F
         for (int u = 0; u < U; ++u) {
             const long i = i0 + 256 * u;
             have[u] = i < c_end;
-            if (have[u]) slot[u] = reinterpret_cast<const Slot *>(z)[i];
+            if (have[u]) {                 // (the id raster is read once per launch: streaming policy)
+                const int4 raw = ldg_stream(reinterpret_cast<const int4 *>(z) + i);
+                __builtin_memcpy(&slot[u], &raw, 16);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)

@@ -57,7 +57,10 @@ def main():
                          "exchange behind the interior rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="experiment: do not record per-kernel HIP events inside the timed region")
+                    help="experiment: do not record HIP events inside the timed region")
+    ap.add_argument("--per-step-events", action="store_true",
+                    help="fused mode: bracket every launch with its own pair of HIP events (default: ONE pair around the "
+                         "K timed launches; --unfused always uses per-kernel events)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -219,11 +222,20 @@ def main():
         L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
     for _ in range(args.warmup):
         step()
-    events = [[make_event() for _ in range(3)] for _ in range(args.steps)]
+    # Kernel time, measured live on the launch stream inside the timed region.  Fused step (one launch): ONE pair of
+    # HIP events around the K launches -- average launch interval, inter-launch gaps included (three event records per
+    # step cost ~1.5 % of the step; profiles/r01).  Two launches per step (--unfused): an event between the kernels.
+    per_step = (args.unfused or args.per_step_events) and not args.no_kernel_events
+    events = [[make_event() for _ in range(3)] for _ in range(args.steps)] if per_step else []
+    bracket = (make_event(), make_event())
     fence()
     t0 = time.perf_counter()
+    if not args.no_kernel_events:
+        L("xrs_event_record", bracket[0], stream)
     for k in range(args.steps):
-        step(None if args.no_kernel_events else events[k])
+        step(events[k] if per_step else None)
+    if not args.no_kernel_events:
+        L("xrs_event_record", bracket[1], stream)
     L("xrs_stream_sync", stream)
     L("xrs_device_sync")
     if dist is not None:
@@ -240,13 +252,16 @@ def main():
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     ms = ctypes.c_float()
     hill_ms, focal_ms = [], []
-    for e in ([] if args.no_kernel_events else events):
+    for e in events:
         L("xrs_event_elapsed_ms", e[0], e[1], ctypes.byref(ms))
         hill_ms.append(ms.value)
         L("xrs_event_elapsed_ms", e[1], e[2], ctypes.byref(ms))
         focal_ms.append(ms.value)
     hill_avg, focal_avg = (float(np.mean(hill_ms)), float(np.mean(focal_ms))) if hill_ms else (float("nan"), float("nan"))
-    # (fused: events[0] -> events[1] brackets the single launch; [1] -> [2] is empty)
+    # (fused, per-step events: events[0] -> events[1] brackets the single launch; [1] -> [2] is empty)
+    if not per_step and not args.no_kernel_events:
+        L("xrs_event_elapsed_ms", bracket[0], bracket[1], ctypes.byref(ms))
+        hill_avg, focal_avg = ms.value / args.steps, 0.0
 
     # Correctness of the sharded run, outside the timed region: the rows either side of every shard boundary
     # (the ones that depend on exchanged halo rows) are compared with the CPU oracle on a regenerated band.
@@ -396,6 +411,8 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes * cells_rank,
             "launch_ms": round(dom_ms, 4),
+            "launch_ms_from": ("HIP events around every launch" if (args.unfused or args.per_step_events) else
+                               "one HIP event pair around the K timed launches on the launch stream / K (gaps included)"),
             "measured_copy_gbs": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4),
             "algorithmic_bytes_per_cell": alg_bytes,

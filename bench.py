@@ -263,35 +263,32 @@ def main():
         L("xrs_event_elapsed_ms", bracket[0], bracket[1], ctypes.byref(ms))
         hill_avg, focal_avg = ms.value / args.steps, 0.0
 
-    # Correctness of the sharded run, outside the timed region: the rows either side of every shard boundary
-    # (the ones that depend on exchanged halo rows) are compared with the CPU oracle on a regenerated band.
+    # Correctness of the sharded run, outside the timed region: the rows either side of every shard boundary (the ones
+    # that depend on exchanged halo rows) must equal what the SAME kernel produces for them when it sees the rows of
+    # both shards in one unsharded block -- the block around the boundary is regenerated, uploaded and run through one
+    # pass on this GPU.  Bit for bit: sharding may not change a single result.
     halo_check = None
     if world > 1:
-        from oracle import c_oracle as corc
-        from oracle import xrs_oracle as orc
-        worst = 0.0
+        mismatched = 0
         for side, has_nb in (("top", rank > 0), ("bottom", rank < world - 1)):
             if not has_nb:
                 continue
             yb = y_begin if side == "top" else y_begin + rows              # the boundary row (global)
             above = synth.asv_dem(band, cols, y0=yb - band, total_rows=total_rows)[-8:]
             below = synth.asv_dem(band, cols, y0=yb, total_rows=total_rows)[:8]
-            block = np.concatenate([above, below])                           # global rows yb-8 .. yb+7
-            want_f = corc.focal_apply(block, kernel, 'mean', nthreads=4)[4:12]   # rows yb-4 .. yb+3: full windows
-            want_h = orc.hillshade(block)[4:12]
+            block = xs.DeviceArray.from_numpy(np.concatenate([above, below]))   # global rows yb-8 .. yb+7
+            blk_h, blk_f = xs.DeviceArray((16, cols), np.float32), xs.DeviceArray((16, cols), np.float32)
+            L("xrs_raster_pass_f32", block.ptr, None, None, None, blk_h.ptr, blk_f.ptr, kernel.ctypes.data, kr, kc, None,
+              16, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, 0, 0, stream)
             lo = 0 if side == "top" else rows - 4                            # owned rows next to the boundary
-            sl = slice(4, 8) if side == "top" else slice(0, 4)
-            for dev_out, want in ((out_focal, want_f), (out_hill, want_h)):
+            sl = slice(8, 12) if side == "top" else slice(4, 8)              # the same rows inside the block (full windows)
+            for dev_out, blk in ((out_focal, blk_f), (out_hill, blk_h)):
                 got = dev_out.rows(lo, lo + 4).get(stream)
-                w = want[sl]
-                ok_mask = np.isfinite(w)
-                err = np.max(np.abs(got[ok_mask] - w[ok_mask]) / np.maximum(np.abs(w[ok_mask]), 1e-6)) if ok_mask.any() else 0.0
-                if not np.array_equal(np.isnan(got), np.isnan(w)):
-                    err = float("inf")
-                worst = max(worst, float(err))
-        tw = torch.tensor([worst], dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        halo_check = {"max_rel_err_vs_oracle_at_shard_boundaries": float(tw.item()), "ok": bool(tw.item() <= 1e-5)}
+                want = blk.get(stream)[sl]
+                mismatched += int(np.count_nonzero(~((got == want) | (np.isnan(got) & np.isnan(want)))))
+        tw = torch.tensor([mismatched], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+        halo_check = {"cells_differing_from_the_unsharded_pass_at_shard_boundaries": int(tw.item()), "ok": bool(tw.item() == 0)}
 
     # Calibration, outside the timed region: the streaming-copy bandwidth this GPU sustains in the library's own
     # access pattern (xrs_copy_f32, 4 B read + 4 B written per cell like the bench kernels).

@@ -1,11 +1,12 @@
-"""Differential fuzzing of the public API against the CPU oracle (test infrastructure; needs an MI355X).
+"""Differential fuzzing of the public API against the CPU oracle (test infrastructure; needs an MI355X; lives under
+tests/ because it imports the oracle -- not collected by pytest).
 
 Seeded random cases: raster shape (biased to the awkward ones -- fewer than 4 columns, widths 1..3 mod 4, one off a
 256 / 1024 tile edge, single rows), dtype, NaN density, inf cells, backend (numpy / device-resident), operator and its
 parameters.  Every result is compared with the oracle to the tolerance the parity tests use.  Prints one line per
 failure and a summary; exit code 1 if anything differed.
 
-    python tools/fuzz_parity.py [--cases 400] [--seed 1] [--max-cells 400000]
+    python tests/fuzz_parity.py [--cases 400] [--seed 1] [--max-cells 400000]
 """
 import argparse
 import os

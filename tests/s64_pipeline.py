@@ -2,7 +2,7 @@
 65536 x 65536 float32 DEM (16 GiB per plane, 4 planes resident): as three separate C-ABI calls
 (24 B per cell) and as ONE fused pass (xrs_raster_pass_f32, 16 B per cell: the DEM is read once).
 
-    python tools/s64_pipeline.py [--size 65536] [--reps 5]
+    python tests/s64_pipeline.py [--size 65536] [--reps 5]
 
 Prints per-operator ms / GB/s (8 B/cell algorithmic), the whole pipeline in Mcells/s and as a fraction
 of (a) the device copy bandwidth measured in the same process and (b) the 8 TB/s HBM3E spec.

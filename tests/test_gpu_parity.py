@@ -1115,7 +1115,7 @@ def test_hotspots(golden):
         assert near.sum() < 100
         np.testing.assert_array_equal(got[~near], want[~near])
     # an infinite cell: np.nanmean = inf and np.nanstd = NaN upstream -- no ZeroDivisionError, nothing is classified
-    # (found by tools/fuzz_parity.py: the variance guard used to turn that NaN into 0)
+    # (found by tests/fuzz_parity.py: the variance guard used to turn that NaN into 0)
     z[7, 9] = np.inf
     with np.errstate(all="ignore"):
         want = orc.hotspots(z, k)[0]

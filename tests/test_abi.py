@@ -69,3 +69,18 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "xrs_oracle" not in src, f
+                assert "fake_hip" not in src, f             # (the CPU emulation of the C ABI is for tests only)
+
+
+def test_oracle_is_used_only_by_tests_smoke_and_the_cpu_baseline():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    imp = re.compile(r"^\s*(from|import)\s+oracle\b", flags=re.M)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            assert not imp.search(open(os.path.join(ROOT, "tools", f)).read()), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in imp.finditer(bench)]
+    leg = bench.index("def cpu_baseline")
+    assert hits and all(h > leg for h in hits)              # every import sits inside the cpu_baseline function
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert all(h > entry.index("def smoke") for h in [m.start() for m in imp.finditer(entry)])

@@ -51,6 +51,7 @@ def main():
 
     ops = {
         "copy_d2d": lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, None),
+        "copy_kernel": lambda: L("xrs_copy_f32", dem.ptr, outs[0].ptr, cells, None),      # the library's streaming copy
         "hillshade": lambda: L("xrs_hillshade_f32", dem.ptr, outs[0].ptr, 0, n, n, n, n, 225.0, 25.0, 0, 0, None),
         "slope": lambda: L("xrs_slope_f32", dem.ptr, outs[1].ptr, n, n, n, n, 1.0, 1.0, 0, 0, None),
         "focal_mean_5x5": lambda: L("xrs_focal_stats_f32", dem.ptr, ptrs, 1, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, None),
@@ -71,7 +72,7 @@ def main():
         res[name] = {"ms": med, "ms_min": mn, "gb_s": cells * bpc / (med * 1e-3) / 1e9,
                      "mcells_s": cells / (med * 1e-3) / 1e6}
         print(f"{name:18s} {med:9.3f} ms  {res[name]['gb_s']:8.0f} GB/s  {res[name]['mcells_s']:10.0f} Mcells/s", flush=True)
-    copy_bw = res["copy_d2d"]["gb_s"]
+    copy_bw = max(res["copy_d2d"]["gb_s"], res["copy_kernel"]["gb_s"])      # the better of hipMemcpy and the streaming copy
     pipe = res["pipeline_3_calls"]
     pipe["frac_of_measured_copy_bw"] = pipe["gb_s"] / copy_bw
     pipe["frac_of_8TBs_spec"] = pipe["gb_s"] / 8000.0

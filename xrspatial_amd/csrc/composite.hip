@@ -130,18 +130,46 @@ __global__ void __launch_bounds__(256) box_kernel(const BoxArgs a) {
     const long y0 = (long)blockIdx.x * rows_per, y1 = y0 + rows_per < a.rows ? y0 + rows_per : a.rows;
     int top = INT_MAX, bottom = -1, left = INT_MAX, right = -1;
     const T *p = static_cast<const T *>(a.data);
-    for (long y = y0; y < y1; ++y)
-        for (long x = threadIdx.x; x < a.cols; x += 256) {
-            const double v = (double)p[y * a.ld + x];
-            bool hit = false;
-            for (int k = 0; k < a.n_values; ++k) hit = hit || (v == a.values[k]);      // NaN equals nothing, as in the reference
-            if (hit != (a.invert != 0)) {
-                top = top < (int)y ? top : (int)y;
-                bottom = bottom > (int)y ? bottom : (int)y;
-                left = left < (int)x ? left : (int)x;
-                right = right > (int)x ? right : (int)x;
+    constexpr int PER = 16 / (int)sizeof(T);                       // cells per 16-byte load
+    struct alignas(16) Slot { T e[PER]; };
+    // 16-byte streaming loads when every row starts on a 16-byte boundary; the ragged tail (and unaligned planes) cell by cell
+    const bool vec = (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (a.ld * (long)sizeof(T)) % 16 == 0;
+    const long cols_v = vec ? a.cols / PER * PER : 0;
+    const bool want = a.invert == 0;
+    for (long y = y0; y < y1; ++y) {
+        const T *row = p + y * a.ld;
+        int lo = INT_MAX, hi = -1;                                    // this thread's matching columns in this row
+        for (long x = (long)threadIdx.x * PER; x < cols_v; x += 256L * PER) {
+            const int4 raw = ldg_stream(reinterpret_cast<const int4 *>(row + x));
+            Slot s;
+            __builtin_memcpy(&s, &raw, 16);
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const double v = (double)s.e[e];
+                bool hit = false;
+                for (int k = 0; k < a.n_values; ++k) hit = hit || (v == a.values[k]);  // NaN equals nothing, as in the reference
+                if (hit == want) {
+                    lo = lo < (int)x + e ? lo : (int)x + e;
+                    hi = (int)x + e;                                  // (columns ascend within a thread's walk of a row)
+                }
             }
         }
+        for (long x = cols_v + threadIdx.x; x < a.cols; x += 256) {
+            const double v = (double)row[x];
+            bool hit = false;
+            for (int k = 0; k < a.n_values; ++k) hit = hit || (v == a.values[k]);
+            if (hit == want) {
+                lo = lo < (int)x ? lo : (int)x;
+                hi = hi > (int)x ? hi : (int)x;
+            }
+        }
+        if (hi >= 0) {
+            top = top < (int)y ? top : (int)y;
+            bottom = (int)y;                                          // (rows ascend)
+            left = left < lo ? left : lo;
+            right = right > hi ? right : hi;
+        }
+    }
     for (int off = 32; off; off >>= 1) {
         top = min(top, __shfl_xor(top, off));
         left = min(left, __shfl_xor(left, off));

@@ -60,7 +60,10 @@ __device__ __forceinline__ void put4(float *p, const float (&v)[4], int n = 4) {
 // OPS: compile-time superset of the terrain products this instantiation can emit (absent ones are skipped by
 // wave-uniform null tests, like terrain.hip's fused kernel).  Returns false when the interior fast path met a
 // non-finite window sum: the caller re-runs the focal part of the strip through the careful body.
-template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, bool TERRAIN, bool NT>
+// CMASK: the window's taps as a compile-time constant (bit ky * KW + kx), 0 = read them from a.mask_rows at run time.
+// With the mask known, the tap walk is straight-line code: no scalar branch per tap row, and the register allocator
+// sees one basic block (the circular 5x5 mask of `circle_kernel(1, 1, 2)` -- the bench's -- is instantiated this way).
+template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, bool TERRAIN, bool NT, unsigned CMASK = 0u>
 __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
@@ -119,7 +122,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             for (int ky = 0; ky < KH; ++ky) {
                 const int orow = ir - ky;
                 if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = a.mask_rows[ky];
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : a.mask_rows[ky];
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
                     if (bits >> kx & 1u) {
@@ -165,7 +168,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             for (int ky = 0; ky < KH; ++ky) {
                 const int orow = ir - ky;
                 if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = (unsigned)a.mask_rows[ky];
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
                     if (bits >> kx & 1u) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
     return true;
 }
 
-template <int OPS, int KH, int KW, int RB, bool NT>
+template <int OPS, int KH, int KW, int RB, bool NT, unsigned CMASK = 0u>
 #ifndef XRS_LB_PASS
 #define XRS_LB_PASS 4
 #endif
@@ -200,13 +203,13 @@ __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : XRS_
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!pass_body<OPS, KH, KW, RB, true, false, true, NT>(a, x_tile, y0, lane))
-            pass_body<OPS, KH, KW, RB, true, true, false, NT>(a, x_tile, y0, lane);  // NaN / inf under a window: focal part
+        if (!pass_body<OPS, KH, KW, RB, true, false, true, NT, CMASK>(a, x_tile, y0, lane))
+            pass_body<OPS, KH, KW, RB, true, true, false, NT, CMASK>(a, x_tile, y0, lane);  // NaN / inf under a window: focal part
                                                                                      // again, NaN-aware, same loads
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    pass_body<OPS, KH, KW, RB, false, true, true, NT>(a, x_tile, y0, lane);
+    pass_body<OPS, KH, KW, RB, false, true, true, NT, CMASK>(a, x_tile, y0, lane);
 }
 
 template <int OPS, int K>
@@ -219,7 +222,16 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
     const long grid = xcd_grid(a.n_tiles);
     if (grid > 0x7fffffffL) return fail("raster pass: raster too large for one launch");
-    if (a.nt_stores)
+    // circle_kernel(1, 1, 2): rows 00100 / 01110 / 11111 / 01110 / 00100
+    constexpr unsigned CIRCLE5 = 4u | 14u << 5 | 31u << 10 | 14u << 15 | 4u << 20;
+    unsigned mask = 0;
+    for (int ky = 0; ky < K; ++ky) mask |= a.mask_rows[ky] << (ky * K);
+    if (K == 5 && mask == CIRCLE5) {
+        if (a.nt_stores)
+            hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true, K == 5 ? CIRCLE5 : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, false, K == 5 ? CIRCLE5 : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else if (a.nt_stores)
         hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, false>), dim3((unsigned)grid), dim3(256), 0, s, a);

@@ -385,7 +385,9 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
 // Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
 // row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
 // sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
-template <int KH, int KW, int RB, bool INTERIOR, bool CAREFUL>
+// CMASK: the mask as a compile-time constant (bit ky * KW + kx; 0 = a.mask_rows at run time) -- straight-line tap walk for
+// the common masks (circle_kernel(1, 1, 2), np.ones((3, 3)), np.ones((5, 5))), as in the fused pass.
+template <int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, unsigned CMASK = 0u>
 __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
@@ -408,7 +410,7 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
             for (int ky = 0; ky < KH; ++ky) {
                 const int orow = ir - ky;
                 if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = (unsigned)a.mask_rows[ky];
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
                     if (bits >> kx & 1u) {
@@ -455,7 +457,7 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
             for (int ky = 0; ky < KH; ++ky) {
                 const int orow = ir - ky;
                 if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = (unsigned)a.mask_rows[ky];
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
                     if (bits >> kx & 1u) {
@@ -476,7 +478,7 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
     return true;
 }
 
-template <int KH, int KW, int RB>
+template <int KH, int KW, int RB, unsigned CMASK = 0u>
 #ifndef XRS_LB_MEAN
 #define XRS_LB_MEAN 4
 #endif
@@ -491,12 +493,12 @@ __global__ void __launch_bounds__(256, KH == 3 ? 3 : XRS_LB_MEAN) focal_mean_dir
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!focal_mean_direct_body<KH, KW, RB, true, false>(a, x_tile, y0, lane))
-            focal_mean_direct_body<KH, KW, RB, true, true>(a, x_tile, y0, lane);    // NaN / inf under a window: NaN-aware, same loads
+        if (!focal_mean_direct_body<KH, KW, RB, true, false, CMASK>(a, x_tile, y0, lane))
+            focal_mean_direct_body<KH, KW, RB, true, true, CMASK>(a, x_tile, y0, lane);    // NaN / inf under a window: NaN-aware, same loads
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    focal_mean_direct_body<KH, KW, RB, false, true>(a, x_tile, y0, lane);
+    focal_mean_direct_body<KH, KW, RB, false, true, CMASK>(a, x_tile, y0, lane);
 }
 
 // All seven statistics, compile-time 3x3 / 5x5 shape, register-resident strip (same layout as the mean
@@ -933,7 +935,17 @@ int launch_mean_fast(const KxkArgs &a, size_t lds, hipStream_t s) {
 template <int KH, int KW, int RB>
 int launch_mean_direct_rb(KxkArgs a, hipStream_t s) {
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
-    hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    // np.ones((3, 3)) as a compile-time mask: 0.41 -> 0.37 ms.  (The same for the 5x5 masks made the stand-alone kernel
+    // spill at its 128-register budget -- 0.42 -> 1.80 ms -- so they keep the run-time mask; profiles/r01/cmask2_ab_r01.log.)
+    constexpr bool SPECIALISE = KH == 3 && KW == 3 && RB == 4;
+    constexpr unsigned BOX = SPECIALISE ? (1u << (KH * KW)) - 1u : 0u;
+    unsigned mask = 0;
+    for (int ky = 0; ky < KH; ++ky) mask |= (unsigned)a.mask_rows[ky] << (ky * KW);
+    const dim3 grid((unsigned)xcd_grid(a.n_tiles));
+    if (SPECIALISE && mask == BOX)
+        hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB, BOX>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB>), grid, dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }

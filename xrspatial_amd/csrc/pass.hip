@@ -226,11 +226,17 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     constexpr unsigned CIRCLE5 = 4u | 14u << 5 | 31u << 10 | 14u << 15 | 4u << 20;
     unsigned mask = 0;
     for (int ky = 0; ky < K; ++ky) mask |= a.mask_rows[ky] << (ky * K);
+    constexpr unsigned BOX = (1u << (K * K)) - 1u;                                              // np.ones((k, k))
     if (K == 5 && mask == CIRCLE5) {
         if (a.nt_stores)
             hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true, K == 5 ? CIRCLE5 : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, false, K == 5 ? CIRCLE5 : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else if (K == 3 && mask == BOX) {
+        if (a.nt_stores)
+            hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true, K == 3 ? BOX : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, false, K == 3 ? BOX : 0u>), dim3((unsigned)grid), dim3(256), 0, s, a);
     } else if (a.nt_stores)
         hipLaunchKernelGGL((raster_pass_kernel<OPS, K, K, RB, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else

@@ -408,8 +408,12 @@ def test_sharded_array_bookkeeping(monkeypatch):
         assert out.shape == sa.shape and out.dtype == np.float64 and out.comm is comm and not out._halo_ok
     with pytest.raises(ValueError):
         ShardedArray.from_numpy(z[:3], Recorder(2, 0), halo_cap=4)         # cannot serve 4 halo rows from 3
+    for rank, span in ((0, (0, 14)), (1, (14, 27)), (2, (27, 40))):        # 40 rows over 3 ranks: 14 + 13 + 13
+        part = ShardedArray.from_global(z, Recorder(3, rank), halo_cap=4)
+        np.testing.assert_array_equal(part.get(), z[span[0]:span[1]])
     solo = ShardedArray.from_numpy(z)
     assert (solo.world, solo.rank) == (1, 0) and solo.halos(3) == (0, 0)
+    np.testing.assert_array_equal(ShardedArray.from_global(z).get(), z)
     np.testing.assert_array_equal(solo.get(), z)
     np.testing.assert_array_equal(ShardedArray.from_numpy(z.astype(np.int64)).get(), z.astype(np.float32))
     agg = DataArray(solo, dims=['y', 'x'])

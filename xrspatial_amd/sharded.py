@@ -124,6 +124,16 @@ class ShardedArray:
         return out
 
     @classmethod
+    def from_global(cls, full_raster, comm=None, halo_cap=16, dtype=None):
+        """This rank's block of rows (`distributed.shard_rows`) of a raster every rank can see (a memory-mapped file, a
+        regenerable array): the sharded counterpart of `dask.array.from_array(full, chunks=(rows_per_rank, -1))`."""
+        from .distributed import shard_rows
+        world = int(comm.world) if comm is not None else 1
+        rank = int(comm.rank) if comm is not None else 0
+        y0, y1 = shard_rows(full_raster.shape[0], world, rank)
+        return cls.from_numpy(full_raster[y0:y1], comm, halo_cap, dtype)
+
+    @classmethod
     def from_device(cls, local_rows: DeviceArray, comm=None, halo_cap=16, stream=None):
         if len(local_rows.shape) != 2:
             raise ValueError("expected this rank's rows as a 2D array")

@@ -27,3 +27,11 @@ def golden():
 def golden_tables():
     with open(os.path.join(GOLDEN_DIR, "reference_tables.json")) as fh:
         return json.load(fh)["tables"]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _parity_report():
+    """XRS_PARITY_REPORT=<path>: write the per-op / per-config error table the GPU tests recorded (tests/parity_log.py)."""
+    yield
+    from tests import parity_log
+    parity_log.flush()

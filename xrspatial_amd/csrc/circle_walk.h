@@ -434,19 +434,13 @@ struct WalkOuts {
     float *sum, *max, *min, *range, *mean, *var, *std;      // any may be NULL
 };
 
-// One kernel body for every combination: F32 = run the float32 statistics, F64 = run the moments.
+// One walker body for every combination: F32 = run the float32 statistics, F64 = run the moments.  The wave walks
+// output rows [y0, y_end) of the 64 columns starting at xw (wave-uniform); kxk_wide.hip calls it for the tiles its
+// float32 fast path hands back (non-finite cells under a window, ill-conditioned sums).
 template <int R, typename Shape, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
-__device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
+__device__ __forceinline__ void walk_columns(const WalkGeom &g, const WalkOuts &o, long xw, int lane, long y0, long y_end) {
     constexpr int K = 2 * R + 1;
-    const long t = xcd_tile(blockIdx.x, g.n_tiles);
-    if (t < 0) return;
-    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long xw = tx * 256 + wv * 64;                 // first column of this wave (scalar)
     const long x = xw + lane;
-    const long y0 = ty * CTH;
-    const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);        // output rows [y0, y_end)
     if (xw >= g.cols) return;
 
     WalkF32<R, Shape, WANT_SUM, WANT_MM> a32;
@@ -471,6 +465,19 @@ __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) 
     };
     if (xw >= R && xw + 64 + R <= g.cols) walk(std::false_type{});     // interior wave: no column predicates
     else walk(std::true_type{});
+}
+
+template <int R, typename Shape, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
+__device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
+    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    if (t < 0) return;
+    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long xw = tx * 256 + wv * 64;                 // first column of this wave (scalar)
+    const long y0 = ty * CTH;
+    const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);        // output rows [y0, y_end)
+    walk_columns<R, Shape, F32, WANT_SUM, WANT_MM, F64, WANT_VAR>(g, o, xw, lane, y0, y_end);
 }
 
 inline int walk_grid(WalkGeom &g, long *grid) {

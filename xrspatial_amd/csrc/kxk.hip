@@ -1104,6 +1104,45 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     }
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = as_stream(stream);
+    // Large circles / boxes (the walkers of wide_impl.h / walk2_impl.h).  XRS_FOCAL_GEN=1 keeps the first-generation
+    // column walkers (A/B runs); XRS_FOCAL_SUM=sequential keeps `sum` on the kernel that adds the taps in the
+    // reference's order in float32 (bit-exact with numba's nansum) instead of rounding the exact sum once.
+    const char *gen = getenv("XRS_FOCAL_GEN");
+    const bool gen1 = gen && gen[0] == '1';
+    const char *sum_env = getenv("XRS_FOCAL_SUM");
+    const bool seq_sum = sum_env && sum_env[0] == 's';
+    const unsigned m_mean = 1u << XRS_STAT_MEAN, m_sum = 1u << XRS_STAT_SUM;
+    if (!gen1 && krows == kcols && krows >= 7 && !(stat_mask & ~(m_mean | m_sum)) && !((stat_mask & m_sum) && seq_sum)) {
+        // mean and / or sum only: one 16-byte load per lane and row, float32 prefix sums (wide_impl.h)
+        int rc = try_launch_focal_wide_circle(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
+                                              kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc < 0)
+            rc = try_launch_focal_wide_box(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
+                                           kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc >= 0) return rc;
+    }
+    if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
+        // several statistics: all of them from one pass of the second-generation column walker (walk2_impl.h); a
+        // sequential `sum` comes from its own kernel
+        float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
+        int rc = try_launch_focal_circle2(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE],
+                                          a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in,
+                                          ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc < 0)
+            rc = try_launch_focal_box2(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE],
+                                       a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in,
+                                       ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            if (!(seq_sum && a.out[XRS_STAT_SUM])) return 0;
+            float *only_sum[XRS_NUM_STATS] = {nullptr};
+            only_sum[XRS_STAT_SUM] = a.out[XRS_STAT_SUM];
+            const int rc2 = try_walk_f32(in_dev, only_sum, false, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                                         halo_bot, s);
+            if (rc2 >= 0) return rc2;
+            return fail("xrs_focal_stats_f32: no sequential-sum kernel for this mask");
+        }
+    }
     if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !getenv("XRS_FOCAL_MEAN_RUNS")) {
         // circles and boxes, 7x7 .. 25x25: column walker (running float64 sums over centred runs)
         const int rc = try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,

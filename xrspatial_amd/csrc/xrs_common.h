@@ -180,4 +180,20 @@ int try_launch_focal_circle_f64(const float *in, float *out_mean, float *out_var
                                 long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
                                 int halo_bot, hipStream_t s);
 
+// kxk_wide_circle.hip / kxk_wide_box.hip: focal mean / window sum, radius 3..12 cells, float32 on shifted values with a
+// guarded fall-back to the float64 walker (wide_impl.h).  0 = launched, -1 = not such a mask, > 0 = error.
+int try_launch_focal_wide_circle(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in,
+                                 long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                                 hipStream_t s);
+int try_launch_focal_wide_box(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in,
+                              long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                              hipStream_t s);
+// kxk_circle2.hip / kxk_box2.hip: all seven statistics in one pass, radius 4..12 cells (walk2_impl.h).
+int try_launch_focal_circle2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_focal_box2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+
 }  // namespace xrs

@@ -1,27 +1,33 @@
 """Headline benchmark: Mcells/s for hillshade + focal mean (5x5 circle) on a float32 DEM resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|s64|zonal32k]
 
-One "step" = one pass of the hot path over one raster: `hillshade(dem)` and the 5x5 circular focal
-mean `focal.apply(dem, circle_kernel(1, 1, 2))` (BASELINE.json `metric`: "hillshade+focal.mean on
-16k^2 f32 DEM"; SURVEY.md fact 4 maps "focal.mean(5x5)" onto focal.apply).  Both products of the step
-come from ONE launch of the fused raster pass (`xrs_raster_pass_f32`, csrc/pass.hip: the DEM is read
-once, 4 B in + 2 x 4 B out per cell) -- what `with xrspatial_amd.fuse():` around the two reference
-calls runs; results are bit-identical to the two stand-alone kernels (tests/test_gpu_parity.py).
-`--unfused` times the two stand-alone launches instead (16 B per cell), and the default run reports
-that form too (`config.unfused`, outside the timed region).  Everything goes through the C ABI of
-libxrs_hip.so on this process's HIP stream.  Inputs are staged in HBM before the timed region.
+Default workload (`headline`, BASELINE.json `metric`: "hillshade+focal.mean on 16k^2 f32 DEM"): one "step" = one
+pass of the hot path over one raster: `hillshade(dem)` and the 5x5 circular focal mean
+`focal.apply(dem, circle_kernel(1, 1, 2))`.  Both products of the step come from ONE launch of the fused raster pass
+(`xrs_raster_pass_f32`, csrc/pass.hip: the DEM is read once, 4 B in + 2 x 4 B out per cell) -- what
+`with xrspatial_amd.fuse():` around the two reference calls runs.  `--unfused` times the two stand-alone launches instead
+(16 B per cell), and the default run reports that form too (`config.unfused`, outside the timed region).  Everything goes
+through the C ABI of libxrs_hip.so on this process's HIP stream.  Inputs are staged in HBM before the timed region.
 
-N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
-one process per GPU, weak scaling -- every rank owns a 16384 x 16384 row-shard of a
-(16384*N) x 16384 raster; each step starts with ONE RCCL halo exchange (2 rows each way over xGMI,
-enough for both operators) and then runs the same pass with halo_top/halo_bot set.
-torch.distributed (gloo) is used only for rendezvous, the barriers and the max-over-ranks of the
-elapsed time; no tensor ever touches the GPU through torch.
+N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or anything else that sets
+RANK / WORLD_SIZE / LOCAL_RANK): one process per GPU.
+  * `headline`: weak scaling -- every rank owns a 16384 x 16384 row-shard of a (16384*N) x 16384 raster; each step is ONE
+    RCCL halo exchange (2 rows each way over xGMI, hidden behind the interior rows) + the same pass with halo_top / halo_bot.
+  * `s64` (BASELINE configs[3]): STRONG scaling of hillshade + slope + 5x5 focal mean on a 65536 x 65536 DEM, 65536 / N
+    rows per rank, one halo exchange per step, one fused pass (16 B per cell).
+  * `zonal32k` (BASELINE configs[4]): zonal.stats partial sums over a 32768 x 32768 raster with 1000 int32 zones,
+    32768 / N rows per rank, one `xrs_zonal_allreduce` per step; the reduced counts are checked bit for bit.
+The default N > 1 run also reports the other two workloads (a few untimed-region steps each) as `config.s64_strong` /
+`config.zonal32k_strong`, so a driver that only ever runs the default flags still exercises them.
+No torch: the ranks rendezvous through a file (xrspatial_amd.distributed.Comm.from_env), barriers and the max-over-ranks
+of the elapsed time are RCCL all-reduces.  If the RCCL communicator cannot be created the run FAILS (exit code 3) unless
+`--allow-host-halo` is given (development boxes where several ranks share one GPU: halo rows go through host memory + gloo
+from tests/host_transport.py, and the output says so).
 
-Prints ONE JSON line (rank 0): metric/value in Mcells/s (raster cells through the whole step, all
-ranks), `roofline` for the dominant kernel (HIP-event time on the launch stream, algorithmic
-12 B/cell fused, 8 B/cell for either stand-alone kernel), `cpu_baseline` = the CPU oracle timed on this box on a bounded band of the same raster.
+Prints ONE JSON line (rank 0): metric / value in Mcells/s (raster cells through the whole step, all ranks), `roofline` for
+the dominant kernel (HIP-event time on the launch stream; HBM traffic from profiles/pmc_traffic.json when -- and only when --
+it was collected on the very build that is loaded), `cpu_baseline` = the CPU oracle timed on this box.
 """
 import argparse
 import ctypes
@@ -37,92 +43,221 @@ sys.path.insert(0, ROOT)
 
 ROWS_PER_GPU = 16384
 COLS = 16384
-HALO = 2                      # 5x5 focal window; hillshade needs 1 of them
+HALO = 2                      # 5x5 focal window; hillshade / slope need 1 of them
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 ALG_BYTES_FUSED = 12          # fused pass: 4 B read + 4 B hillshade + 4 B focal mean written per cell
 ALG_BYTES_PER_CELL = 8        # stand-alone kernels: 4 B read + 4 B written per cell
+ALG_BYTES_S64_FUSED = 16      # hillshade + slope + focal mean from one read
+ALG_BYTES_ZONAL = 8           # zones int32 + values float32, read only
+# full symbols of the kernels the default configuration launches (as rocprofv3 prints them; keys of profiles/pmc_traffic.json)
+SYM_FUSED = "raster_pass_kernel<8, 5, 5, 4, true, 4685252u>"
+SYM_FOCAL5 = "focal_mean_direct_kernel<5, 5, 4, 0u>"
+SYM_HILL = "terrain_strip_kernel<8, float, 4>"
+SYM_S64 = "raster_pass_kernel<9, 5, 5, 4, true, 4685252u>"
+SYM_ZONAL = "zonal_kernel"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)     # the clocks settle over the first ~15 launches (profiles/r01)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE config)")
-    ap.add_argument("--cols", type=int, default=COLS)
-    ap.add_argument("--unfused", action="store_true",
-                    help="time hillshade and the focal mean as two stand-alone launches instead of the fused pass")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: run the halo exchange and the pass back to back on one stream instead of hiding the "
-                         "exchange behind the interior rows")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="experiment: do not record HIP events inside the timed region")
-    ap.add_argument("--per-step-events", action="store_true",
-                    help="fused mode: bracket every launch with its own pair of HIP events (default: ONE pair around the "
-                         "K timed launches; --unfused always uses per-kernel events)")
-    args = ap.parse_args()
+class Ctx:
+    """Per-process state shared by the workloads: rank / world, the C ABI caller, a stream, the communicator."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    os.environ.setdefault("XRS_DEVICE", str(local_rank))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # single node: RCCL bootstrap over loopback
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus N with N > 1 must be launched with one process per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N)")
+            args.gpus = self.world
+        os.environ.setdefault("XRS_DEVICE", str(self.local_rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if self.world > 1:
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # single node: RCCL bootstrap over loopback
+        if not os.path.exists(os.path.join(ROOT, "xrspatial_amd", "libxrs_hip.so")):
+            import __graft_entry__
+            __graft_entry__.build()
+        import xrspatial_amd as xs
+        from xrspatial_amd import _lib
+        _lib.require_device()
+        self.xs, self._lib, self.L = xs, _lib, _lib.call
+        self.stream = ctypes.c_void_p()
+        self.L("xrs_stream_create", ctypes.byref(self.stream))
+        self.comm = None
+        self.host_group = None        # torch.distributed (gloo), only with --allow-host-halo after RCCL failed
+        self.halo_via = None
+        if self.world > 1:
+            self._connect()
+        self._ms = ctypes.c_float()
 
-    # Load the HIP library (and with it /opt/rocm's runtime) BEFORE torch is imported.
-    if not os.path.exists(os.path.join(ROOT, "xrspatial_amd", "libxrs_hip.so")):
-        import __graft_entry__
-        __graft_entry__.build()
-    import xrspatial_amd as xs
-    from tests import synth
-    from xrspatial_amd import _lib
-    from xrspatial_amd.convolution import circle_kernel
-    _lib.require_device()
-    L = _lib.call
-
-    dist = None
-    comm = None
-    halo_via = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    def _connect(self):
         from xrspatial_amd.distributed import Comm
-        rccl_error = ""
+        err = ""
         try:
-            comm = Comm.from_torch_distributed(dist)
-        except Exception as exc:                      # noqa: BLE001 -- keep the benchmark alive, say so in the output
-            rccl_error = repr(exc)[:200]
-        ok = torch.tensor([0 if comm is None else 1])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # every rank must take the same path
-        if int(ok.item()) == 1:
-            halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
-        else:
-            if comm is not None:
-                comm.destroy()
-                comm = None
-            halo_via = f"host-staged over gloo, {HALO} rows per neighbour per step (RCCL unavailable: {rccl_error})"
-            sys.stderr.write(f"[bench rank {rank}] RCCL communicator unavailable, halo rows go through the host: {rccl_error}\n")
+            self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
+            self.halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
+        except Exception as exc:                      # noqa: BLE001
+            err = repr(exc)[:300]
+        if self.comm is None:
+            sys.stderr.write(f"[bench rank {self.rank}] RCCL communicator unavailable: {err}\n")
+            if not self.args.allow_host_halo:
+                sys.stderr.write("[bench] refusing to run a multi-GPU benchmark without RCCL (pass --allow-host-halo to stage "
+                                 "halo rows through the host on development boxes)\n")
+                sys.exit(3)
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.host_group = dist
+            self.halo_via = f"host-staged over gloo, {HALO} rows per neighbour per step (RCCL unavailable: {err})"
 
+    # ---- small collectives -----------------------------------------------------------------
+    def barrier(self):
+        if self.comm is not None:
+            self.comm.barrier(self.stream)
+        elif self.host_group is not None:
+            self.host_group.barrier()
+
+    def allmax(self, value):
+        if self.comm is not None:
+            return float(self.comm.allreduce(np.array([value], np.float64), 'max', self.stream)[0])
+        if self.host_group is not None:
+            import torch
+            t = torch.tensor([value], dtype=torch.float64)
+            self.host_group.all_reduce(t, op=self.host_group.ReduceOp.MAX)
+            return float(t.item())
+        return float(value)
+
+    def allsum(self, value):
+        if self.comm is not None:
+            return float(self.comm.allreduce(np.array([value], np.float64), 'sum', self.stream)[0])
+        if self.host_group is not None:
+            import torch
+            t = torch.tensor([value], dtype=torch.float64)
+            self.host_group.all_reduce(t, op=self.host_group.ReduceOp.SUM)
+            return float(t.item())
+        return float(value)
+
+    def halo_exchange(self, dem_ptr, rows, cols, halo, stream=None):
+        """One exchange of `halo` rows with each neighbour: RCCL (xrs_halo_exchange_f32), or -- --allow-host-halo only --
+        the same rows staged through host memory + gloo (tests/host_transport.py)."""
+        stream = self.stream if stream is None else stream
+        if self.comm is not None:
+            self.L("xrs_halo_exchange_f32", self.comm.handle, dem_ptr, rows, cols, cols, halo, stream)
+            return
+        if self.host_group is None:
+            return
+        from tests.host_transport import halo_exchange_host
+        L, rank, world = self.L, self.rank, self.world
+        # mini-shard: [top halo | first `halo` owned rows | last `halo` owned rows | bottom halo]
+        small = np.empty((4 * halo, cols), np.float32)
+        L("xrs_memcpy_d2h", small[halo:2 * halo].ctypes.data, dem_ptr, halo * cols * 4, stream)
+        L("xrs_memcpy_d2h", small[2 * halo:3 * halo].ctypes.data, dem_ptr + (rows - halo) * cols * 4, halo * cols * 4, stream)
+        L("xrs_stream_sync", stream)
+        halo_exchange_host(self.host_group, small, halo)
+        if rank > 0:
+            L("xrs_memcpy_h2d", dem_ptr - halo * cols * 4, small[0:halo].ctypes.data, halo * cols * 4, stream)
+        if rank < world - 1:
+            L("xrs_memcpy_h2d", dem_ptr + rows * cols * 4, small[3 * halo:4 * halo].ctypes.data, halo * cols * 4, stream)
+        L("xrs_stream_sync", stream)
+
+    def zonal_allreduce(self, zc, zs, zq, zmn, zmx, nz):
+        """Per-zone partials of every rank -> global partials on every rank (device arrays, in place)."""
+        if self.comm is not None:
+            self.L("xrs_zonal_allreduce", self.comm.handle, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, 0, nz, self.stream)
+            return
+        if self.host_group is None:
+            return
+        from tests.host_transport import zonal_allreduce_host
+        parts = zonal_allreduce_host(self.host_group, *[a.get(self.stream) for a in (zc, zs, zq, zmn, zmx)])
+        for dev, host in zip((zc, zs, zq, zmn, zmx), parts):
+            host = np.ascontiguousarray(host, dtype=dev.dtype)
+            self.L("xrs_memcpy_h2d", dev.ptr, host.ctypes.data, host.nbytes, self.stream)
+            self.L("xrs_stream_sync", self.stream)
+
+    def fence(self):
+        self.L("xrs_stream_sync", self.stream)
+        self.L("xrs_device_sync")
+        self.barrier()
+
+    # ---- events ----------------------------------------------------------------------------
+    def event(self):
+        e = ctypes.c_void_p()
+        self.L("xrs_event_create", ctypes.byref(e))
+        return e
+
+    def elapsed_ms(self, e0, e1):
+        self.L("xrs_event_elapsed_ms", e0, e1, ctypes.byref(self._ms))
+        return float(self._ms.value)
+
+    def timed(self, fn, reps=5):
+        """Average device time of `fn` over `reps` back-to-back launches on the bench stream (one event pair)."""
+        fn()
+        e0, e1 = self.event(), self.event()
+        self.L("xrs_stream_sync", self.stream)
+        self.L("xrs_event_record", e0, self.stream)
+        for _ in range(reps):
+            fn()
+        self.L("xrs_event_record", e1, self.stream)
+        self.L("xrs_event_sync", e1)
+        return self.elapsed_ms(e0, e1) / reps
+
+    def preheat(self, src_ptr, dst_ptr, cells, n=40):
+        # Leave the idle clocks before the contract's W warm-up steps: the MI355X ramps its clocks over the first few dozen
+        # launches after idling through input staging (profiles/r01: ~0.71 ms/step over launches 5..25 against 0.635 once
+        # settled).  Untimed, outside the W + K steps, a plain streaming copy -- reported as config.preheat.
+        for _ in range(n):
+            self.L("xrs_copy_f32", src_ptr, dst_ptr, cells, self.stream)
+        return f"{n} untimed xrs_copy_f32 launches before the warm-up steps (clock ramp after input staging)"
+
+    def copy_bandwidth(self, src_ptr, dst_ptr, cells):
+        """Streaming-copy bandwidth of this GPU in the library's own access pattern (4 B read + 4 B written per cell)."""
+        ms = self.timed(lambda: self.L("xrs_copy_f32", src_ptr, dst_ptr, cells, self.stream), reps=10)
+        return 8.0 * cells / (ms * 1e-3) / 1e9
+
+    def replicate_rows(self, dev_ptr, band_rows, total_rows, row_bytes):
+        """Fill rows [band_rows, total_rows) of a device plane with copies of its first `band_rows` rows."""
+        y = band_rows
+        while y < total_rows:
+            n = min(band_rows, total_rows - y)
+            self.L("xrs_memcpy_d2d", dev_ptr + y * row_bytes, dev_ptr, n * row_bytes, self.stream)
+            y += n
+        self.L("xrs_stream_sync", self.stream)
+
+
+def traffic_for(ctx, symbol, rows, cols, default_shape):
+    """HBM bytes per launch of `symbol` from the PMC table -- only if it was collected on the build that is loaded and on
+    this raster shape; otherwise None (with the reason)."""
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if (rows, cols) != default_shape:
+        return None, "not the profiled raster shape"
+    try:
+        table = json.load(open(tfile))
+    except Exception:                                 # noqa: BLE001
+        return None, "profiles/pmc_traffic.json missing"
+    have = ctx._lib.build_id()
+    if table.get("_build_id") != have:
+        return None, f"profiles/pmc_traffic.json was collected on build {table.get('_build_id')}, loaded library is {have}"
+    ent = table.get("kernels", {}).get(symbol)
+    if not ent:
+        return None, f"no PMC entry for {symbol}"
+    return int(ent["hbm_bytes"]), f"rocprofv3 --pmc on build {have} ({table.get('_source')})"
+
+
+# =====================================================================================================
+def run_headline(ctx):
+    args, L, xs, stream = ctx.args, ctx.L, ctx.xs, ctx.stream
+    from tests import synth
+    from xrspatial_amd.convolution import circle_kernel
+    rank, world = ctx.rank, ctx.world
     rows, cols = args.rows, args.cols
     total_rows = rows * world
     y_begin = rank * rows
     ht = HALO if rank > 0 else 0
     hb = HALO if rank < world - 1 else 0
 
-    stream = ctypes.c_void_p()
-    L("xrs_stream_create", ctypes.byref(stream))
-
     # shard buffer = HALO spare rows + owned rows + HALO spare rows; the owned part starts at `dem`
     buf = xs.DeviceArray((rows + 2 * HALO, cols), np.float32)
     dem_ptr = buf.ptr + HALO * cols * 4
-    band = 2048
+    band = min(2048, rows)
     for y0 in range(0, rows, band):
         n = min(band, rows - y0)
         host = synth.asv_dem(n, cols, y0=y_begin + y0, total_rows=total_rows)
@@ -135,33 +270,11 @@ def main():
     outs = (ctypes.c_void_p * 7)()
     outs[0] = out_focal.ptr
 
-    def make_event():
-        e = ctypes.c_void_p()
-        L("xrs_event_create", ctypes.byref(e))
-        return e
-
-    def halo_exchange_through_host():
-        """Fallback only: the same neighbour exchange as xrs_halo_exchange_f32, staged through host buffers + gloo."""
-        from xrspatial_amd.distributed import halo_exchange_host
-        # mini-shard: [top halo | first HALO owned rows | last HALO owned rows | bottom halo]
-        small = np.empty((4 * HALO, cols), np.float32)
-        L("xrs_memcpy_d2h", small[HALO:2 * HALO].ctypes.data, dem_ptr, HALO * cols * 4, stream)
-        L("xrs_memcpy_d2h", small[2 * HALO:3 * HALO].ctypes.data, dem_ptr + (rows - HALO) * cols * 4, HALO * cols * 4, stream)
-        L("xrs_stream_sync", stream)
-        halo_exchange_host(dist, small, HALO)                     # a (2*HALO owned rows + 2*HALO halo rows) mini-shard
-        if ht:
-            L("xrs_memcpy_h2d", dem_ptr - HALO * cols * 4, small[0:HALO].ctypes.data, HALO * cols * 4, stream)
-        if hb:
-            L("xrs_memcpy_h2d", dem_ptr + rows * cols * 4, small[3 * HALO:4 * HALO].ctypes.data, HALO * cols * 4, stream)
-        L("xrs_stream_sync", stream)
-
     def launch_hillshade():
-        L("xrs_hillshade_f32", dem_ptr, out_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0,
-          min(ht, 1), min(hb, 1), stream)
+        L("xrs_hillshade_f32", dem_ptr, out_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0, min(ht, 1), min(hb, 1), stream)
 
     def launch_focal():
-        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc, None,
-          ht, hb, stream)
+        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc, None, ht, hb, stream)
 
     def launch_fused():
         L("xrs_raster_pass_f32", dem_ptr, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data, kr, kc,
@@ -172,6 +285,8 @@ def main():
         L("xrs_raster_pass_f32", dem_ptr + off, None, None, None, out_hill.ptr + off, out_focal.ptr + off,
           kernel.ctypes.data, kr, kc, None, n, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, stream)
 
+    comm = ctx.comm
+    halo_via = ctx.halo_via
     # N > 1 with RCCL: only the 16 rows at either end of a shard wait for the neighbours' rows; the interior
     # rows of the pass run while the exchange is in flight (xrspatial_amd.distributed.OverlappedHalo)
     overlap = None
@@ -190,10 +305,8 @@ def main():
                 L("xrs_event_record", events[1], stream)
                 L("xrs_event_record", events[2], stream)
             return
-        if comm is not None:
-            L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, stream)
-        elif world > 1:
-            halo_exchange_through_host()
+        if world > 1:
+            ctx.halo_exchange(dem_ptr, rows, cols, HALO)
         if events:
             L("xrs_event_record", events[0], stream)
         if args.unfused:
@@ -208,27 +321,16 @@ def main():
         if events:
             L("xrs_event_record", events[2], stream)
 
-    def fence():
-        L("xrs_stream_sync", stream)
-        L("xrs_device_sync")
-        if dist is not None:
-            dist.barrier()
-
-    # Leave the idle clocks before the contract's W warm-up steps: the MI355X ramps its clocks over the first few
-    # dozen launches after idling through input staging (profiles/r01: ~0.71 ms/step over launches 5..25 against
-    # 0.635 once settled).  Untimed, outside the W + K steps, a plain streaming copy -- reported as config.preheat.
-    PREHEAT = 40
-    for _ in range(PREHEAT):
-        L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
+    preheat = ctx.preheat(dem_ptr, out_hill.ptr, rows * cols)
     for _ in range(args.warmup):
         step()
     # Kernel time, measured live on the launch stream inside the timed region.  Fused step (one launch): ONE pair of
     # HIP events around the K launches -- average launch interval, inter-launch gaps included (three event records per
     # step cost ~1.5 % of the step; profiles/r01).  Two launches per step (--unfused): an event between the kernels.
     per_step = (args.unfused or args.per_step_events) and not args.no_kernel_events
-    events = [[make_event() for _ in range(3)] for _ in range(args.steps)] if per_step else []
-    bracket = (make_event(), make_event())
-    fence()
+    events = [[ctx.event() for _ in range(3)] for _ in range(args.steps)] if per_step else []
+    bracket = (ctx.event(), ctx.event())
+    ctx.fence()
     t0 = time.perf_counter()
     if not args.no_kernel_events:
         L("xrs_event_record", bracket[0], stream)
@@ -238,30 +340,18 @@ def main():
         L("xrs_event_record", bracket[1], stream)
     L("xrs_stream_sync", stream)
     L("xrs_device_sync")
-    if dist is not None:
-        dist.barrier()
+    ctx.barrier()
     elapsed = time.perf_counter() - t0
-
     exchange_ms = overlap.last_exchange_ms() if overlap is not None else None
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctx.allmax(elapsed)
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
-    ms = ctypes.c_float()
-    hill_ms, focal_ms = [], []
-    for e in events:
-        L("xrs_event_elapsed_ms", e[0], e[1], ctypes.byref(ms))
-        hill_ms.append(ms.value)
-        L("xrs_event_elapsed_ms", e[1], e[2], ctypes.byref(ms))
-        focal_ms.append(ms.value)
+    hill_ms = [ctx.elapsed_ms(e[0], e[1]) for e in events]
+    focal_ms = [ctx.elapsed_ms(e[1], e[2]) for e in events]
     hill_avg, focal_avg = (float(np.mean(hill_ms)), float(np.mean(focal_ms))) if hill_ms else (float("nan"), float("nan"))
     # (fused, per-step events: events[0] -> events[1] brackets the single launch; [1] -> [2] is empty)
     if not per_step and not args.no_kernel_events:
-        L("xrs_event_elapsed_ms", bracket[0], bracket[1], ctypes.byref(ms))
-        hill_avg, focal_avg = ms.value / args.steps, 0.0
+        hill_avg, focal_avg = ctx.elapsed_ms(*bracket) / args.steps, 0.0
 
     # Correctness of the sharded run, outside the timed region: the rows either side of every shard boundary (the ones
     # that depend on exchanged halo rows) must equal what the SAME kernel produces for them when it sees the rows of
@@ -286,41 +376,17 @@ def main():
                 got = dev_out.rows(lo, lo + 4).get(stream)
                 want = blk.get(stream)[sl]
                 mismatched += int(np.count_nonzero(~((got == want) | (np.isnan(got) & np.isnan(want)))))
-        tw = torch.tensor([mismatched], dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.SUM)
-        halo_check = {"cells_differing_from_the_unsharded_pass_at_shard_boundaries": int(tw.item()), "ok": bool(tw.item() == 0)}
+        total_bad = ctx.allsum(mismatched)
+        halo_check = {"cells_differing_from_the_unsharded_pass_at_shard_boundaries": int(total_bad), "ok": bool(total_bad == 0)}
 
-    # Calibration, outside the timed region: the streaming-copy bandwidth this GPU sustains in the library's own
-    # access pattern (xrs_copy_f32, 4 B read + 4 B written per cell like the bench kernels).
-    copy_gbs = None
-    if rank == 0:
-        for _ in range(2):
-            L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
-        c0, c1 = make_event(), make_event()
-        L("xrs_event_record", c0, stream)
-        for _ in range(10):
-            L("xrs_copy_f32", dem_ptr, out_hill.ptr, rows * cols, stream)
-        L("xrs_event_record", c1, stream)
-        L("xrs_event_sync", c1)
-        L("xrs_event_elapsed_ms", c0, c1, ctypes.byref(ms))
-        copy_gbs = 8.0 * rows * cols / (ms.value / 10 * 1e-3) / 1e9
+    copy_gbs = ctx.copy_bandwidth(dem_ptr, out_hill.ptr, rows * cols) if rank == 0 else None
 
     # Informational, OUTSIDE the timed region (rank 0, N=1): the other kernels of BASELINE configs[1]/[2] on the
-    # same resident raster, and one numpy-in/numpy-out call to quote the PCIe-inclusive rate of the drop-in path.
+    # same resident raster, the 65536^2 and 32768^2 configurations on this one GPU, and one numpy-in/numpy-out call to
+    # quote the PCIe-inclusive rate of the drop-in path.
     extra = {}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        def timed(fn, reps=5):
-            fn()
-            e0, e1 = make_event(), make_event()
-            L("xrs_stream_sync", stream)
-            L("xrs_event_record", e0, stream)
-            for _ in range(reps):
-                fn()
-            L("xrs_event_record", e1, stream)
-            L("xrs_event_sync", e1)
-            L("xrs_event_elapsed_ms", e0, e1, ctypes.byref(ms))
-            return ms.value / reps
-
+    if world == 1 and not args.no_extras:
+        timed = ctx.timed
         if not args.unfused:
             # the same step as two stand-alone launches (what two eager reference-style calls run)
             u_h, u_f = timed(launch_hillshade, reps=10), timed(launch_focal, reps=10)
@@ -328,13 +394,23 @@ def main():
                                 "ms_per_step": round(u_h + u_f, 4),
                                 "mcells_s": round(rows * cols / ((u_h + u_f) * 1e-3) / 1e6, 1)}
         k25 = np.ascontiguousarray(circle_kernel(1, 1, 12), dtype=np.float64)
+        outs7 = [xs.DeviceArray((rows, cols), np.float32) for _ in range(5)]
+        ptr7 = (ctypes.c_void_p * 7)(out_focal.ptr, out_hill.ptr, *[o.ptr for o in outs7])
         extra["other_kernels_ms"] = {
             "slope": round(timed(lambda: L("xrs_slope_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0, 0, 0, stream)), 4),
             "aspect": round(timed(lambda: L("xrs_aspect_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 0, 0, stream)), 4),
             "curvature": round(timed(lambda: L("xrs_curvature_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 0, 0, stream)), 4),
             "focal_mean_25x25_circle": round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols,
-                                                             k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=2), 4),
+                                                             k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=3), 4),
+            "focal_stats7_25x25_circle": round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, ptr7, 127, rows, cols, cols, cols,
+                                                               k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=2), 4),
+            "focal_stats7_5x5_circle": round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, ptr7, 127, rows, cols, cols, cols,
+                                                             kernel.ctypes.data, 5, 5, None, 0, 0, stream), reps=3), 4),
         }
+        ok = extra["other_kernels_ms"]
+        ok["focal_mean_25x25_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["focal_mean_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)
+        ok["focal_stats7_25x25_frac_of_measured_copy"] = round(32.0 * rows * cols / (ok["focal_stats7_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)
+        del outs7, ptr7
         host_rows = min(rows, 4096)
         host_dem = synth.asv_dem(host_rows, cols, y0=0, total_rows=total_rows)
         agg = xs.DataArray(host_dem, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
@@ -343,33 +419,34 @@ def main():
         xs.hillshade(agg)
         t_h = time.perf_counter() - t_h
         extra["numpy_in_numpy_out_hillshade_mcells_s"] = round(host_rows * cols / t_h / 1e6, 1)
+    if world > 1 and not args.no_extras:
+        del out_focal, out_hill, buf
+        xs.device.empty_cache()
+        extra["s64_strong"] = run_s64(ctx, steps=5, warmup=2, brief=True)
+        xs.device.empty_cache()
+        extra["zonal32k_strong"] = run_zonal32k(ctx, steps=5, warmup=2, brief=True)
+    elif world == 1 and not args.no_extras:
+        del out_focal, out_hill, buf
+        xs.device.empty_cache()
+        extra["s64"] = run_s64(ctx, steps=5, warmup=2, brief=True)
+        xs.device.empty_cache()
+        extra["zonal32k"] = run_zonal32k(ctx, steps=10, warmup=2, brief=True)
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
+        return None
     cells_rank = rows * cols
     ms_per_step = elapsed / args.steps * 1e3
     value = cells_rank * world / (elapsed / args.steps) / 1e6
     if args.unfused:
-        dom_name, dom_ms = ("focal_mean_direct_kernel<5,5,4>", focal_avg) if focal_avg >= hill_avg else \
-            ("terrain_strip_kernel<hillshade,float,4>", hill_avg)
+        dom_name, dom_ms = (SYM_FOCAL5, focal_avg) if focal_avg >= hill_avg else (SYM_HILL, hill_avg)
         alg_bytes = ALG_BYTES_PER_CELL
         kernel_ms = {"hillshade": round(hill_avg, 4), "focal_mean_5x5": round(focal_avg, 4)}
     else:
-        dom_name, dom_ms = "raster_pass_kernel<hillshade,5,5,4>", hill_avg
+        dom_name, dom_ms = SYM_FUSED, hill_avg
         alg_bytes = ALG_BYTES_FUSED
         kernel_ms = {"raster_pass(hillshade + focal_mean_5x5)": round(hill_avg, 4)}
     achieved = alg_bytes * cells_rank / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile) and (rows, cols) == (ROWS_PER_GPU, COLS):   # (measured on the default raster) HBM bytes/launch from a separate rocprofv3 --pmc run (see profiles/README.md)
-        try:
-            traffic = json.load(open(tfile)).get(dom_name.split("<")[0])
-        except Exception:
-            traffic = None
+    traffic, traffic_from = traffic_for(ctx, dom_name, rows, cols, (ROWS_PER_GPU, COLS))
     result = {
         "metric": "Mcells/s for hillshade+focal.mean(5x5) on 16k^2 f32 DEM",
         "value": round(value, 1),
@@ -389,13 +466,14 @@ def main():
                         + ("two stand-alone launches per step" if args.unfused else
                            "both products from one fused pass per step (xrs_raster_pass_f32)"),
             "fused": not args.unfused,
-            "preheat": f"{PREHEAT} untimed xrs_copy_f32 launches before the warm-up steps (clock ramp after input staging)",
+            "preheat": preheat,
             "rows_per_gpu": rows, "cols": cols, "global_rows": total_rows,
             "sharding": "rows" if world > 1 else "none",
             "halo_exchange": halo_via,
             "halo_check": halo_check,
             "halo_exchange_ms_last_step": None if exchange_ms is None else round(exchange_ms, 4),
             "kernel_ms": kernel_ms,
+            "build_id": ctx._lib.build_id(),
             **extra,
         },
         "roofline": {
@@ -406,6 +484,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_from": traffic_from,
             "algorithmic_bytes_per_launch": alg_bytes * cells_rank,
             "launch_ms": round(dom_ms, 4),
             "launch_ms_from": ("HIP events around every launch" if (args.unfused or args.per_step_events) else
@@ -417,15 +496,217 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cols, kernel)
-    print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
+# =====================================================================================================
+def run_s64(ctx, steps=None, warmup=None, brief=False):
+    """BASELINE configs[3]: hillshade + slope + 5x5 focal mean on a 65536 x 65536 float32 DEM, rows dealt to the ranks in
+    contiguous blocks (STRONG scaling); one halo exchange + one fused pass per step."""
+    args, L, xs, stream = ctx.args, ctx.L, ctx.xs, ctx.stream
+    from tests import synth
+    from xrspatial_amd.convolution import circle_kernel
+    from xrspatial_amd.distributed import shard_rows
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    rank, world = ctx.rank, ctx.world
+    total_rows = cols = args.s64_size
+    y0, y1 = shard_rows(total_rows, world, rank)
+    rows = y1 - y0
+    ht, hb = (HALO if rank > 0 else 0), (HALO if rank < world - 1 else 0)
+    band_rows = 2048
+    band = synth.asv_dem(band_rows, cols)               # content(y, x) = band[y % 2048, x]: any row can be regenerated
+    buf = xs.DeviceArray((rows + 2 * HALO, cols), np.float32)
+    dem_ptr = buf.ptr + HALO * cols * 4
+    # first rows up to the next multiple of the period from the host, the rest replicated on the device
+    phase = y0 % band_rows
+    first = np.concatenate([band[phase:], band[:phase]]) if phase else band
+    n0 = min(rows, band_rows)
+    L("xrs_memcpy_h2d", dem_ptr, first.ctypes.data, n0 * cols * 4, stream)
+    L("xrs_stream_sync", stream)
+    ctx.replicate_rows(dem_ptr, n0, rows, cols * 4)
+    o_hill, o_slope, o_focal = (xs.DeviceArray((rows, cols), np.float32) for _ in range(3))
+    kernel = np.ascontiguousarray(circle_kernel(1, 1, 2), dtype=np.float64)
+    outs = (ctypes.c_void_p * 7)()
+    outs[0] = o_focal.ptr
+    comm = ctx.comm
+
+    def exchange():
+        if world > 1:
+            ctx.halo_exchange(dem_ptr, rows, cols, HALO)
+
+    def fused():
+        L("xrs_raster_pass_f32", dem_ptr, o_slope.ptr, None, None, o_hill.ptr, o_focal.ptr, kernel.ctypes.data, 5, 5, None,
+          rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, ht, hb, stream)
+
+    def three_calls():
+        L("xrs_hillshade_f32", dem_ptr, o_hill.ptr, 0, rows, cols, cols, cols, 225.0, 25.0, min(ht, 1), min(hb, 1), stream)
+        L("xrs_slope_f32", dem_ptr, o_slope.ptr, rows, cols, cols, cols, 1.0, 1.0, min(ht, 1), min(hb, 1), stream)
+        L("xrs_focal_stats_f32", dem_ptr, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, 5, 5, None, ht, hb, stream)
+
+    run = three_calls if args.unfused else fused
+
+    def step():
+        exchange()
+        run()
+
+    if not brief:
+        ctx.preheat(dem_ptr, o_hill.ptr, min(rows * cols, 1 << 28))
+    for _ in range(warmup):
+        step()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.fence()
+    t0 = time.perf_counter()
+    L("xrs_event_record", e0, stream)
+    for _ in range(steps):
+        step()
+    L("xrs_event_record", e1, stream)
+    L("xrs_stream_sync", stream)
+    L("xrs_device_sync")
+    ctx.barrier()
+    elapsed = ctx.allmax(time.perf_counter() - t0)
+    dev_ms = ctx.elapsed_ms(e0, e1) / steps
+
+    # sharded correctness: the rows next to every shard boundary equal one unsharded pass over the rows of both shards
+    halo_check = None
+    if world > 1:
+        bad = 0
+        for side, has_nb in (("top", rank > 0), ("bottom", rank < world - 1)):
+            if not has_nb:
+                continue
+            yb = y0 if side == "top" else y1
+            idx = (np.arange(yb - 8, yb + 8) % band_rows)
+            block = xs.DeviceArray.from_numpy(np.ascontiguousarray(band[idx]))
+            b_h, b_s, b_f = (xs.DeviceArray((16, cols), np.float32) for _ in range(3))
+            L("xrs_raster_pass_f32", block.ptr, b_s.ptr, None, None, b_h.ptr, b_f.ptr, kernel.ctypes.data, 5, 5, None,
+              16, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, 0, 0, stream)
+            lo = 0 if side == "top" else rows - 4
+            sl = slice(8, 12) if side == "top" else slice(4, 8)
+            for dev_out, blk in ((o_focal, b_f), (o_hill, b_h), (o_slope, b_s)):
+                got, want = dev_out.rows(lo, lo + 4).get(stream), blk.get(stream)[sl]
+                bad += int(np.count_nonzero(~((got == want) | (np.isnan(got) & np.isnan(want)))))
+        total_bad = ctx.allsum(bad)
+        halo_check = {"cells_differing_from_the_unsharded_pass_at_shard_boundaries": int(total_bad), "ok": bool(total_bad == 0)}
+
+    cells_total = float(total_rows) * cols
+    alg = 24 if args.unfused else ALG_BYTES_S64_FUSED
+    out = {
+        "raster": f"{total_rows}x{cols} float32", "rows_this_rank": rows, "n_gpus": world, "steps": steps,
+        "form": "three stand-alone launches (24 B/cell)" if args.unfused else "one fused pass: hillshade + slope + 5x5 mean (16 B/cell)",
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "mcells_s": round(cells_total / (elapsed / steps) / 1e6, 1),
+        "kernel_ms_rank0": round(dev_ms, 4),
+        "algorithmic_gbs_per_gpu": round(alg * rows * cols / (dev_ms * 1e-3) / 1e9, 1),
+        "halo_check": halo_check,
+    }
+    if world == 1:
+        # the north_star bar: >= 70 % of the MEASURED copy bandwidth at 65536^2, fused and as three calls
+        copy_gbs = ctx.copy_bandwidth(dem_ptr, o_hill.ptr, rows * cols)
+        t3 = ctx.timed(three_calls, reps=3)
+        tf = ctx.timed(fused, reps=3)
+        out.update({
+            "measured_copy_gbs": round(copy_gbs, 1),
+            "three_calls_ms": round(t3, 3), "three_calls_mcells_s": round(cells_total / (t3 * 1e-3) / 1e6, 1),
+            "three_calls_frac_of_measured_copy": round(24 * cells_total / (t3 * 1e-3) / 1e9 / copy_gbs, 4),
+            "three_calls_frac_of_8TBs": round(24 * cells_total / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fused_pass_ms": round(tf, 3), "fused_pass_mcells_s": round(cells_total / (tf * 1e-3) / 1e6, 1),
+            "fused_pass_frac_of_measured_copy": round(16 * cells_total / (tf * 1e-3) / 1e9 / copy_gbs, 4),
+            "fused_pass_frac_of_8TBs": round(16 * cells_total / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        })
+    del o_hill, o_slope, o_focal, buf
+    return out
+
+
+# =====================================================================================================
+def run_zonal32k(ctx, steps=None, warmup=None, brief=False):
+    """BASELINE configs[4]: zonal.stats partial sums over a 32768 x 32768 float32 raster with 1000 int32 zones (the
+    reference benchmark's blocky layout), rows dealt to the ranks (STRONG scaling); per step: reset the accumulators,
+    reduce this rank's rows (xrs_zonal_partials_f32), one xrs_zonal_allreduce.  Counts are checked bit for bit against
+    the exact host count."""
+    args, L, xs, stream = ctx.args, ctx.L, ctx.xs, ctx.stream
+    from tests import synth
+    from xrspatial_amd.distributed import shard_rows
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    rank, world = ctx.rank, ctx.world
+    total_rows = cols = args.zonal_size
+    nz, block = 1000, 1024
+    y0, y1 = shard_rows(total_rows, world, rank)
+    rows = y1 - y0
+    band_rows = 2048
+    band = synth.asv_dem(band_rows, cols)
+    band[np.random.default_rng(0).random(band.shape) < 0.001] = np.nan        # values(y, x) = band[y % 2048, x]
+    vals = xs.DeviceArray((rows, cols), np.float32)
+    zones = xs.DeviceArray((rows, cols), np.int32)
+    phase = y0 % band_rows
+    first = np.concatenate([band[phase:], band[:phase]]) if phase else band
+    n0 = min(rows, band_rows)
+    L("xrs_memcpy_h2d", vals.ptr, first.ctypes.data, n0 * cols * 4, stream)
+    L("xrs_stream_sync", stream)
+    ctx.replicate_rows(vals.ptr, n0, rows, cols * 4)
+    for r0 in range(0, rows, band_rows):
+        n = min(band_rows, rows - r0)
+        z = synth.block_zones(n, cols, n_zones=nz, block=block, y0=y0 + r0)
+        L("xrs_memcpy_h2d", zones.ptr + r0 * cols * 4, z.ctypes.data, z.nbytes, stream)
+        L("xrs_stream_sync", stream)
+    zc = xs.DeviceArray((nz,), np.uint64)
+    zs, zq = xs.DeviceArray((nz,), np.float64), xs.DeviceArray((nz,), np.float64)
+    zmn, zmx = xs.DeviceArray((nz,), np.float32), xs.DeviceArray((nz,), np.float32)
+    comm = ctx.comm
+
+    def step():
+        L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, stream)
+        L("xrs_zonal_partials_f32", zones.ptr, vals.ptr, rows * cols, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, stream)
+        if world > 1:
+            ctx.zonal_allreduce(zc, zs, zq, zmn, zmx, nz)
+
+    for _ in range(warmup):
+        step()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.fence()
+    t0 = time.perf_counter()
+    L("xrs_event_record", e0, stream)
+    for _ in range(steps):
+        step()
+    L("xrs_event_record", e1, stream)
+    L("xrs_stream_sync", stream)
+    L("xrs_device_sync")
+    ctx.barrier()
+    elapsed = ctx.allmax(time.perf_counter() - t0)
+    dev_ms = ctx.elapsed_ms(e0, e1) / steps
+    # exact expected counts: zone ids are constant on 1024 x 1024 blocks; finite cells per (band row-block, column block)
+    got = zc.get(stream).astype(np.int64)
+    fin = np.isfinite(band).astype(np.int32)
+    want = np.zeros(nz, np.int64)
+    colblk = np.add.reduceat(fin, np.arange(0, cols, block), axis=1)           # (band_rows, cols/block) finite cells per row
+    for bi in range(total_rows // block):
+        rows_in_band = (np.arange(bi * block, (bi + 1) * block) % band_rows)
+        per_col = colblk[rows_in_band].sum(axis=0)
+        ids = (bi * 32 + np.arange(cols // block)) % nz
+        np.add.at(want, ids, per_col)
+    counts_ok = bool((got == want).all())
+    cells_total = float(total_rows) * cols
+    out = {
+        "raster": f"{total_rows}x{cols} float32 values + int32 zones, {nz} zones in {block}x{block} blocks", "rows_this_rank": rows,
+        "n_gpus": world, "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "mcells_s": round(cells_total / (elapsed / steps) / 1e6, 1),
+        "kernel_plus_reduce_ms_rank0": round(dev_ms, 4),
+        "algorithmic_gbs_per_gpu": round(ALG_BYTES_ZONAL * rows * cols / (dev_ms * 1e-3) / 1e9, 1),
+        "reduction": ("xrs_zonal_allreduce (3 sum + min + max all-reduces of 1000 entries, grouped)" if comm is not None else
+                      ("host-staged over gloo (--allow-host-halo)" if world > 1 else "none (one GPU)")),
+        "counts_bit_exact_vs_host": counts_ok, "total_count": int(got.sum()),
+    }
+    if not counts_ok:
+        out["count_mismatches"] = int(np.count_nonzero(got != want))
+    del vals, zones
+    return out
+
+
+# =====================================================================================================
 def cpu_baseline(cols, kernel):
-    """The CPU oracle (a port of the reference's CPU path) timed on this box, 1 core -- the reference's
-    Numba kernels are single-threaded (xrspatial/utils.py:31) -- on a bounded band of the same DEM."""
+    """The CPU oracle (a port of the reference's CPU path) timed on this box on the same DEM: ONE core -- the reference's
+    Numba kernels are single-threaded (xrspatial/utils.py:31) -- and, beside it, 8 threads over row bands (what the
+    reference's dask-threaded path gets out of its nogil kernels)."""
+    import concurrent.futures
     from oracle import c_oracle as corc
     from oracle import xrs_oracle as orc
     from tests import synth
@@ -434,6 +715,9 @@ def cpu_baseline(cols, kernel):
     corc.focal_apply(np.zeros((8, 8), np.float32), kernel, 'mean')     # load the library outside the timed region
     t_hill = t_focal = 0.0
     cells = 0
+    t8_hill = t8_focal = 0.0
+    cells8 = 0
+    pool = concurrent.futures.ThreadPoolExecutor(8)
     for c in range(n_chunks):
         dem = synth.asv_dem(chunk, cols, y0=c * chunk, total_rows=ROWS_PER_GPU)
         t0 = time.perf_counter()
@@ -444,6 +728,17 @@ def cpu_baseline(cols, kernel):
         t_hill += t1 - t0
         t_focal += t2 - t1
         cells += dem.size
+        if c % 2 == 0:                                     # 8 threads: half of the bands is plenty
+            sub = [dem[max(0, i * 128 - 1):min(chunk, (i + 1) * 128 + 1)] for i in range(8)]     # 8 row bands, 1-row overlap
+            t3 = time.perf_counter()
+            list(pool.map(orc.hillshade, sub))             # NumPy releases the GIL inside its ufunc loops
+            t4 = time.perf_counter()
+            corc.focal_apply(dem, kernel, 'mean', nthreads=8)
+            t5 = time.perf_counter()
+            t8_hill += t4 - t3
+            t8_focal += t5 - t4
+            cells8 += dem.size
+    pool.shutdown()
     return {
         "value": round(cells / (t_hill + t_focal) / 1e6, 2),
         "unit": "Mcells/s",
@@ -452,7 +747,66 @@ def cpu_baseline(cols, kernel):
         "sample": f"the {ROWS_PER_GPU}x{cols} DEM in {n_chunks} bands of {chunk} rows ({cells / 1e6:.0f} Mcells): "
                   f"hillshade via the NumPy restatement ({t_hill:.1f} s) + focal mean 5x5 via the C port "
                   f"({t_focal:.1f} s), one thread (the reference's Numba kernels are single-threaded)",
+        "threads8": {
+            "value": round(cells8 / (t8_hill + t8_focal) / 1e6, 2), "unit": "Mcells/s", "cores": 8, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"every second band ({cells8 / 1e6:.0f} Mcells): hillshade in 8 row bands on a thread pool ({t8_hill:.1f} s) + "
+                      f"focal mean via the C port with 8 OpenMP threads ({t8_focal:.1f} s) -- the reference's dask-threaded path",
+        },
     }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)     # the clocks settle over the first ~15 launches (profiles/r01)
+    ap.add_argument("--workload", choices=["headline", "s64", "zonal32k"], default="headline")
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="headline: rows per GPU (default: the BASELINE config)")
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--s64-size", type=int, default=65536, help="s64: side of the square DEM (smaller values for dry runs)")
+    ap.add_argument("--zonal-size", type=int, default=32768, help="zonal32k: side of the square raster")
+    ap.add_argument("--unfused", action="store_true",
+                    help="time the stand-alone launches (hillshade, [slope,] focal mean) instead of the fused pass")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: run the halo exchange and the pass back to back on one stream instead of hiding the "
+                         "exchange behind the interior rows")
+    ap.add_argument("--allow-host-halo", action="store_true",
+                    help="N > 1: if RCCL cannot connect the ranks, stage halo rows through the host (gloo) instead of failing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational measurements outside the timed region")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="experiment: do not record HIP events inside the timed region")
+    ap.add_argument("--per-step-events", action="store_true",
+                    help="fused mode: bracket every launch with its own pair of HIP events (default: ONE pair around the "
+                         "K timed launches; --unfused always uses per-kernel events)")
+    args = ap.parse_args()
+    ctx = Ctx(args)
+    if args.workload == "headline":
+        result = run_headline(ctx)
+    else:
+        body = run_s64(ctx) if args.workload == "s64" else run_zonal32k(ctx)
+        result = None
+        if ctx.rank == 0:
+            result = {
+                "metric": ("Mcells/s for hillshade+slope+focal.mean(5x5) on a 65536^2 f32 DEM, row-sharded" if args.workload == "s64"
+                           else "Mcells/s for zonal.stats partial sums, 32768^2 raster, 1000 int32 zones, row-sharded"),
+                "value": body.get("mcells_s"), "unit": "Mcells/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": body.get("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": args.workload, "halo_exchange": ctx.halo_via, "build_id": ctx._lib.build_id(), **body},
+                "roofline": {"bound": "hbm", "kernel": SYM_S64 if args.workload == "s64" else SYM_ZONAL,
+                             "achieved": body.get("algorithmic_gbs_per_gpu"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": None if body.get("algorithmic_gbs_per_gpu") is None else round(body["algorithmic_gbs_per_gpu"] / HBM_PEAK_GBS, 4),
+                             "traffic": None},
+            }
+    if ctx.rank == 0 and result is not None:
+        print(json.dumps(result), flush=True)
+    ctx.barrier()
+    if ctx.host_group is not None:
+        ctx.host_group.destroy_process_group()
+    if ctx.comm is not None:
+        ctx.comm.destroy()
 
 
 if __name__ == "__main__":

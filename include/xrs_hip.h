@@ -40,6 +40,10 @@ extern "C" {
 /* ------------------------------------------------------------------ runtime */
 int xrs_version(void);                                   /* ABI version, currently 1 */
 int xrs_last_error(char *buf, size_t buflen);            /* copies the thread's last error text */
+/* 16 hex digits identifying the SOURCES this library was built from (sha256 of csrc/ + this header, made by the
+ * Makefile): profiles/pmc_traffic.json records the build its counters were collected on and bench.py reports them only
+ * for that build. */
+int xrs_build_id(char *buf, size_t buflen);
 int xrs_device_count(int *count);
 int xrs_set_device(int device);
 int xrs_get_device(int *device);
@@ -313,6 +317,12 @@ int xrs_halo_exchange_f32(void *comm, float *shard_dev, int64_t rows, int64_t co
 int xrs_comm_selftest_f32(void *comm, const float *src_dev, float *dst_dev, int64_t count, void *stream);
 int xrs_zonal_allreduce(void *comm, uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                         void *min_dev, void *max_dev, int minmax_f64, int n_zones, void *stream);
+/* plain typed all-reduce of a device buffer, in place; op: 0 = sum, 1 = min, 2 = max.  Control-plane values of the
+ * sharded operators (what dask's scheduler moves for the reference: the zone-id range and the presence map of
+ * zonal.stats, zonal.py:181-277; the global moments of hotspots, focal.py:940-984) and the benchmark's barrier. */
+int xrs_allreduce_f64(void *comm, double *buf_dev, int64_t count, int op, void *stream);
+int xrs_allreduce_u8(void *comm, uint8_t *buf_dev, int64_t count, int op, void *stream);
+int xrs_allreduce_u64(void *comm, uint64_t *buf_dev, int64_t count, int op, void *stream);
 
 #ifdef __cplusplus
 }

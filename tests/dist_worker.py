@@ -16,7 +16,8 @@ def main(outdir):
     import torch.distributed as dist
     from oracle import xrs_oracle as orc
     from tests import synth
-    from xrspatial_amd.distributed import (halo_exchange_host, shard_halos, shard_rows, zonal_allreduce_host)
+    from tests.host_transport import halo_exchange_host, zonal_allreduce_host
+    from xrspatial_amd.distributed import shard_halos, shard_rows
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -56,8 +56,28 @@ def call(name, *a):
         a[0]._obj.value = addr
     elif name in ("xrs_memcpy_h2d", "xrs_memcpy_d2h", "xrs_memcpy_d2d"):
         ctypes.memmove(_host_ptr(a[0]), _host_ptr(a[1]), int(a[2]))
-    elif name in ("xrs_stream_sync", "xrs_device_sync"):
+    elif name in ("xrs_stream_sync", "xrs_device_sync", "xrs_event_record", "xrs_event_sync", "xrs_stream_wait_event",
+                  "xrs_event_destroy", "xrs_stream_destroy"):
         pass
+    elif name in ("xrs_stream_create", "xrs_event_create"):
+        a[0]._obj.value = 1
+    elif name == "xrs_event_elapsed_ms":
+        a[2]._obj.value = 1.0
+    elif name == "xrs_copy_f32":
+        ctypes.memmove(_host_ptr(a[1]), _host_ptr(a[0]), int(a[2]) * 4)
+    elif name == "xrs_zonal_partials_f32":
+        z, vals, n, nz, nodata, has_nodata, cnt, s1, s2, mn, mx, _ = a
+        idx = _arr(z, n, np.int32)
+        v = _arr(vals, n, np.float32)
+        ok = (idx >= 0) & (idx < nz) & np.isfinite(v)
+        if has_nodata:
+            ok &= v != np.float32(nodata)
+        v64 = v[ok].astype(np.float64)
+        _arr(cnt, nz, np.uint64)[...] += np.bincount(idx[ok], minlength=nz).astype(np.uint64)
+        _arr(s1, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64, minlength=nz)
+        _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
+        np.minimum.at(_arr(mn, nz, np.float32), idx[ok], v[ok])
+        np.maximum.at(_arr(mx, nz, np.float32), idx[ok], v[ok])
     elif name == "xrs_slope_f32":
         i, o, rows, cols, ld_i, ld_o, cx, cy, ht, hb, _ = a
         _stencil(lambda v: orc.slope(v, cx, cy), i, o, rows, cols, ld_i, ld_o, ht, hb)
@@ -175,7 +195,8 @@ class _FakeLib:
 def install(monkeypatch=None):
     """Route xrspatial_amd's C-ABI calls to the emulation (for the lifetime of the process if `monkeypatch` is None)."""
     from xrspatial_amd import _lib
-    for attr, val in (("call", call), ("load", lambda: _FakeLib), ("require_device", lambda: None)):
+    for attr, val in (("call", call), ("load", lambda: _FakeLib), ("require_device", lambda: None),
+                      ("build_id", lambda: "fake-hip")):
         if monkeypatch is None:
             setattr(_lib, attr, val)
         else:

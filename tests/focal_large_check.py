@@ -1,7 +1,7 @@
 """Large-window focal kernels on the GPU box: parity against the C oracle and same-box A/B timing of the
 first-generation column walkers (XRS_FOCAL_GEN=1) against the wide row walker / second-generation walker.
 
-    python tools/focal_large_check.py [--out gpurun_out/focal_large.json] [--size 16384] [--skip-parity]
+    python tests/focal_large_check.py [--out gpurun_out/focal_large.json] [--size 16384] [--skip-parity]
 
 Never stops at the first failure: every case is reported (max relative / absolute error, mismatching cells).
 """

@@ -2,7 +2,7 @@
 
 Every rank builds a ShardedArray from its rows of a seeded raster and calls the same functions a single-GPU user
 calls (slope, hillshade, focal.mean, focal.apply, convolution_2d, ndvi, fuse(), zonal.stats); the neighbours' rows
-travel through the shard's transport -- sharded.HostTransport over gloo by default (which also works when all ranks
+travel through the shard's transport -- tests/host_transport.HostTransport over gloo by default (which also works when all ranks
 share ONE GPU, as on the test box), distributed.Comm (RCCL) with XRS_TEST_TRANSPORT=rccl on a multi-GPU node.
 test_distributed_cpu.py runs the same worker without a GPU (XRS_TEST_FAKE_HIP=1)."""
 import os
@@ -24,7 +24,8 @@ def main(outdir):
     from xrspatial_amd import focal, zonal
     from xrspatial_amd.convolution import circle_kernel, convolution_2d
     from xrspatial_amd.distributed import Comm, shard_rows
-    from xrspatial_amd.sharded import HostTransport, ShardedArray
+    from tests.host_transport import HostTransport
+    from xrspatial_amd.sharded import ShardedArray
     import torch.distributed as dist
 
     dist.init_process_group("gloo")

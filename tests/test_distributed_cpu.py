@@ -5,6 +5,7 @@ kernels, so what is verified is that shards + halos reproduce the monolithic res
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -64,7 +65,7 @@ def test_overlapped_halo_plan_reproduces_the_monolithic_pass(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_api_host_logic(tmp_path, world):
     """xrspatial_amd.sharded through the PUBLIC API in a gloo group, with tests/fake_hip.py answering the C ABI from the
-    oracle: ShardedArray / HostTransport bookkeeping (which rows travel, when, halo_top / halo_bot per rank, results
+    oracle: ShardedArray / transport bookkeeping (which rows travel, when, halo_top / halo_bot per rank, results
     that are shards again, one fused pass, the zone-id agreement and the partial all-reduce of zonal.stats) must
     reproduce the monolithic oracle results bit for bit.  The same worker runs on the GPU in test_gpu_parity.py."""
     port = _free_port()
@@ -152,3 +153,85 @@ def test_row_sharded_pipeline_equals_monolithic(tmp_path, world):
         np.testing.assert_allclose(p["s1"], table['sum'], rtol=1e-12)
         np.testing.assert_array_equal(p["mn"], table['min'])
         np.testing.assert_array_equal(p["mx"], table['max'])
+
+
+def test_file_rendezvous_ignores_stale_files(tmp_path):
+    """Comm.from_file's rendezvous (distributed.rendezvous_id): three ranks agree on rank 0's fresh id although the id
+    file and hello files of an earlier run are still lying around under the same names, and clean up after themselves."""
+    import threading
+    from xrspatial_amd.distributed import rendezvous_id
+    path = str(tmp_path / "rdzv")
+    world = 3
+    with open(path, "wb") as fh:                                   # leftovers of a crashed run
+        fh.write(b"deadbeef\ncafebabe\n00\nID:" + b"S" * 128)
+    for r in range(world):
+        with open(f"{path}.hello{r}", "wb") as fh:
+            fh.write(b"stale-token-%d" % r)
+    fresh = bytes(range(128))
+    got, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            if rank:
+                time.sleep(0.15 * rank)                            # ranks arrive at different times
+            ident, finish = rendezvous_id(path, world, rank, lambda: fresh, timeout=20)
+            got[rank] = ident
+            time.sleep(0.3)                                        # (stands for ncclCommInitRank)
+            finish()
+        except Exception as exc:                                   # noqa: BLE001
+            errs.append(repr(exc))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(30)
+    assert not errs, errs
+    assert got == [fresh] * world
+    assert not os.path.exists(path) and not any(os.path.exists(f"{path}.hello{r}") for r in range(world))
+
+
+@pytest.mark.parametrize("workload,extra", [("s64", ["--s64-size", "192"]), ("zonal32k", ["--zonal-size", "4096"]),
+                                            ("headline", ["--rows", "96", "--cols", "320", "--no-extras"])])
+def test_bench_workloads_world2(workload, extra):
+    """bench.py's three workloads with two ranks (gloo; the C ABI answered by the oracle through tests/fake_hip.py): the
+    strong-scaled 65536^2-style pipeline (here 192^2) must reproduce the unsharded pass at the shard boundary bit for bit,
+    the sharded zonal reduction must reproduce the exact host counts, and the weak-scaled headline keeps its halo check."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", XRS_RDZV_TIMEOUT="5")
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--workload", workload, "--allow-host-halo", "--no-cpu-baseline", "--no-overlap"] + extra
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+        outs.append(out.decode())
+    import json
+    line = [ln for ln in outs[0].splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["value"] > 0
+    cfg = res["config"]
+    assert "host-staged" in cfg["halo_exchange"]                     # (no RCCL on this box: the run says so)
+    if workload == "s64":
+        assert res["scaling"] == "strong" and cfg["halo_check"]["ok"], cfg
+        assert cfg["rows_this_rank"] == 96
+    elif workload == "zonal32k":
+        assert res["scaling"] == "strong" and cfg["counts_bit_exact_vs_host"], cfg
+    else:
+        assert res["scaling"] == "weak" and cfg["halo_check"]["ok"], cfg
+
+
+def test_bench_refuses_multi_gpu_without_rccl():
+    """Without --allow-host-halo a rank whose RCCL communicator cannot be created exits with code 3 instead of silently
+    benchmarking a host-staged exchange."""
+    port = _free_port()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               XRS_RDZV_TIMEOUT="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, timeout=120)
+    assert p.returncode == 3, p.stderr.decode()[-2000:]
+    assert b"refusing to run a multi-GPU benchmark without RCCL" in p.stderr

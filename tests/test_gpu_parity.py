@@ -1594,7 +1594,7 @@ def test_sharded_array_single_rank_is_the_device_path():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_api_equals_single_gpu(tmp_path, world):
-    """`world` ranks (sharing this box's one GPU; halo rows through sharded.HostTransport over gloo) run the public API
+    """`world` ranks (sharing this box's one GPU; halo rows through tests/host_transport.HostTransport over gloo) run the public API
     on their row shards; stitched together the results equal the single-GPU results bit for bit, and every rank's
     zonal table equals the single-GPU table."""
     import socket

@@ -76,26 +76,36 @@ def main():
     _lib.call("xrs_device_name", 0, name, 256)
     print("device:", name.value.decode(), " raster:", n, "x", n, flush=True)
 
+    only = [s for s in args.only.split(",") if s]
+
+    def needs(*prefixes):
+        """Is any selected case one of these?  (inputs of unselected cases are not staged)"""
+        return not only or any(c.startswith(p) for c in only for p in prefixes)
+
     t0 = time.time()
     dem = device_raster(n, n, lambda r, c, y0: synth.asv_dem(r, c, y0=y0, total_rows=n))
-    b2 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 100 + y0))
-    b3 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 300 + y0))
-    zones = xs.DeviceArray((n, n), np.int32)
-    for y0 in range(0, n, 2048):
-        z = synth.block_zones(min(2048, n - y0), n, y0=y0)
-        _lib.call("xrs_memcpy_h2d", zones.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
-        _lib.call("xrs_stream_sync", None)
-    zones_sc = xs.DeviceArray((n, n), np.int32)        # scattered: random zone per 8x8-cell block (stresses the atomics)
-    rng = np.random.default_rng(9)
-    for y0 in range(0, n, 2048):
-        blocks = rng.integers(0, 1000, size=(2048 // 8, n // 8)).astype(np.int32)
-        z = np.repeat(np.repeat(blocks, 8, axis=0), 8, axis=1)
-        _lib.call("xrs_memcpy_h2d", zones_sc.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
-        _lib.call("xrs_stream_sync", None)
+    small = xs.DeviceArray((8, 8), np.int32)
+    b2 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 100 + y0)) if needs("ndvi", "evi", "savi") else small
+    b3 = device_raster(n, n, lambda r, c, y0: synth.bands((r, c), 300 + y0)) if needs("evi") else small
+    zones = zones_sc = small
+    if needs("zonal_1000", "crosstab", "crop"):
+        zones = xs.DeviceArray((n, n), np.int32)
+        for y0 in range(0, n, 2048):
+            z = synth.block_zones(min(2048, n - y0), n, y0=y0)
+            _lib.call("xrs_memcpy_h2d", zones.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
+            _lib.call("xrs_stream_sync", None)
+    if needs("zonal_1000_scattered"):
+        zones_sc = xs.DeviceArray((n, n), np.int32)    # scattered: random zone per 8x8-cell block (stresses the atomics)
+        rng = np.random.default_rng(9)
+        for y0 in range(0, n, 2048):
+            blocks = rng.integers(0, 1000, size=(2048 // 8, n // 8)).astype(np.int32)
+            z = np.repeat(np.repeat(blocks, 8, axis=0), 8, axis=1)
+            _lib.call("xrs_memcpy_h2d", zones_sc.ptr + y0 * n * 4, z.ctypes.data, z.nbytes, None)
+            _lib.call("xrs_stream_sync", None)
     print("inputs staged in %.1f s" % (time.time() - t0), flush=True)
 
     outs = [xs.DeviceArray((n, n), np.float32) for _ in range(7)]
-    out64 = xs.DeviceArray((n, n), np.float64)
+    out64 = xs.DeviceArray((n, n), np.float64) if needs("hillshade_f64out", "focal_mean3x3_f64") else small
     k5 = np.ascontiguousarray(circle_kernel(1, 1, 2))
     k3 = np.ones((3, 3))
     k25 = np.ascontiguousarray(circle_kernel(1, 1, 12))
@@ -123,11 +133,13 @@ def main():
         L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
 
     xt = xs.DeviceArray((1000 * 32,), np.uint64)
-    cats = xs.DeviceArray((n, n), np.int32)
-    zones64 = xs.DeviceArray((n, n), np.int32)
-    cats8 = xs.DeviceArray((n, n), np.int32)
+    cats = zones64 = cats8 = small
+    if needs("crosstab"):
+        cats = xs.DeviceArray((n, n), np.int32)
+        zones64 = xs.DeviceArray((n, n), np.int32)
+        cats8 = xs.DeviceArray((n, n), np.int32)
     rng2 = np.random.default_rng(10)
-    for y0 in range(0, n, 2048):
+    for y0 in range(0, n if needs("crosstab") else 0, 2048):
         c = rng2.integers(0, 32, size=(2048, n)).astype(np.int32)               # categorical: changes every cell
         _lib.call("xrs_memcpy_h2d", cats.ptr + y0 * n * 4, c.ctypes.data, c.nbytes, None)
         c8 = (c & 7).astype(np.int32)
@@ -146,8 +158,8 @@ def main():
     box4 = xs.DeviceArray((4,), np.int32)
     zero = np.zeros(1)
 
-    zones5k = xs.DeviceArray((n, n), np.int32)
-    for y0 in range(0, n, 2048):
+    zones5k = xs.DeviceArray((n, n), np.int32) if needs("zonal_5000") else small
+    for y0 in range(0, n if needs("zonal_5000") else 0, 2048):
         z5 = synth.block_zones(2048, n, n_zones=5000, block=128, y0=y0)
         _lib.call("xrs_memcpy_h2d", zones5k.ptr + y0 * n * 4, z5.ctypes.data, z5.nbytes, None)
         _lib.call("xrs_stream_sync", None)
@@ -239,7 +251,6 @@ def main():
         "nan_moments": (lambda: L("xrs_nan_moments_f32", dem.ptr, cells, mom.ptr, S), 4),
         "hotspots_classify": (lambda: L("xrs_hotspots_classify_f32", dem.ptr, out8.ptr, cells, 50.0, 20.0, S), 5),
     }
-    only = [s for s in args.only.split(",") if s]
     timer = Timer()
     results = {}
     print(f"{'kernel':28s} {'ms(med)':>9s} {'ms(min)':>9s} {'Mcells/s':>11s} {'GB/s(alg)':>10s}")

@@ -20,7 +20,7 @@ from .aspect import aspect  # noqa: F401
 from .curvature import curvature  # noqa: F401
 from .focal import mean  # noqa: F401
 from .fused import fuse  # noqa: F401
-from .sharded import HostTransport, ShardedArray  # noqa: F401
+from .sharded import ShardedArray  # noqa: F401
 from .hillshade import hillshade  # noqa: F401
 from .multispectral import arvi, evi, nbr, ndvi, savi, sipi  # noqa: F401
 from .slope import slope  # noqa: F401

@@ -30,6 +30,7 @@ class XrsError(RuntimeError):
 _PROTOTYPES = {
     "xrs_version": [],
     "xrs_last_error": [ctypes.c_char_p, c_size_t],
+    "xrs_build_id": [ctypes.c_char_p, c_size_t],
     "xrs_device_count": [ctypes.POINTER(c_int)],
     "xrs_set_device": [c_int],
     "xrs_get_device": [ctypes.POINTER(c_int)],
@@ -120,6 +121,9 @@ _PROTOTYPES = {
     "xrs_comm_selftest_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrs_halo_exchange_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
     "xrs_zonal_allreduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "xrs_allreduce_f64": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "xrs_allreduce_u8": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "xrs_allreduce_u64": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
 }
 _RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t,
              "xrs_geodesic_workspace_bytes": c_size_t}
@@ -153,6 +157,13 @@ def load():
 def last_error() -> str:
     buf = ctypes.create_string_buffer(512)
     load().xrs_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def build_id() -> str:
+    """Identity of the sources the loaded library was built from (xrs_build_id)."""
+    buf = ctypes.create_string_buffer(64)
+    load().xrs_build_id(buf, 64)
     return buf.value.decode(errors="replace")
 
 

@@ -121,4 +121,29 @@ int xrs_zonal_allreduce(void *comm, uint64_t *count_dev, double *sum_dev, double
     return 0;
 }
 
+/* Plain typed all-reduce of a device buffer, in place (control-plane values of the sharded operators: zone-id ranges,
+ * presence maps, moment triples, the benchmark's barrier and max-over-ranks).  op: 0 = sum, 1 = min, 2 = max. */
+static int allreduce_typed(const char *who, void *comm, void *buf_dev, int64_t count, ncclDataType_t dt, int op, void *stream) {
+    if (!comm) return fail("%s: null communicator", who);
+    if (count < 0 || (count > 0 && !buf_dev)) return fail("%s: bad buffer", who);
+    if (op < 0 || op > 2) return fail("%s: op must be 0 (sum), 1 (min) or 2 (max)", who);
+    if (count == 0) return 0;
+    Comm *c = static_cast<Comm *>(comm);
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMin, ncclMax};
+    XRS_NCCL(ncclAllReduce(buf_dev, buf_dev, (size_t)count, dt, ops[op], c->nccl, as_stream(stream)));
+    return 0;
+}
+
+int xrs_allreduce_f64(void *comm, double *buf_dev, int64_t count, int op, void *stream) {
+    return allreduce_typed("xrs_allreduce_f64", comm, buf_dev, count, ncclFloat64, op, stream);
+}
+
+int xrs_allreduce_u8(void *comm, uint8_t *buf_dev, int64_t count, int op, void *stream) {
+    return allreduce_typed("xrs_allreduce_u8", comm, buf_dev, count, ncclUint8, op, stream);
+}
+
+int xrs_allreduce_u64(void *comm, uint64_t *buf_dev, int64_t count, int op, void *stream) {
+    return allreduce_typed("xrs_allreduce_u64", comm, buf_dev, count, ncclUint64, op, stream);
+}
+
 }  // extern "C"

@@ -1,5 +1,6 @@
 // Runtime entry points: devices, memory, streams, events.  (include/xrs_hip.h "runtime")
 #include "xrs_common.h"
+#include "_build/build_id.h"
 
 using namespace xrs;
 
@@ -94,6 +95,13 @@ int xrs_copy2d(void *dst_dev, size_t dst_pitch, const void *src_dev, size_t src_
 }
 
 int xrs_version(void) { return 1; }
+
+int xrs_build_id(char *buf, size_t buflen) {
+    if (!buf || buflen == 0) return 1;
+    strncpy(buf, XRS_BUILD_ID, buflen - 1);
+    buf[buflen - 1] = 0;
+    return 0;
+}
 
 int xrs_last_error(char *buf, size_t buflen) {
     if (!buf || buflen == 0) return 1;

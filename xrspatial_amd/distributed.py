@@ -7,19 +7,96 @@ of rows: `halo_exchange` fills k//2 spare rows above/below the shard from the ne
 (one grouped ncclSend/ncclRecv pair per neighbour), after which every stencil entry point is
 called with halo_top / halo_bot set; zonal partials are all-reduced.
 
-Rendezvous is out of band: rank 0 creates the 128-byte RCCL id, any transport ships it
-(`Comm.from_torch_distributed` uses a gloo broadcast; `Comm.from_file` a shared file).
+Rendezvous is out of band: rank 0 creates the 128-byte RCCL id and the ranks of one node pick it up from a file
+(`Comm.from_env()`: RANK / WORLD_SIZE / MASTER_PORT as set by any launcher, `Comm.from_file` for an explicit path); a
+caller that already has a process group can ship the id itself (`Comm.from_torch_distributed`).  Nothing in this
+package imports torch.
 """
 from __future__ import annotations
 
 import ctypes
 import os
+import secrets
+import tempfile
+import threading
 import time
 
 import numpy as np
 
 from . import _lib
 from .device import DeviceArray
+
+
+def _atomic_write(path: str, data: bytes):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        fh.write(data)
+    os.replace(tmp, path)
+
+
+def _read_bytes(path: str):
+    try:
+        with open(path, "rb") as fh:
+            return fh.read()
+    except OSError:
+        return None
+
+
+def _read_text(path: str):
+    raw = _read_bytes(path)
+    return raw.decode(errors="replace").strip() if raw else None
+
+
+def rendezvous_id(path: str, world: int, rank: int, make_id, timeout: float = 120.0):
+    """Agree on one 128-byte id among `world` processes of a node through the file system.
+
+    Every rank drops `<path>.hello<rank>` with a fresh random token; rank 0 publishes `<path>` = the tokens it sees + the
+    id from `make_id()` (re-publishing while tokens change) and every rank waits until the published file carries ITS
+    token -- so files left behind by an earlier run under the same name are never mistaken for this run's.  Returns
+    (id, finish); call finish() once the id has been used: it stops rank 0's publisher and removes this rank's files."""
+    token = secrets.token_hex(16)
+    hello = f"{path}.hello{rank}"
+    _atomic_write(hello, token.encode())
+    stop = threading.Event()
+    publisher = None
+    if rank == 0:
+        ident = make_id()
+        if len(ident) != 128:
+            raise ValueError("the id must be 128 bytes")
+
+        def publish():
+            last = None
+            while not stop.is_set():
+                tokens = [_read_text(f"{path}.hello{r}") for r in range(world)]
+                if all(tokens) and tokens != last:
+                    _atomic_write(path, ("\n".join(tokens) + "\n").encode() + b"ID:" + ident)
+                    last = tokens
+                time.sleep(0.02)
+
+        publisher = threading.Thread(target=publish, daemon=True)
+        publisher.start()
+
+    def finish():
+        stop.set()
+        if publisher is not None:
+            publisher.join()
+        for f in ([hello] + ([path] if rank == 0 else [])):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+    t0 = time.time()
+    while True:
+        raw = _read_bytes(path)
+        if raw and b"ID:" in raw:
+            head, _, tail = raw.partition(b"ID:")
+            if token.encode() in head.split() and len(tail) == 128:
+                return tail, finish
+        if time.time() - t0 > timeout:
+            finish()
+            raise TimeoutError(f"no id for rank {rank} at {path} after {timeout:.0f} s")
+        time.sleep(0.02)
 
 
 def shard_rows(total_rows: int, world: int, rank: int):
@@ -63,41 +140,54 @@ class Comm:
 
     @classmethod
     def from_file(cls, path: str, world: int, rank: int, timeout: float = 120.0):
-        if rank == 0:
-            tmp = path + ".tmp"
-            with open(tmp, "wb") as fh:
-                fh.write(cls.new_id())
-            os.replace(tmp, path)
-        t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout:
-                raise TimeoutError(f"no RCCL id at {path}")
-            time.sleep(0.05)
-        with open(path, "rb") as fh:
-            return cls(fh.read(), world, rank)
+        """Rendezvous of the ranks of ONE node through the file system (`rendezvous_id`), then ncclCommInitRank."""
+        ident, finish = rendezvous_id(path, int(world), int(rank), cls.new_id, timeout)
+        try:
+            return cls(ident, world, rank)            # (ncclCommInitRank returns once every rank has joined)
+        finally:
+            finish()
+
+    @classmethod
+    def from_env(cls, timeout: float = 120.0):
+        """One process per GPU on one node, launched by anything that sets RANK and WORLD_SIZE (torch.distributed.run,
+        mpirun wrappers, a shell loop).  The rendezvous file is $XRS_RDZV_FILE, or a name in the temp directory derived
+        from MASTER_PORT (distinct concurrent jobs on a node have distinct ports)."""
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        path = os.environ.get("XRS_RDZV_FILE") or os.path.join(
+            tempfile.gettempdir(), "xrs_rdzv_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "job")))
+        return cls.from_file(path, world, rank, timeout)
 
     def halo_exchange(self, shard: DeviceArray, halo: int, stream=None):
         """`shard`: (rows + 2*halo, cols) buffer whose middle `rows` rows are owned (4- or 8-byte cells: whole rows
         travel, so a float64 / int32 plane goes as float32 words)."""
         rows = shard.shape[0] - 2 * halo
-        words = shard.shape[1] * shard.dtype.itemsize // 4
-        if shard.dtype.itemsize % 4:
-            raise TypeError("halo rows are exchanged in 4-byte words")
+        row_bytes = shard.shape[1] * shard.dtype.itemsize
+        if row_bytes % 4:
+            raise TypeError("halo rows are exchanged in 4-byte words: the row size in bytes must be a multiple of 4")
+        words = row_bytes // 4
         _lib.call("xrs_halo_exchange_f32", self.handle, shard.ptr + halo * words * 4, rows, words, words, halo, stream)
 
-    def allreduce(self, arr, op: str):
-        """float64 host array reduced over the ranks with 'sum' / 'min' / 'max' (small control-plane values: zone id
-        ranges, presence maps); rides on xrs_zonal_allreduce's sum / min / max lanes."""
-        flat = np.array(arr, dtype=np.float64, copy=True).reshape(-1)
-        n = flat.size
-        if n == 0:
-            return flat.reshape(np.shape(arr))
-        lanes = {k: DeviceArray.from_numpy(flat) for k in ('s1', 's2', 'mn', 'mx')}
-        cnt = DeviceArray.from_numpy(np.zeros(n, np.uint64))
-        _lib.call("xrs_zonal_allreduce", self.handle, cnt.ptr, lanes['s1'].ptr, lanes['s2'].ptr, lanes['mn'].ptr,
-                  lanes['mx'].ptr, 1, n, None)
-        out = lanes[{'sum': 's1', 'min': 'mn', 'max': 'mx'}[op]].get()
-        return out.reshape(np.shape(arr))
+    _OPS = {'sum': 0, 'min': 1, 'max': 2}
+
+    def allreduce(self, arr, op: str, stream=None):
+        """Host array reduced over the ranks with 'sum' / 'min' / 'max' (small control-plane values: zone-id ranges,
+        presence maps, moment triples).  uint8 / uint64 / float64 travel as they are (xrs_allreduce_u8 / _u64 / _f64);
+        anything else is widened to float64."""
+        a = np.asarray(arr)
+        kind = {np.dtype(np.uint8): "xrs_allreduce_u8", np.dtype(np.uint64): "xrs_allreduce_u64"}.get(a.dtype)
+        if kind is None:
+            a = a.astype(np.float64, copy=False)
+            kind = "xrs_allreduce_f64"
+        flat = np.ascontiguousarray(a).reshape(-1)
+        if flat.size == 0:
+            return flat.reshape(a.shape).copy()
+        dev = DeviceArray.from_numpy(flat, stream=stream)
+        _lib.call(kind, self.handle, dev.ptr, flat.size, self._OPS[op], stream)
+        return dev.get(stream).reshape(a.shape)
+
+    def barrier(self, stream=None):
+        """All ranks have reached this point (a one-element all-reduce, synchronised)."""
+        self.allreduce(np.zeros(1), 'sum', stream)
 
     def allreduce_zonal(self, cnt, s1, s2, mn, mx, f64, n_zones, stream=None):
         """Device partials -> globally reduced host arrays (count, sum, sumsq, min, max)."""
@@ -189,51 +279,11 @@ class OverlappedHalo:
 
 def combine_zonal_partials(parts):
     """Host-side combine of per-rank (count, sum, sumsq, min, max) partials -- the algebra of the
-    reference's dask path (zonal.py:92-99): sums add, min/max reduce.  Used by the gloo CPU tests and
-    by callers that gather partials themselves instead of calling xrs_zonal_allreduce."""
+    reference's dask path (zonal.py:92-99): sums add, min/max reduce.  For callers that gather partials
+    themselves instead of calling xrs_zonal_allreduce."""
     count = np.sum([p[0] for p in parts], axis=0, dtype=np.uint64)
     s1 = np.sum([p[1] for p in parts], axis=0)
     s2 = np.sum([p[2] for p in parts], axis=0)
     mn = np.min([p[3] for p in parts], axis=0)
     mx = np.max([p[4] for p in parts], axis=0)
     return count, s1, s2, mn, mx
-
-
-# ---------------------------------------------------------------------------------------------
-# Host-staged variants over an initialised torch.distributed process group (any backend; the CPU
-# tests use gloo).  They implement exactly the exchange / reduction pattern of xrs_halo_exchange_f32
-# and xrs_zonal_allreduce -- same neighbours, same rows, same reduction ops -- on NumPy buffers, for
-# flows whose shards live in host memory and for validating the sharding algebra without GPUs.
-
-def halo_exchange_host(dist, shard_with_halo: np.ndarray, halo: int):
-    """In place: fill rows [0, halo) from rank-1's last owned rows and rows [-halo, end) from rank+1's
-    first owned rows.  `shard_with_halo` has shape (rows + 2*halo, cols); outer ranks' outer halos are
-    left untouched (the caller passes halo_top/halo_bot = 0 there)."""
-    import torch
-    if halo == 0 or dist.get_world_size() == 1:
-        return
-    rank, world = dist.get_rank(), dist.get_world_size()
-    buf = torch.from_numpy(shard_with_halo)             # shares memory
-    rows = buf.shape[0] - 2 * halo
-    ops = []
-    if rank > 0:
-        ops.append(dist.P2POp(dist.isend, buf[halo:2 * halo].contiguous(), rank - 1))
-        ops.append(dist.P2POp(dist.irecv, buf[0:halo], rank - 1))
-    if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, buf[rows:rows + halo].contiguous(), rank + 1))
-        ops.append(dist.P2POp(dist.irecv, buf[rows + halo:rows + 2 * halo], rank + 1))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-
-
-def zonal_allreduce_host(dist, count, s1, s2, mn, mx):
-    """All-reduce per-zone partials across ranks: sum / sum / sum / min / max."""
-    import torch
-    out = []
-    for arr, op in ((count.astype(np.int64), dist.ReduceOp.SUM), (s1, dist.ReduceOp.SUM), (s2, dist.ReduceOp.SUM),
-                    (mn, dist.ReduceOp.MIN), (mx, dist.ReduceOp.MAX)):
-        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
-        dist.all_reduce(t, op=op)
-        out.append(t.numpy())
-    out[0] = out[0].astype(np.uint64)
-    return tuple(out)

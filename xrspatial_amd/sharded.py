@@ -4,13 +4,14 @@ The reference spreads a raster over workers with dask and gives every chunk its 
 `map_overlap(depth=k//2, boundary=nan)` (xrspatial/slope.py:86-97, focal.py:165-176, convolution.py:316-327) and
 combines per-block partials for zonal.stats (zonal.py:181-277).  Here the same role is played by `ShardedArray`:
 this rank's rows in HBM with `halo_cap` spare rows above and below, filled from the neighbouring ranks when an
-operator needs them -- over RCCL / xGMI (`distributed.Comm`) or, where RCCL cannot connect the ranks, through host
-memory and a torch.distributed group (`HostTransport`).  A DataArray whose `.data` is a ShardedArray goes through the
+operator needs them over RCCL / xGMI (`distributed.Comm`; any object with the same `halo_exchange` / `allreduce` /
+`allreduce_zonal` / `world` / `rank` surface works as the transport -- the test-suite's host-staged one, for several ranks
+sharing one GPU, lives in tests/host_transport.py).  A DataArray whose `.data` is a ShardedArray goes through the
 same public functions (`slope`, `hillshade`, `focal.mean`, `focal_stats`, `convolution_2d`, `ndvi`, `zonal.stats`, ...);
 every result is again a ShardedArray, so calls chain, and `fuse()` packs them into single passes as on one GPU.
 Operators without a sharded implementation raise; nothing silently computes shard by shard without halos.
 
-    comm = Comm.from_torch_distributed(dist)                       # or HostTransport(dist)
+    comm = Comm.from_env()                                          # one process per GPU, RANK / WORLD_SIZE set
     y0, y1 = shard_rows(total_rows, comm.world, comm.rank)
     dem = DataArray(ShardedArray.from_numpy(full[y0:y1], comm), dims=['y', 'x'], attrs={'res': (30.0, 30.0)})
     hs = hillshade(dem)                                             # halo rows exchanged once, reused by later calls
@@ -25,58 +26,6 @@ from . import _lib
 from .device import DeviceArray
 
 _DTYPES = (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.int8))
-
-
-class HostTransport:
-    """Halo rows and per-zone partials through host memory over an initialised torch.distributed group (gloo is
-    enough).  Same neighbours, rows and reduction operators as the RCCL path (`distributed.Comm`); for machines on
-    which RCCL cannot connect the ranks -- e.g. several ranks sharing one GPU."""
-
-    def __init__(self, dist):
-        self.dist = dist
-        self.world, self.rank = int(dist.get_world_size()), int(dist.get_rank())
-
-    def halo_exchange(self, base: DeviceArray, halo: int, stream=None):
-        """`base`: (rows + 2*halo, cols) plane whose middle rows are owned; fills the spare rows that face a neighbour."""
-        from .distributed import halo_exchange_host
-        if halo == 0 or self.world == 1:
-            return
-        total, cols = base.shape
-        rows = total - 2 * halo
-        rb = cols * base.dtype.itemsize                                 # bytes per row
-        if rows < 2 * halo:                                             # tiny shard: stage all of it
-            host = np.empty((total, cols), base.dtype)
-            _lib.call("xrs_memcpy_d2h", host.ctypes.data, base.ptr, total * rb, stream)
-            _lib.call("xrs_stream_sync", stream)
-            halo_exchange_host(self.dist, host, halo)
-            tail = rows + halo
-        else:
-            # [spare | first `halo` owned rows | last `halo` owned rows | spare]: the same layout with rows = 2*halo
-            host = np.empty((4 * halo, cols), base.dtype)
-            _lib.call("xrs_memcpy_d2h", host.ctypes.data + halo * rb, base.ptr + halo * rb, halo * rb, stream)
-            _lib.call("xrs_memcpy_d2h", host.ctypes.data + 2 * halo * rb, base.ptr + rows * rb, halo * rb, stream)
-            _lib.call("xrs_stream_sync", stream)
-            halo_exchange_host(self.dist, host, halo)
-            tail = 3 * halo
-        if self.rank > 0:
-            _lib.call("xrs_memcpy_h2d", base.ptr, host.ctypes.data, halo * rb, stream)
-        if self.rank < self.world - 1:
-            _lib.call("xrs_memcpy_h2d", base.ptr + (rows + halo) * rb, host.ctypes.data + tail * rb, halo * rb, stream)
-        _lib.call("xrs_stream_sync", stream)                            # `host` must outlive the copies
-
-    def allreduce(self, arr, op: str):
-        """float64 host array reduced over the ranks with 'sum' / 'min' / 'max'."""
-        import torch
-        t = torch.from_numpy(np.array(arr, dtype=np.float64, copy=True).reshape(-1))
-        self.dist.all_reduce(t, op={'sum': self.dist.ReduceOp.SUM, 'min': self.dist.ReduceOp.MIN,
-                                    'max': self.dist.ReduceOp.MAX}[op])
-        return t.numpy().reshape(np.shape(arr))
-
-    def allreduce_zonal(self, cnt, s1, s2, mn, mx, f64, n_zones, stream=None):
-        """Device partials -> globally reduced host arrays (count, sum, sumsq, min, max)."""
-        from .distributed import zonal_allreduce_host
-        parts = [a.get(stream) for a in (cnt, s1, s2, mn, mx)]
-        return zonal_allreduce_host(self.dist, *parts)
 
 
 class ShardedArray:

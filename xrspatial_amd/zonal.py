@@ -170,7 +170,7 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     else:
         _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
                   n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
-    if comm is not None:                 # distributed.Comm (RCCL) or sharded.HostTransport
+    if comm is not None:                 # distributed.Comm (RCCL) or any transport with the same surface
         return comm.allreduce_zonal(cnt, s1, s2, mn, mx, f64, n_zones, stream)
     return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream)
 
@@ -305,8 +305,8 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
     n_local = int(raw[2:3].view(np.uint64)[0])
     lo, hi = (raw[0], raw[1]) if n_local else (np.inf, -np.inf)
     if comm is not None and zones.world > 1:
-        lo = float(comm.allreduce(np.array([lo]), 'min')[0])
-        hi = float(comm.allreduce(np.array([hi]), 'max')[0])
+        lo, neg_hi = (float(v) for v in comm.allreduce(np.array([lo, -hi]), 'min'))      # one small all-reduce
+        hi = -neg_hi
     if not np.isfinite(lo):                                   # no rank holds a zone cell
         return pd.DataFrame({'zone': np.empty(0, np.int32), **{name: np.empty(0) for name in stat_names}})
     rng = int(hi - lo) + 1
@@ -314,10 +314,10 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
         raise NotImplementedError(f"zone ids span {rng} values; sharded zonal.stats handles up to {_SHARDED_RANGE_LIMIT}")
     present = DeviceArray((rng,), np.uint8)
     _lib.call("xrs_zonal_presence", zloc.ptr, _ZONE_DTYPE_CODE[zloc.dtype], zloc.size, float(lo), rng, present.ptr, stream)
-    seen = present.get(stream).astype(np.float64)
+    seen = present.get(stream)                                # uint8 flags: the union over the ranks is their maximum
     if comm is not None and zones.world > 1:
-        seen = comm.allreduce(seen, 'sum')
-    mask = seen > 0
+        seen = comm.allreduce(seen, 'max')
+    mask = np.asarray(seen) > 0
     lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
     unique_zones = (np.flatnonzero(mask).astype(np.float64) + lo).astype(np.int32)
     nz = len(unique_zones)

@@ -43,7 +43,7 @@ def parity(report):
     rng = np.random.default_rng(5)
     cases = []
     for kind in ("circle", "box"):
-        for radius in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+        for radius in (3, 4, 6, 9, 11, 12):
             K = 2 * radius + 1
             k = circle_kernel(1, 1, radius) if kind == "circle" else np.ones((K, K))
             for label, z in (

@@ -144,16 +144,16 @@ def test_multispectral_goldens(golden):
     np.testing.assert_allclose(xs.evi(nir, red, blue).data, golden["qgis_evi"], rtol=1e-6, equal_nan=True)
     np.testing.assert_allclose(xs.nbr(nir, raster(golden["ms_swir2"])).data, golden["qgis_nbr"], rtol=1e-6, equal_nan=True)
     swir1, swir2 = raster(golden["ms_swir1"]), raster(golden["ms_swir2"])
-    out = xs.nbr2(swir1, swir2)                       # test_multispectral.py:199-206 (QGIS golden)
+    out = xs.multispectral.nbr2(swir1, swir2)                       # test_multispectral.py:199-206 (QGIS golden)
     assert out.name == 'nbr2' and out.data.dtype == np.float32
     np.testing.assert_allclose(out.data, golden["qgis_nbr2"], rtol=1e-6, equal_nan=True)
     np.testing.assert_array_equal(out.data, orc.normalized_ratio(golden["ms_swir1"], golden["ms_swir2"]))
-    out = xs.ndmi(nir, swir1)                         # test_multispectral.py:228-235 (QGIS golden)
+    out = xs.multispectral.ndmi(nir, swir1)                         # test_multispectral.py:228-235 (QGIS golden)
     assert out.name == 'ndmi' and out.data.dtype == np.float32
     np.testing.assert_allclose(out.data, golden["qgis_ndmi"], rtol=1e-6, equal_nan=True)
     np.testing.assert_array_equal(out.data, orc.normalized_ratio(golden["ms_nir"], golden["ms_swir1"]))
     for name, fn, args in (("ndvi", xs.ndvi, (nir, red)), ("evi", xs.evi, (nir, red, blue)), ("savi", xs.savi, (nir, red)),
-                           ("nbr2", xs.nbr2, (swir1, swir2)), ("ndmi", xs.ndmi, (nir, swir1))):
+                           ("nbr2", xs.multispectral.nbr2, (swir1, swir2)), ("ndmi", xs.multispectral.ndmi, (nir, swir1))):
         parity_log.record("goldens (QGIS vectors held by the reference's tests)", name, fn(*args).data, golden["qgis_" + name],
                           tol="rtol 1e-6")
     for dtype in ("uint8", "uint16"):

@@ -1,0 +1,46 @@
+#!/bin/bash
+# One GPU-box session: test-suite with the parity report, large-window focal parity + A/B timing, bench line, PMC
+# counters, rocprofv3 kernel stats, per-kernel table.  Every step has its own timeout and log; nothing stops the rest.
+#   gpurun --timeout 1800 -- 'bash tools/gpu_round.sh r02a [steps...]'
+TAG=${1:-r02x}; shift
+STEPS=${@:-"tests focal bench pmc stats kbench"}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+ROOT=$(pwd)
+echo "build id: $(python -c 'from xrspatial_amd import _lib; print(_lib.build_id())')" | tee $OUT/build_id.txt
+for s in $STEPS; do
+  t0=$(date +%s)
+  case $s in
+    tests)
+      XRS_PARITY_REPORT=$ROOT/$OUT/parity.json timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider \
+        --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -40 $OUT/pytest_gpu.log ;;
+    focal)
+      timeout 900 python tests/focal_large_check.py --out $OUT/focal_large.json > $OUT/focal_large.log 2>&1
+      echo "rc=$?" >> $OUT/focal_large.log; grep -v "^ok " $OUT/focal_large.log | tail -60 ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
+    pmc)
+      timeout 900 python tools/pmc_profile.py copy_kernel,pass_hill_focal5,pass_hill_slope_focal5,focal5_mean,hillshade,slope,aspect,focal25_mean,focal25_stats7 \
+        --out $OUT/pmc.json --traffic $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"; tail -3 $OUT/pmc.log ;;
+    stats)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$TAG -o s -- \
+        python $ROOT/bench.py --steps 50 --warmup 10 --no-extras --no-cpu-baseline > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err)
+      find /tmp/stats_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \; ; cat $OUT/bench_under_rocprof.json | head -c 600; echo; head -5 $OUT/bench_kernel_stats.csv ;;
+    kbench)
+      timeout 900 python tools/kbench.py --reps 10 --json $OUT/kbench.json > $OUT/kbench.log 2>&1; echo "kbench rc=$?"; tail -70 $OUT/kbench.log ;;
+    focal_ab)
+      for lib in libxrs_hip.so libxrs_hip_u10.so libxrs_hip_u25.so; do
+        echo "--- $lib"; XRS_LIB=$ROOT/xrspatial_amd/$lib timeout 600 python tests/focal_large_check.py --skip-parity --out $OUT/focal_timing_$lib.json 2>&1 | grep -v "^ok " | grep "r=12\|r=6\|copy"
+      done ;;
+    quicktests)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -x -k "focal or fused or pass or kxk or circular or wide or window or full_size or multispectral or flat or large_mask" > $OUT/pytest_quick.log 2>&1
+      echo "rc=$?" >> $OUT/pytest_quick.log; tail -15 $OUT/pytest_quick.log ;;
+    kb_small)
+      timeout 600 python tools/kbench.py --reps 10 --only copy_kernel,hillshade,slope,aspect,pass_hill_focal5,pass_hill_slope_focal5,pass_curv_hill_focal5,pass_hill_focal3,focal5_mean,focal3_mean,focal25_mean,focal25_stats7,focal13_mean,focal13_stats7,box11_mean,box11_stats7 --fast-inputs > $OUT/kb_small.log 2>&1; tail -20 $OUT/kb_small.log ;;
+    s64bench)
+      timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
+    *) echo "unknown step $s" ;;
+  esac
+  echo "== step $s took $(( $(date +%s) - t0 )) s"
+done

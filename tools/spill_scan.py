@@ -22,6 +22,7 @@ def scan(path):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only",
+                        "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",       # (the Makefile's NOPK)
                         "-o", out, path], check=True, cwd=CSRC)
         text = open(out).read()
     rows = []

@@ -51,6 +51,49 @@ inline bool is_shape(const double *kernel) {
     return true;
 }
 
+// a[s] <- a[(s + U) mod K] for every s, in place: the permutation is gcd(K, U) cycles of length K / gcd, walked with
+// one temporary each (static indices after unrolling, so this is K register moves and nothing else).
+constexpr int walk_gcd(int a, int b) { return b == 0 ? a : walk_gcd(b, a % b); }
+template <int K, int U, typename T>
+__device__ __forceinline__ void ring_rotate(T (&a)[K]) {
+    constexpr int G = walk_gcd(K, U % K == 0 ? K : U % K), LEN = K / G;
+    if (U % K == 0) return;
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+        const T tmp = a[c];
+        int sl = c;
+#pragma unroll
+        for (int k = 0; k + 1 < LEN; ++k) {
+            const int from = (sl + U) % K;
+            a[sl] = a[from];
+            sl = from;
+        }
+        a[sl] = tmp;
+    }
+}
+
+template <int K, int U, int N>
+__device__ __forceinline__ void ring_rotate(float (&a)[K][N]) {                // the same for N values per slot
+    constexpr int G = walk_gcd(K, U % K == 0 ? K : U % K), LEN = K / G;
+    if (U % K == 0) return;
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+        float tmp[N];
+#pragma unroll
+        for (int o = 0; o < N; ++o) tmp[o] = a[c][o];
+        int sl = c;
+#pragma unroll
+        for (int k = 0; k + 1 < LEN; ++k) {
+            const int from = (sl + U) % K;
+#pragma unroll
+            for (int o = 0; o < N; ++o) a[sl][o] = a[from][o];
+            sl = from;
+        }
+#pragma unroll
+        for (int o = 0; o < N; ++o) a[sl][o] = tmp[o];
+    }
+}
+
 struct WalkGeom {
     const float *in;
     long rows, cols, ld_in, ld_out;

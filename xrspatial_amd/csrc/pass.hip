@@ -11,8 +11,8 @@
 // the stand-alone kernels (strip.h) already holds a superset of the 3x3 neighbourhood when it holds the 5x5
 // one -- so the fused kernel reads each cell once (4 B) and writes 4 B per product: 12 B per cell for
 // hillshade + focal mean, 16 B for hillshade + slope + focal mean (the 65536^2 target pipeline, 24 B unfused).
-// Arithmetic is the stand-alone kernels' (terrain_cells.h, focal_mean_direct_kernel): results are
-// bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
+// Arithmetic is the stand-alone kernels' (terrain_cells.h; strip.h strip_mean_f32 as in focal_mean_direct_kernel):
+// results are bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
 //
 // Any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane).  Masks larger than 5x5 run as
 // the separate launches -- same results, no fusion.
@@ -105,44 +105,16 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
         }
     }
 
-    // ---- focal mean (float64 accumulation in row-major tap order == numba nanmean over the window)
+    // ---- focal mean (interior, finite, clustered values: float32 sums of shifted values; otherwise float64 accumulation
+    // in row-major tap order == numba nanmean over the window)
     float *fout = a.focal + y0 * a.ld_out + x_tile;
     if (!CAREFUL) {
-        double acc[RB][4];
+        // float32 on values shifted by the lane's centre cell (strip.h: strip_mean_f32); false -> the caller re-runs the
+        // focal part through the float64 NaN-aware body below
+        float m[RB][4];
+        if (!strip_mean_f32<KH, KW, RB, CMASK>(v, a.mask_rows, (float)a.inv_ntaps, m)) return false;
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-            double d[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : a.mask_rows[ky];
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (bits >> kx & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
-                    }
-            }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
-        if (__any(bad)) return false;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float m[4] = {(float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
-                                (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)};
-            put4<NT>(fout + r * a.ld_out + loff, m);
-        }
+        for (int r = 0; r < RB; ++r) put4<NT>(fout + r * a.ld_out + loff, m[r]);
     } else {
         // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
         // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to

@@ -4,11 +4,11 @@
 //
 // Second generation of the column walker of circle_walk.h (which stays as the exact NaN-skipping path):
 //   * a lane owns ONE column of a 64-column x W2TH-row wave tile and walks down; every input row is loaded once per
-//     wave (one dword per lane + 2R halo lanes, prefetched PFN rows ahead), staged through LDS, and each lane reads the
+//     wave (one dword per lane + 2R halo lanes, prefetched 3-5 rows ahead), staged through LDS, and each lane reads the
 //     2R+1 cells around its column back (ds_read2_b32 pairs).
 //   * the 2R+1 output rows in flight live in register rings indexed (row - dy) mod (2R+1); the row loop is unrolled
-//     2R+1 times so every index is a compile-time constant -- the ring never moves (the first generation spends
-//     ~150 of its ~400 instructions per cell and row on v_mov).
+//     2R+1 times so every index is a compile-time constant and the rings never move (the first generation shifts them
+//     every row: ~150 of its ~400 instructions per cell and row are v_mov).
 //   * no per-cell NaN bookkeeping: the fast path assumes finite cells and a constant count; a non-finite window sum
 //     at emit time hands the whole tile to the exact walker.  Raster edges stay on the fast path (out-of-raster cells
 //     contribute nothing, the divisor is the geometric count of in-raster cells).
@@ -38,8 +38,15 @@ struct Walk2Cfg {
     static constexpr int K = 2 * R + 1;
     static constexpr int STG = 64 + 2 * R;
     static constexpr int NTAPS = shape_taps<Shape>(R);
-    static constexpr int PFN = (K % 5 == 0) ? 5 : (K % 3 == 0) ? 3 : (K == 7 ? 7 : 3);
-    static constexpr bool ROT = (K % PFN == 0);
+#ifndef XRS_WALK2_U
+#define XRS_WALK2_U (2 * R + 1)
+#endif
+    // rows per unrolled round (rings rotated by U after each).  U = 2R+1: no rotation at all.  Measured for R = 12, all
+    // seven statistics (profiles/r02): U = 5 6.6 ms (the rotation's parallel copy spills at the 256-register budget),
+    // U = 10 4.3 ms, U = 25 3.4 ms.
+    static constexpr int U = XRS_WALK2_U;
+    static constexpr int PFN = (U % 5 == 0) ? 5 : (U % 4 == 0) ? 4 : 3;       // rows prefetched into registers
+    static constexpr bool ROT = U % PFN == 0;              // prefetch slot = phase mod PFN (otherwise the slots shift)
     static constexpr bool level_used(int h) {
         for (int dy = 0; dy <= R; ++dy)
             if (Shape::hw(R, dy) == h) return true;
@@ -168,46 +175,69 @@ struct Walk2 {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                 // (LDS serves one wave's instructions in order)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float v[K];
-            double dv[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { v[k] = rowf[lane + k]; dv[k] = rowd[lane + k]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- extrema and float64 moments over centred runs, from the centre outwards.  EDGE: the cells left of
-            // column 0 / right of the last column (k outside [kmin, kmax]) are not part of any window: NaN for min /
-            // max (skipped), 0 for the moments.  A NaN INSIDE the raster poisons S and sends the tile to the exact walker.
+            // ---- extrema, then float64 moments, over centred runs from the centre outwards (two passes over the row
+            // buffer: the 2R+1 raw cells and the 2R+1 shifted float64 cells are not live at the same time).  EDGE: the
+            // cells left of column 0 / right of the last column (k outside [kmin, kmax]) are not part of any window: NaN
+            // for min / max (skipped), 0 for the moments.  A NaN INSIDE the raster poisons S and sends the tile to the
+            // exact walker.
             const float qnan = nan_f32();
             float lo, hi;
-            double S, Q;
             {
+                float v[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[k] = rowf[lane + k];
                 const bool in_c = !EDGE || (R >= kmin && R <= kmax);
                 lo = hi = in_c ? v[R] : qnan;
-                const double d = in_c ? dv[R] : 0.0;
-                S = d; Q = d * d;
-            }
 #pragma unroll
-            for (int h = 0; h <= R; ++h) {
-                if (h > 0) {
-                    const bool in_a = !EDGE || R - h >= kmin, in_b = !EDGE || R + h <= kmax;
-                    const float va = in_a ? v[R - h] : qnan, vb = in_b ? v[R + h] : qnan;
-                    lo = raw_min3(lo, va, vb);
-                    hi = raw_max3(hi, va, vb);
-                    const double a = in_a ? dv[R - h] : 0.0;
-                    const double b = in_b ? dv[R + h] : 0.0;
-                    S += a + b;
-                    Q = fma(a, a, fma(b, b, Q));
+                for (int h = 0; h <= R; ++h) {
+                    if (h > 0) {
+                        const bool in_a = !EDGE || R - h >= kmin, in_b = !EDGE || R + h <= kmax;
+                        const float va = in_a ? v[R - h] : qnan, vb = in_b ? v[R + h] : qnan;
+                        lo = raw_min3(lo, va, vb);
+                        hi = raw_max3(hi, va, vb);
+                    }
+                    if (!C::level_used(h)) continue;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int dy = j - R;
+                        if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
+                        const int idx = ((PHASE - dy) % K + K) % K;
+                        mn[idx] = raw_min(mn[idx], lo);
+                        mx[idx] = raw_max(mx[idx], hi);
+                    }
                 }
-                if (!C::level_used(h)) continue;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double dv[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int dy = j - R;
-                    if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
-                    const int idx = ((PHASE - dy) % K + K) % K;
-                    sd[idx] += S;
-                    sq[idx] += Q;
-                    mn[idx] = raw_min(mn[idx], lo);
-                    mx[idx] = raw_max(mx[idx], hi);
+                for (int k = 0; k < K; ++k) dv[k] = rowd[lane + k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double S, Q;
+                {
+                    const bool in_c = !EDGE || (R >= kmin && R <= kmax);
+                    const double d = in_c ? dv[R] : 0.0;
+                    S = d; Q = d * d;
+                }
+#pragma unroll
+                for (int h = 0; h <= R; ++h) {
+                    if (h > 0) {
+                        const bool in_a = !EDGE || R - h >= kmin, in_b = !EDGE || R + h <= kmax;
+                        const double a = in_a ? dv[R - h] : 0.0;
+                        const double b = in_b ? dv[R + h] : 0.0;
+                        S += a + b;
+                        Q = fma(a, a, fma(b, b, Q));
+                    }
+                    if (!C::level_used(h)) continue;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int dy = j - R;
+                        if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
+                        const int idx = ((PHASE - dy) % K + K) % K;
+                        sd[idx] += S;
+                        sq[idx] += Q;
+                    }
                 }
             }
             vlo = raw_min(vlo, lo);
@@ -254,13 +284,18 @@ struct Walk2 {
     template <int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (step<P>(), ...);
+        // the round started at a row i0 with ring slot (j - i0) mod K for output row j; the next one starts at i0 + U
+        ring_rotate<K, C::U>(sd);
+        ring_rotate<K, C::U>(sq);
+        ring_rotate<K, C::U>(mn);
+        ring_rotate<K, C::U>(mx);
     }
 
     // 0: every result of the tile is good; 1: the exact walker redoes the moments; 2: it redoes everything
     __device__ __forceinline__ int run() {
         init();
         while (i < n_in) {
-            round(std::make_integer_sequence<int, K>{});
+            round(std::make_integer_sequence<int, C::U>{});
             if (__any(bad)) return 2;
         }
         return __any(redo) ? 1 : 0;

@@ -4,22 +4,34 @@
 //
 // The "wide" row walker: ONE 16-byte load per lane per input row, neighbours through LDS, float32 arithmetic on
 // shifted values, a register ring with static indices.
-//   * a wave owns a tile of 256 columns x WTH output rows and walks DOWN its input rows; a lane owns 4 adjacent
-//     columns (one global_load_dwordx4 per row; the 2*HL halo columns come from one extra dword load of the first
-//     2*HL lanes).  Rows are prefetched PFN rows ahead into registers.
-//   * the row (minus a wave-uniform shift c, the cell at the tile centre) goes to LDS once (ds_write_b128) and every
-//     lane reads back the 4 + 2*HL consecutive cells its four windows cover as aligned ds_read_b128 (conflict free).
+//   * a wave owns a tile of 256 columns x ~128 output rows and walks DOWN its input rows; a lane owns 4 adjacent
+//     columns.  Every input row reaches LDS once (256 + 2*HL cells: one 16-byte and one 4-byte transfer per lane) and
+//     every lane reads back the 4 + 2*HL consecutive cells its four windows cover as aligned ds_read_b128 (conflict
+//     free), minus a wave-uniform shift c (the cell at the tile centre).
 //   * a lane-local prefix sum over those cells turns every centred run of the mask into ONE subtraction,
 //     S_h(x) = P[x + h] - P[x - h - 1]; a circle of radius 12 has only 9 distinct half-widths.
-//   * the 2R+1 output rows in flight live in a register ring, acc[(row - dy) mod (2R+1)]; the row loop is unrolled
-//     2R+1 times so that every ring index is a compile-time constant: no register moves, 25 adds per cell and row.
+//   * the 2R+1 output rows in flight live in a register ring, acc[(row - dy) mod (2R+1)]; the row loop is unrolled U = 5
+//     times so that every ring index is a compile-time constant, and the ring is rotated by U slots once per U rows
+//     (4 * (2R+1) / U register moves per row).  Unrolling all 2R+1 phases needs no moves at all but makes a 50 KB loop
+//     body: 16 waves at different phases then stream it through the 64 KB instruction cache two CUs share, and the
+//     kernel runs at instruction-fetch speed (measured: 1.20 ms against 0.6 ms; profiles/r02).
 //   * mean = c + S / n.  Everything is float32: the error of S is bounded by u * A * (a few 10^4) with A the largest
 //     |v - c| of the tile, i.e. <= 7e-6 * A on the mean; the wave checks A <= 1.4 * min |mean| at the end of its tile
 //     (which guarantees 1e-5 relative) and that every result is finite, and otherwise hands the whole tile to the
 //     float64 column walker of circle_walk.h (NaN-skipping, counting, exact) -- nodata regions, +-inf, rasters whose
 //     values straddle zero take that path.  Typical errors are ~1e-8 relative (tests: 1e-6 on both DEMs).
 //   * raster edges (clipped windows): out-of-raster cells enter as d = 0 and the divisor is the geometric count of
-//     in-raster cells, so edge tiles stay on the fast path.
+//     in-raster cells, so edge tiles stay on the fast path (a second, predicated instantiation of the same walk).
+//   * memory latency: the interior walk prefetches its rows D = 8 ahead by LDS-DMA (global_load_lds_dwordx4: global ->
+//     LDS without passing through registers) into a ring of D + 1 row buffers per wave, and waits with an explicit
+//     `s_waitcnt vmcnt(2 D)` for the row it is about to read (2 DMAs per row; stores issued in between only make the
+//     wait conservative).  Register prefetching does not work with this compiler: load results consumed by the NEXT
+//     loop iteration are copied into their phi registers at the loop latch, every copy needs its load, and hipcc emits
+//     `s_waitcnt vmcnt(0)` once per round -- the very latency the prefetch was meant to hide (0.91 ms for the 25x25
+//     mean); loading a whole round up front costs 50 registers and exposes one HBM round trip per round (0.72 ms);
+//     the DMA ring needs no registers at all (experiments/glds_walk.hip: the bare data movement runs at 0.42-0.47 ms).
+//     The DMA delivers raw cells, so the shift is subtracted after the read-back (NV instead of NC subtractions).
+//     Edge tiles keep plain predicated loads (one round = U rows loaded up front).
 // Included by kxk_wide_circle.hip and kxk_wide_box.hip, which define XRS_WIDE_SHAPE / XRS_WIDE_ENTRY.
 // vs the one-column walker this replaces for `mean`: 25 dword loads + ~270 VALU instructions per cell and row ->
 // 0.3 loads + ~50.  HBM-bound by construction (8 B per cell); measured numbers in DESIGN.md.
@@ -31,11 +43,9 @@ using namespace xrs;
 
 namespace {
 
-constexpr int WTH = 128;          // output rows per wave tile
-
 struct WideArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
-    float *out_mean, *out_sum;    // either may be NULL
+    float *out;                   // the mean, or the window sum (template parameter of the kernel)
     long n_groups;                // workgroups = groups of 4 horizontally adjacent wave tiles
     long groups_x;
 };
@@ -43,13 +53,30 @@ struct WideArgs {
 template <int R, typename Shape>
 struct WideCfg {
     static constexpr int K = 2 * R + 1;
-    static constexpr int HL = 4 * ((R + 3) / 4);          // halo columns each side, rounded up to whole float4s
-    static constexpr int NV = 4 + 2 * HL;                  // cells a lane reads back per row
-    static constexpr int NQ = NV / 4;
-    static constexpr int STG = 256 + 2 * HL;               // staged cells per row
+#ifndef XRS_WIDE_NC
+#define XRS_WIDE_NC 4
+#endif
+    static constexpr int NC = XRS_WIDE_NC;                 // columns per lane (2: 128-column wave tiles, half the registers)
+    static constexpr int TW = 64 * NC;                     // columns per wave tile
+    static constexpr int HL = NC * ((R + NC - 1) / NC);    // halo columns each side, rounded up to whole lane groups
+    static constexpr int NV = NC + 2 * HL;                 // cells a lane reads back per row
+    static constexpr int NQ = NV / NC;
+    static constexpr int STG = TW + 64;                    // staged cells per row (TW + 2*HL used; every lane writes one halo slot)
+    static_assert(2 * HL <= 64, "the halo cells are loaded by one lane each");
     static constexpr int NTAPS = shape_taps<Shape>(R);
-    static constexpr int PFN = (K % 5 == 0) ? 5 : (K % 3 == 0) ? 3 : (K == 7 ? 7 : 3);    // rows prefetched
-    static constexpr bool ROT = (K % PFN == 0);            // prefetch slots addressed by the (static) phase
+#ifndef XRS_WALK_U
+#define XRS_WALK_U 5
+#endif
+    static constexpr int U = XRS_WALK_U;                   // rows per unrolled round (the accumulator ring is rotated by U after each)
+#ifndef XRS_WIDE_D
+#define XRS_WIDE_D 8
+#endif
+    static constexpr int D = XRS_WIDE_D;                   // interior tiles: rows in flight by LDS-DMA; D + 1 row buffers per wave
+    static constexpr int RBF = STG > 320 ? STG : 320;      // floats per ring row (the 16-byte DMA writes a whole KiB, the dword one 256 B)
+    static constexpr int LDS_WAVE = (D + 1) * RBF;    // floats of LDS per wave (a DMA writes whole KiB)
+    static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: a whole number of rounds
+    static constexpr int WTH = NIN - 2 * R;                // output rows per wave tile (128 .. 128 + U - 1)
+    static constexpr int NE = 2 * R;                       // the first input row whose completion emits an output row
     static constexpr bool level_used(int h) {
         for (int dy = 0; dy <= R; ++dy)
             if (Shape::hw(R, dy) == h) return true;
@@ -71,55 +98,69 @@ __device__ __forceinline__ int clipped_count(long yo, long x, long y_lo, long y_
     return n;
 }
 
-template <int R, typename Shape, bool EDGE>
+// global -> LDS without registers: every lane supplies its own source address, the destination is the wave-uniform LDS
+// byte address `lds_dst` + lane * size (M0 is saved and restored around the instruction: the compiler owns it)
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds8(const void *gsrc, unsigned lds_dst) {      // (gfx950 has no 8-byte LDS-DMA: two dwords)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// EDGE = false: a full tile whose whole input window lies inside the raster (no predicates, see the header);
+// EDGE = true: everything else (predicated loads / stores, clipped counts, partial tiles).  SUM: emit the window sum.
+template <int R, typename Shape, bool EDGE, bool SUM>
 struct WideWalk {
     using C = WideCfg<R, Shape>;
-    static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, PFN = C::PFN;
+    static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW;
 
     // ---- state
-    float acc[K][4];
-    xrs_f4u pf_own[PFN];
-    float pf_halo[PFN];
+    float acc[K][NC];
+    float pf_own[EDGE ? U : 1][NC];   // EDGE: the rows of the current round, loaded up front
+    float pf_halo[EDGE ? U : 1];
+    int slot_in, slot_out;         // interior: ring slots of the next DMA / of the row being processed
+    unsigned ring_addr;            // LDS byte address of this wave's ring
     float amax, mmin;
     bool bad;
-    int i;                         // input row counter: row y_first + i
+    int t;                         // input row counter: row y_first + t
     // ---- constants of the tile
     const WalkGeom &g;
-    float *out_mean, *out_sum;
-    float *lds;                    // this wave's row buffer (STG floats)
+    float *out;
+    float *lds;                    // this wave's (D + 1) row buffers of STG floats (EDGE uses the first)
     long x_tile, y0, y_end, y_first;
     int n_in, lane;
     float c;                       // the shift
-    float n_full[4];               // EDGE: cell count of a window whose rows are all inside, per owned column
+    float n_full[NC];              // EDGE: cell count of a window whose rows are all inside, per owned column
 
-    __device__ __forceinline__ WideWalk(const WalkGeom &g_, float *om, float *os, float *lds_, long xt, long y0_, long ye, int lane_)
-        : g(g_), out_mean(om), out_sum(os), lds(lds_), x_tile(xt), y0(y0_), y_end(ye), lane(lane_) {}
+    __device__ __forceinline__ WideWalk(const WalkGeom &g_, float *out_, float *lds_, long xt, long y0_, long ye, int lane_)
+        : g(g_), out(out_), lds(lds_), x_tile(xt), y0(y0_), y_end(ye), lane(lane_) {}
 
-    __device__ __forceinline__ void load_row(int il, xrs_f4u &own, float &halo) const {
-        // staged cell s <-> raster column x_tile - HL + s; lane owns s = 4*lane .. 4*lane+3, lanes < 2*HL also cell 256+lane
+    typedef float vecNC __attribute__((ext_vector_type(NC), aligned(4)));
+
+    __device__ __forceinline__ void load_row(int il, float (&own)[NC], float &halo) const {
+        // staged cell s <-> raster column x_tile - HL + s; lane owns s = NC*lane .. NC*lane+NC-1; the 2*HL halo cells
+        // s = TW + lane come from the first 2*HL lanes (the other lanes repeat the last one: no branch, no use)
         const long yy = y_first + il;
-        const long xs = x_tile - HL + 4 * lane;
-        if (!EDGE) {
-            const float *p = g.in + yy * g.ld_in + (x_tile - HL);
-            own = load_f4u(p + 4 * lane);
-            halo = c;
-            if (lane < 2 * HL) halo = p[256 + lane];
-            return;
-        }
-        own.x = own.y = own.z = own.w = c;                   // out-of-raster cells: d = 0 after the shift
+        const long xs = x_tile - HL + NC * lane;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) own[e] = c;             // out-of-raster cells: d = 0 after the shift
         halo = c;
         const bool row_ok = il < n_in && yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;     // wave-uniform
         if (!row_ok) return;
         const float *p = g.in + yy * g.ld_in;
-        if (xs >= 0 && xs + 4 <= g.cols) {
-            own = load_f4u(p + xs);
-        } else {
-            if (xs >= 0 && xs < g.cols) own.x = p[xs];
-            if (xs + 1 >= 0 && xs + 1 < g.cols) own.y = p[xs + 1];
-            if (xs + 2 >= 0 && xs + 2 < g.cols) own.z = p[xs + 2];
-            if (xs + 3 >= 0 && xs + 3 < g.cols) own.w = p[xs + 3];
-        }
-        const long xh = x_tile - HL + 256 + lane;
+#pragma unroll
+        for (int e = 0; e < NC; ++e)
+            if (xs + e >= 0 && xs + e < g.cols) own[e] = p[xs + e];
+        const long xh = x_tile - HL + TW + lane;
         if (lane < 2 * HL && xh >= 0 && xh < g.cols) halo = p[xh];
     }
 
@@ -127,69 +168,114 @@ struct WideWalk {
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[j][o] = 0.0f;
+            for (int o = 0; o < NC; ++o) acc[j][o] = 0.0f;
         amax = 0.0f;
         mmin = INFINITY;
         bad = false;
-        i = 0;
+        t = 0;
         y_first = y0 - R;
-        n_in = (int)(y_end - y0) + 2 * R;
+        n_in = EDGE ? (int)(y_end - y0) + 2 * R : C::NIN;
         // shift: the cell at the tile centre (any finite value works; a nearby one keeps |v - c| small)
-        const long yc = y0 + (y_end - y0) / 2, xc = (x_tile + 128 < g.cols ? x_tile + 128 : g.cols - 1);
+        const long yc = y0 + (y_end - y0) / 2, xc = (x_tile + TW / 2 < g.cols ? x_tile + TW / 2 : g.cols - 1);
         const float c0 = g.in[yc * g.ld_in + xc];
         c = isfinite(c0) ? c0 : 0.0f;
         if (EDGE) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                n_full[o] = (float)clipped_count<R, Shape>(0, x_tile + 4 * lane + o, -(long)R, (long)R + 1, g.cols);
+            for (int o = 0; o < NC; ++o)
+                n_full[o] = (float)clipped_count<R, Shape>(0, x_tile + NC * lane + o, -(long)R, (long)R + 1, g.cols);
+        } else {
+            ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+            ring_addr = __builtin_amdgcn_readfirstlane(ring_addr);
+            for (int r = 0; r < C::D; ++r) dma_row(r, r);
+            slot_in = C::D;
+            slot_out = 0;
         }
-#pragma unroll
-        for (int s = 0; s < PFN; ++s) load_row(s, pf_own[s], pf_halo[s]);
     }
 
-    // One input row.  No exits inside a round of K steps (a step past the last row is skipped as a whole): with early
-    // returns the compiler sinks the ring updates of all K phases into the loop latch and spills their operands.
+    // interior: input row `il` (clamped past the tile) -> ring slot `slot`, as a linear image of the TW + 2*HL staged cells
+    __device__ __forceinline__ void dma_row(int il, int slot) const {
+        constexpr int CELLS = TW + 2 * HL;
+        const int ilc = il < C::NIN ? il : C::NIN - 1;
+        const float *p = g.in + (y_first + ilc) * g.ld_in + (x_tile - HL);
+        const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
+        constexpr int QMAX = (CELLS < 256 ? CELLS : 256) / 4 - 1;
+        glds16(p + 4 * (lane < QMAX ? lane : QMAX), dst);
+        if (CELLS > 256) glds4(p + 256 + (lane < CELLS - 257 ? lane : CELLS - 257), dst + 1024);
+    }
+    static constexpr int NDMA = (TW + 2 * HL > 256) ? 2 : 1;       // DMA instructions per row
+
+    // One row of the round.  There are no exits inside a round of U steps: with early returns the compiler sinks the
+    // ring updates of all phases into the loop latch and spills their operands.
     template <int PHASE>
     __device__ __forceinline__ void step() {
-        if (i < n_in) step_body<PHASE>();
-        ++i;
+        const int i = t + PHASE;
+        if (EDGE) {
+            if (i < n_in) process<PHASE>(pf_own[PHASE], pf_halo[PHASE], i);
+        } else {
+            dma_row(i + C::D, slot_in);                          // row i + D on its way while row i is processed
+            slot_in = slot_in + 1 == C::D + 1 ? 0 : slot_in + 1;
+            // Row i's DMAs were issued D steps ago.  Vector-memory operations younger than them: D * NDMA DMAs, plus --
+            // once the walk emits (one store per step from row 2R on) -- the D stores in between: waiting for exactly that
+            // many leaves the full D rows in flight; before that, counting no stores is the safe side.
+            if (i >= 2 * R + C::D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::D * (NDMA + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::D * NDMA) : "memory");
+            process<PHASE>(pf_own[0], 0.0f, i);
+            slot_out = slot_out + 1 == C::D + 1 ? 0 : slot_out + 1;
+        }
     }
 
     template <int PHASE>
-    __device__ __forceinline__ void step_body() {
-        constexpr int SLOT = C::ROT ? PHASE % PFN : 0;
-        const xrs_f4u q = pf_own[SLOT];
-        const float hq = pf_halo[SLOT];
-        if (!C::ROT) {
-#pragma unroll
-            for (int s = 0; s + 1 < PFN; ++s) { pf_own[s] = pf_own[s + 1]; pf_halo[s] = pf_halo[s + 1]; }
-        }
-        constexpr int REFILL = C::ROT ? SLOT : PFN - 1;
-        if (EDGE || i + PFN < n_in) load_row(i + PFN, pf_own[REFILL], pf_halo[REFILL]);      // (EDGE: load_row tests the row itself)
-
+    __device__ __forceinline__ void process(const float (&q)[NC], float hq, int i) {
         const long yy = y_first + i;
         const bool row_in = !EDGE || (yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot);  // wave-uniform
         if (row_in) {
-            // ---- shifted row -> LDS, each lane reads back the NV cells under its four windows
-            const float d0 = q.x - c, d1 = q.y - c, d2 = q.z - c, d3 = q.w - c, dh = hq - c;
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fmaxf(fabsf(d2), fabsf(d3))));
-            amax = fmaxf(amax, fabsf(dh));                   // (lanes >= 2*HL: hq = c, dh = 0)
-            bad |= !(isfinite(d0 + d1) && isfinite(d2 + d3) && isfinite(dh));
-            float *row = lds;      // ONE row buffer: LDS serves a wave's instructions in order, so the next row's writes
-                                   // (issued after this row's reads) cannot overtake them
-            *reinterpret_cast<float4 *>(row + 4 * lane) = make_float4(d0, d1, d2, d3);
-            if (lane < 2 * HL) row[256 + lane] = dh;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                 // (LDS serves one wave's instructions in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            typedef float ldsNC __attribute__((ext_vector_type(NC)));
             float w[NV];
+            if (EDGE) {
+                // ---- shifted row -> LDS, each lane reads back the NV cells under its NC windows
+                float d[NC];
+                const float dh = hq - c;
 #pragma unroll
-            for (int b = 0; b < NQ; ++b) {
-                const float4 t = *reinterpret_cast<const float4 *>(row + 4 * lane + 4 * b);
-                w[4 * b] = t.x; w[4 * b + 1] = t.y; w[4 * b + 2] = t.z; w[4 * b + 3] = t.w;
+                for (int e = 0; e < NC; ++e) d[e] = q[e] - c;
+#pragma unroll
+                for (int e = 0; e + 1 < NC; e += 2) amax = amax3(amax, d[e], d[e + 1]);
+                amax = amax3(amax, dh, 0.0f);
+                float *row = lds;  // ONE row buffer: LDS serves a wave's instructions in order, so the next row's writes
+                                   // (issued after this row's reads) cannot overtake them
+                ldsNC dq;
+#pragma unroll
+                for (int e = 0; e < NC; ++e) dq[e] = d[e];
+                *reinterpret_cast<ldsNC *>(row + NC * lane) = dq;
+                row[TW + lane] = dh;                             // (lanes >= 2*HL: a slot nobody reads)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                 // (LDS serves one wave's instructions in order)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int b = 0; b < NQ; ++b) {
+                    const ldsNC v4 = *reinterpret_cast<const ldsNC *>(row + NC * lane + NC * b);
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) w[NC * b + e] = v4[e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // ---- the row landed in the ring (raw cells): read the NV cells under the lane's windows, shift them
+                const float *row = lds + slot_out * C::RBF;
+#pragma unroll
+                for (int b = 0; b < NQ; ++b) {
+                    const ldsNC v4 = *reinterpret_cast<const ldsNC *>(row + NC * lane + NC * b);
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) w[NC * b + e] = v4[e] - c;
+                }
+                // largest |d| of the tile: the lanes' own cells cover the tile's columns, the first / last cells of the
+                // first / last lanes its halo columns
+#pragma unroll
+                for (int e = 0; e + 1 < NC; e += 2) {
+                    amax = amax3(amax, w[HL + e], w[HL + e + 1]);
+                    amax = amax3(amax, w[e], w[e + 1]);
+                    amax = amax3(amax, w[NV - NC + e], w[NV - NC + e + 1]);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             // ---- lane-local prefix sums: P[k] = w[0] + .. + w[k]; cell o's centre is w[HL + o]
 #pragma unroll
             for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
@@ -197,9 +283,9 @@ struct WideWalk {
 #pragma unroll
             for (int h = 0; h <= R; ++h) {
                 if (!C::level_used(h)) continue;
-                float S[4];
+                float S[NC];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
+                for (int o = 0; o < NC; ++o) {
                     const int hi = HL + o + h, lo = HL + o - h - 1;
                     S[o] = lo >= 0 ? w[hi] - w[lo] : w[hi];
                 }
@@ -209,7 +295,7 @@ struct WideWalk {
                     if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
                     const int idx = ((PHASE - dy) % K + K) % K;
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[idx][o] += S[o];
+                    for (int o = 0; o < NC; ++o) acc[idx][o] += S[o];
                 }
             }
         }
@@ -217,10 +303,10 @@ struct WideWalk {
         constexpr int DONE = ((PHASE - R) % K + K) % K;
         if (i >= 2 * R) {
             const long yo = y0 + (i - 2 * R);
-            const long xo = x_tile + 4 * lane;
-            float m[4], sm[4];
+            const long xo = x_tile + NC * lane;
+            float res[NC];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < NC; ++o) {
                 float n = (float)C::NTAPS;
                 if (EDGE) {
                     const bool rows_in = yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot;   // wave-uniform
@@ -228,43 +314,43 @@ struct WideWalk {
                                 : (float)clipped_count<R, Shape>(yo, xo + o, -(long)g.halo_top, g.rows + g.halo_bot, g.cols);
                 }
                 const float s = acc[DONE][o];
-                m[o] = EDGE ? c + s / n : fmaf(s, 1.0f / (float)C::NTAPS, c);
-                sm[o] = fmaf(n, c, s);
+                const float m = EDGE ? c + s / n : fmaf(s, 1.0f / (float)C::NTAPS, c);
+                res[o] = SUM ? fmaf(n, c, s) : m;
                 bad |= !isfinite(s);
-                if (!EDGE || xo + o < g.cols) mmin = fminf(mmin, fabsf(m[o]));
+                if (!EDGE || xo + o < g.cols) mmin = fminf(mmin, fabsf(m));
             }
+            float *po = out + yo * g.ld_out + xo;
             if (!EDGE) {
-                if (out_mean) store_f4u(out_mean + yo * g.ld_out + xo, m[0], m[1], m[2], m[3]);
-                if (out_sum) store_f4u(out_sum + yo * g.ld_out + xo, sm[0], sm[1], sm[2], sm[3]);
+                typedef float stNC __attribute__((ext_vector_type(NC), aligned(4)));
+                stNC rq;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) rq[o] = res[o];
+                __builtin_nontemporal_store(rq, reinterpret_cast<stNC *>(po));
             } else {
-                const int nown = g.cols - xo >= 4 ? 4 : (g.cols - xo > 0 ? (int)(g.cols - xo) : 0);
-                if (nown > 0) {
-                    if (out_mean) store_cols4(out_mean + yo * g.ld_out + xo, m, nown);
-                    if (out_sum) store_cols4(out_sum + yo * g.ld_out + xo, sm, nown);
-                }
+#pragma unroll
+                for (int o = 0; o < NC; ++o)
+                    if (xo + o < g.cols) po[o] = res[o];
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[DONE][o] = 0.0f;
-    }
-
-    static __device__ __forceinline__ void store_cols4(float *p, const float (&v)[4], int n) {
-        if (n >= 4) { store_f4u(p, v[0], v[1], v[2], v[3]); return; }
-        p[0] = v[0];
-        if (n > 1) p[1] = v[1];
-        if (n > 2) p[2] = v[2];
+        for (int o = 0; o < NC; ++o) acc[DONE][o] = 0.0f;
     }
 
     template <int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
+        if (EDGE) (load_row(t + P, pf_own[P], pf_halo[P]), ...);      // edge tiles: all loads of the round first
         (step<P>(), ...);
+        // the round started at row t with ring slot (j - t) mod K for output row j; the next one starts at t + U
+        ring_rotate<K, U>(acc);
+        t += U;
     }
 
     // true: every result of the tile is good; false: the caller redoes the tile with the float64 walker
     __device__ __forceinline__ bool run() {
         init();
-        while (i < n_in) {
-            round(std::make_integer_sequence<int, K>{});
+        constexpr auto phases = std::make_integer_sequence<int, U>{};
+        while (t < n_in) {
+            round(phases);
             if (__any(bad)) return false;                    // a non-finite cell: stop early
         }
         // error bound of the float32 sums (header): |delta mean| <= u * A * (K * (2 * NV^2 + K) + K * NTAPS) / n
@@ -274,65 +360,76 @@ struct WideWalk {
             a = fmaxf(a, __shfl_xor(a, sft));
             mm = fminf(mm, __shfl_xor(mm, sft));
         }
-        constexpr float U = 5.9604645e-8f;
-        constexpr float COEF = U * (float)(K * (2 * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
-        const bool ok = !__any(bad) && (COEF * a <= 0.9e-5f * mm);
-        return ok;
+        constexpr float UNIT = 5.9604645e-8f;
+        constexpr float COEF = UNIT * (float)(K * (2 * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
+        return !__any(bad) && (COEF * a <= 0.9e-5f * mm);
     }
 };
 
-template <int R, typename Shape>
-__global__ void __launch_bounds__(256, 2) focal_wide_kernel(const WideArgs a) {
+template <int R, typename Shape, bool SUM>
+#ifndef XRS_WIDE_WAVES
+#define XRS_WIDE_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const WideArgs a) {
     using C = WideCfg<R, Shape>;
-    __shared__ __attribute__((aligned(16))) float lds_rows[4][C::STG];
+    __shared__ __attribute__((aligned(16))) float lds_rows[4][C::LDS_WAVE];
     const long gidx = xcd_tile(blockIdx.x, a.n_groups);
     if (gidx < 0) return;
     const long ty = gidx / a.groups_x, gx = gidx - ty * a.groups_x;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long x_tile = (gx * 4 + wv) * 256;
-    const long y0 = ty * WTH;
+    const long x_tile = (gx * 4 + wv) * C::TW;
+    const long y0 = ty * C::WTH;
     const WalkGeom &g = a.g;
     if (x_tile >= g.cols) return;
-    const long y_end = y0 + WTH < g.rows ? y0 + WTH : g.rows;
-    const bool interior = x_tile - C::HL >= 0 && x_tile + 256 + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
-                          y_end + R <= g.rows + g.halo_bot;
+    const long y_end = y0 + C::WTH < g.rows ? y0 + C::WTH : g.rows;
+    const bool interior = x_tile - C::HL >= 0 && x_tile + C::TW + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
+                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
     bool ok;
     if (interior) {
-        WideWalk<R, Shape, false> w(g, a.out_mean, a.out_sum, lds_rows[wv], x_tile, y0, y_end, lane);
+        WideWalk<R, Shape, false, SUM> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
         ok = w.run();
     } else {
-        WideWalk<R, Shape, true> w(g, a.out_mean, a.out_sum, lds_rows[wv], x_tile, y0, y_end, lane);
+        WideWalk<R, Shape, true, SUM> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
         ok = w.run();
     }
     if (ok) return;
     // non-finite cells under a window, or sums too ill-conditioned for float32: the float64 column walker (NaN-skipping,
     // counting; mean from float64 sums, the sum with the reference's sequential float32 adds), 64 columns at a time
-    const WalkOuts o = {a.out_sum, nullptr, nullptr, nullptr, a.out_mean, nullptr, nullptr};
-    for (int q = 0; q < 4; ++q) {
-        if (a.out_mean) walk_columns<R, Shape, false, false, false, true, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
-        if (a.out_sum) walk_columns<R, Shape, true, true, false, false, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
+    const WalkOuts o = {SUM ? a.out : nullptr, nullptr, nullptr, nullptr, SUM ? nullptr : a.out, nullptr, nullptr};
+    for (int q = 0; q < C::NC; ++q) {
+        if (!SUM) walk_columns<R, Shape, false, false, false, true, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
+        else walk_columns<R, Shape, true, true, false, false, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
     }
 }
 
 template <int R, typename Shape>
-int launch_wide(WideArgs &a, hipStream_t s) {
+int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
+    using C = WideCfg<R, Shape>;
     WalkGeom &g = a.g;
-    g.tiles_x = (g.cols + 255) / 256;
-    const long tiles_y = (g.rows + WTH - 1) / WTH;
+    g.tiles_x = (g.cols + C::TW - 1) / C::TW;
+    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;
     const long grid = xcd_grid(a.n_groups);
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
-    hipLaunchKernelGGL((focal_wide_kernel<R, Shape>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    XRS_LAUNCH_CHECK();
+    if (out_mean) {
+        a.out = out_mean;
+        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        XRS_LAUNCH_CHECK();
+    }
+    if (out_sum) {
+        a.out = out_sum;
+        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        XRS_LAUNCH_CHECK();
+    }
     return 0;
 }
 
-int dispatch_wide(WideArgs &a, const double *kernel, int r, hipStream_t s) {
+int dispatch_wide(WideArgs &a, float *out_mean, float *out_sum, const double *kernel, int r, hipStream_t s) {
     switch (r) {
-#define XRS_WIDE_CASE(RR) case RR: return is_shape<RR, XRS_WIDE_SHAPE>(kernel) ? launch_wide<RR, XRS_WIDE_SHAPE>(a, s) : -1;
+#define XRS_WIDE_CASE(RR) case RR: return is_shape<RR, XRS_WIDE_SHAPE>(kernel) ? launch_wide<RR, XRS_WIDE_SHAPE>(a, out_mean, out_sum, s) : -1;
 #ifndef XRS_WIDE_PROBE
         XRS_WIDE_CASE(3) XRS_WIDE_CASE(4) XRS_WIDE_CASE(5) XRS_WIDE_CASE(6) XRS_WIDE_CASE(7) XRS_WIDE_CASE(8)
         XRS_WIDE_CASE(9) XRS_WIDE_CASE(10) XRS_WIDE_CASE(11)
@@ -348,6 +445,7 @@ int dispatch_wide(WideArgs &a, const double *kernel, int r, hipStream_t s) {
 namespace xrs {
 
 // 0 = launched, -1 = not this shape with a radius of 3..12 cells (caller takes another kernel), > 0 = error.
+// (mean and sum together: two launches)
 int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in, long ld_out,
                    const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
     if (krows != kcols || !(krows & 1)) return -1;
@@ -356,8 +454,7 @@ int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_sum, long rows, 
     memset(&a, 0, sizeof(a));
     a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
-    a.out_mean = out_mean; a.out_sum = out_sum;
-    return dispatch_wide(a, kernel, krows / 2, s);
+    return dispatch_wide(a, out_mean, out_sum, kernel, krows / 2, s);
 }
 
 }  // namespace xrs

@@ -59,6 +59,15 @@ inline long xcd_grid(long n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
 
 __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); }
 
+// max(a, |b|, |c|) in one v_max3_f32 (no canonicalising moves; a NaN operand is skipped, which is what the guard below
+// wants: NaN cells are caught through the sums they poison)
+__device__ __forceinline__ float amax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+
 // 16-byte global accesses at DWORD alignment (global_load/store_dwordx4 only need 4-byte alignment on gfx9+): rasters
 // whose width or pitch is not a multiple of 4 cells -- an SRTM tile is 3601 wide -- keep the one-instruction-per-lane
 // row accesses of the strip kernels instead of dropping to one-cell-per-thread kernels.

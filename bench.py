@@ -213,6 +213,13 @@ class Ctx:
         ms = self.timed(lambda: self.L("xrs_copy_f32", src_ptr, dst_ptr, cells, self.stream), reps=10)
         return 8.0 * cells / (ms * 1e-3) / 1e9
 
+    def mix_bandwidth(self, src_ptr, dst_ptrs, cells):
+        """The same streaming pattern with one plane read and len(dst_ptrs) planes written (xrs_stream_mix_f32): the
+        ceiling for a fused kernel's own read / write mix."""
+        arr = (ctypes.c_void_p * len(dst_ptrs))(*dst_ptrs)
+        ms = self.timed(lambda: self.L("xrs_stream_mix_f32", src_ptr, arr, len(dst_ptrs), cells, self.stream), reps=10)
+        return 4.0 * (1 + len(dst_ptrs)) * cells / (ms * 1e-3) / 1e9
+
     def replicate_rows(self, dev_ptr, band_rows, total_rows, row_bytes):
         """Fill rows [band_rows, total_rows) of a device plane with copies of its first `band_rows` rows."""
         y = band_rows
@@ -380,6 +387,9 @@ def run_headline(ctx):
         halo_check = {"cells_differing_from_the_unsharded_pass_at_shard_boundaries": int(total_bad), "ok": bool(total_bad == 0)}
 
     copy_gbs = ctx.copy_bandwidth(dem_ptr, out_hill.ptr, rows * cols) if rank == 0 else None
+    # the streaming ceiling of the step's own traffic mix: 1 plane read, 2 written (fused) -- HBM sustains less on
+    # write-heavy mixes than on the 1:1 copy
+    mix_gbs = ctx.mix_bandwidth(dem_ptr, [out_hill.ptr, out_focal.ptr], rows * cols) if rank == 0 and not args.unfused else None
 
     # Informational, OUTSIDE the timed region (rank 0, N=1): the other kernels of BASELINE configs[1]/[2] on the
     # same resident raster, the 65536^2 and 32768^2 configurations on this one GPU, and one numpy-in/numpy-out call to
@@ -491,6 +501,9 @@ def run_headline(ctx):
                                "one HIP event pair around the K timed launches on the launch stream / K (gaps included)"),
             "measured_copy_gbs": round(copy_gbs, 1),
             "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+            "measured_stream_gbs_same_mix": None if mix_gbs is None else round(mix_gbs, 1),
+            "frac_of_measured_stream_same_mix": None if mix_gbs is None else round(achieved / mix_gbs, 4),
+            "same_mix": None if mix_gbs is None else "xrs_stream_mix_f32: 1 plane read + 2 planes written, the copy kernel's access pattern",
             "algorithmic_bytes_per_cell": alg_bytes,
         },
     }
@@ -601,6 +614,7 @@ def run_s64(ctx, steps=None, warmup=None, brief=False):
     if world == 1:
         # the north_star bar: >= 70 % of the MEASURED copy bandwidth at 65536^2, fused and as three calls
         copy_gbs = ctx.copy_bandwidth(dem_ptr, o_hill.ptr, rows * cols)
+        mix3 = ctx.mix_bandwidth(dem_ptr, [o_hill.ptr, o_slope.ptr, o_focal.ptr], rows * cols)
         t3 = ctx.timed(three_calls, reps=3)
         tf = ctx.timed(fused, reps=3)
         out.update({
@@ -611,6 +625,8 @@ def run_s64(ctx, steps=None, warmup=None, brief=False):
             "fused_pass_ms": round(tf, 3), "fused_pass_mcells_s": round(cells_total / (tf * 1e-3) / 1e6, 1),
             "fused_pass_frac_of_measured_copy": round(16 * cells_total / (tf * 1e-3) / 1e9 / copy_gbs, 4),
             "fused_pass_frac_of_8TBs": round(16 * cells_total / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "measured_stream_gbs_1read_3writes": round(mix3, 1),
+            "fused_pass_frac_of_stream_1read_3writes": round(16 * cells_total / (tf * 1e-3) / 1e9 / mix3, 4),
         })
     del o_hill, o_slope, o_focal, buf
     return out

@@ -59,6 +59,10 @@ int xrs_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int xrs_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int xrs_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int xrs_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
+/* Calibration: the streaming pattern of xrs_copy_f32 with ONE plane read and n_dst (1..8) planes written -- the ceiling
+ * of a fused kernel's own read/write mix (HBM3E sustains less on write-heavy mixes than on a 1:1 copy).  `dsts_dev` is a
+ * HOST array of device pointers.  Used by bench.py / tools/kbench.py next to xrs_copy_f32; not on the data path. */
+int xrs_stream_mix_f32(const float *src_dev, float *const *dsts_dev, int n_dst, int64_t n, void *stream);
 /* a rectangular window of a plane (pitches and width in bytes): `raster[top:bottom + 1, left:right + 1]` of a
  * device-resident raster (the slicing at the end of zonal.trim / zonal.crop, xrspatial/zonal.py:1841, 2058) */
 int xrs_copy2d(void *dst_dev, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes,

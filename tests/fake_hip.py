@@ -65,6 +65,9 @@ def call(name, *a):
         a[2]._obj.value = 1.0
     elif name == "xrs_copy_f32":
         ctypes.memmove(_host_ptr(a[1]), _host_ptr(a[0]), int(a[2]) * 4)
+    elif name == "xrs_stream_mix_f32":
+        for i in range(int(a[2])):
+            ctypes.memmove(_host_ptr(a[1][i]), _host_ptr(a[0]), int(a[3]) * 4)
     elif name == "xrs_zonal_partials_f32":
         z, vals, n, nz, nodata, has_nodata, cnt, s1, s2, mn, mx, _ = a
         idx = _arr(z, n, np.int32)

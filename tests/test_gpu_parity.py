@@ -954,8 +954,18 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
         got = focal_stats(raster(z), k)
         want = focal_stats(raster(z, backend='hip'), k).data.get()
         assert isinstance(got.data, np.ndarray) and got.shape == (7, 1400, 1024)
-        np.testing.assert_array_equal(got.data, want, err_msg=f"focal_stats {k.shape}")
-        np.testing.assert_array_equal(apply(raster(z), k).data, want[0])
+        big = k.shape[0] >= 7 and (k == 1).all() | (k.shape[0] == 19)     # circles / boxes from 7x7 up: the row walkers
+        for i, stat in enumerate(orc.FOCAL_STATS):
+            if big and stat in ('mean', 'std', 'var', 'sum'):
+                # the walkers sum values shifted by a cell at the centre of the wave's TILE (float64 in walk2_impl.h,
+                # float32 in wide_impl.h): cutting the raster into bands moves the tiles, and the last bit may move with them
+                np.testing.assert_allclose(got.data[i], want[i], rtol=3e-7, atol=0, equal_nan=True, err_msg=f"focal_stats {stat} {k.shape}")
+            else:
+                np.testing.assert_array_equal(got.data[i], want[i], err_msg=f"focal_stats {stat} {k.shape}")
+        if big:
+            np.testing.assert_allclose(apply(raster(z), k).data, want[0], rtol=3e-7, atol=0, equal_nan=True)
+        else:
+            np.testing.assert_array_equal(apply(raster(z), k).data, want[0])
         w = k / k.sum()
         np.testing.assert_array_equal(convolve_2d(z, w), convolve_2d(zdev, w).get(), err_msg=f"convolve {k.shape}")
     # per-cell indices: same pipeline over flat chunks (ragged tail, mixed input dtypes)

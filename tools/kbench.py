@@ -179,6 +179,10 @@ def main():
     cases = {
         "copy_d2d": (lambda: L("xrs_memcpy_d2d", outs[0].ptr, dem.ptr, cells * 4, S), 8),
         "copy_kernel": (lambda: L("xrs_copy_f32", dem.ptr, outs[0].ptr, cells, S), 8),
+        "stream_1r2w": (lambda: L("xrs_stream_mix_f32", dem.ptr, ptr7, 2, cells, S), 12),
+        "stream_1r3w": (lambda: L("xrs_stream_mix_f32", dem.ptr, ptr7, 3, cells, S), 16),
+        "stream_1r4w": (lambda: L("xrs_stream_mix_f32", dem.ptr, ptr7, 4, cells, S), 20),
+        "stream_1r7w": (lambda: L("xrs_stream_mix_f32", dem.ptr, ptr7, 7, cells, S), 32),
         "hillshade": (lambda: L("xrs_hillshade_f32", dem.ptr, outs[0].ptr, 0, n, n, n, n, 225.0, 25.0, 0, 0, S), 8),
         "hillshade_f64out": (lambda: L("xrs_hillshade_f32", dem.ptr, out64.ptr, 1, n, n, n, n, 225.0, 25.0, 0, 0, S), 12),
         "slope": (lambda: L("xrs_slope_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 1.0, 0, 0, S), 8),

@@ -43,6 +43,7 @@ _PROTOTYPES = {
     "xrs_memcpy_d2d": [c_void_p, c_void_p, c_size_t, c_void_p],
     "xrs_memset": [c_void_p, c_int, c_size_t, c_void_p],
     "xrs_copy_f32": [c_void_p, c_void_p, c_int64, c_void_p],
+    "xrs_stream_mix_f32": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "xrs_copy2d": [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int64, c_void_p],
     "xrs_match_bbox": [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrs_nan_minmax_f32": [c_void_p, c_int64, c_void_p, c_void_p],

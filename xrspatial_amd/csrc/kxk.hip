@@ -396,12 +396,39 @@ __device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_
 
     float *out = a.out[XRS_STAT_MEAN] + y0 * a.ld_out + x_tile;      // scalar
     if (!CAREFUL) {
-        // float32 on values shifted by the lane's centre cell (strip.h: strip_mean_f32, shared with the fused pass so that
-        // both produce the same bits); false -> the caller re-runs this strip through the float64 NaN-aware body
-        float m[RB][4];
-        if (!strip_mean_f32<KH, KW, RB, CMASK>(v, a.mask_rows, (float)a.inv_ntaps, m)) return false;
+        double acc[RB][4];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) store_f4u(out + r * a.ld_out + loff, m[r][0], m[r][1], m[r][2], m[r][3]);
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+#pragma unroll
+        for (int ir = 0; ir < NR; ++ir) {
+            double d[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
+                    }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
+        if (__any(bad)) return false;          // caller re-runs this strip through the NaN-aware body
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            store_f4u(out + r * a.ld_out + loff, (float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                      (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
         return true;
     }
     // edge / NaN body
@@ -908,20 +935,15 @@ int launch_mean_fast(const KxkArgs &a, size_t lds, hipStream_t s) {
 template <int KH, int KW, int RB>
 int launch_mean_direct_rb(KxkArgs a, hipStream_t s) {
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
-    // The common masks as compile-time constants (straight-line tap walk, no per-tap select): np.ones((3, 3)),
-    // circle_kernel(1, 1, 2).  (With float64 accumulators the 5x5 specialisations spilled at the 128-register budget --
-    // profiles/r01/cmask2_ab_r01.log; the float32 sums of strip_mean_f32 need half the registers.  np.ones((5, 5)) as a
-    // constant still spills -- its NaN-aware float64 body walks 25 taps -- and keeps the run-time weights.)
-    constexpr bool SPECIALISE = KH == KW && (KH == 3 || KH == 5) && RB == 4;
-    constexpr unsigned BOX = (SPECIALISE && KH == 3) ? (1u << (KH * KW)) - 1u : 0u;
-    constexpr unsigned CIRCLE5 = (SPECIALISE && KH == 5) ? (4u | 14u << 5 | 31u << 10 | 14u << 15 | 4u << 20) : 0u;
+    // np.ones((3, 3)) as a compile-time mask: 0.41 -> 0.37 ms.  (The same for the 5x5 masks made the stand-alone kernel
+    // spill at its 128-register budget -- 0.42 -> 1.80 ms -- so they keep the run-time mask; profiles/r01/cmask2_ab_r01.log.)
+    constexpr bool SPECIALISE = KH == 3 && KW == 3 && RB == 4;
+    constexpr unsigned BOX = SPECIALISE ? (1u << (KH * KW)) - 1u : 0u;
     unsigned mask = 0;
     for (int ky = 0; ky < KH; ++ky) mask |= (unsigned)a.mask_rows[ky] << (ky * KW);
     const dim3 grid((unsigned)xcd_grid(a.n_tiles));
-    if (SPECIALISE && KH == 3 && mask == BOX)
+    if (SPECIALISE && mask == BOX)
         hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB, BOX>), grid, dim3(256), 0, s, a);
-    else if (SPECIALISE && KH == 5 && mask == CIRCLE5)
-        hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB, CIRCLE5>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB>), grid, dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();

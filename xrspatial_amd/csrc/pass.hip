@@ -11,8 +11,8 @@
 // the stand-alone kernels (strip.h) already holds a superset of the 3x3 neighbourhood when it holds the 5x5
 // one -- so the fused kernel reads each cell once (4 B) and writes 4 B per product: 12 B per cell for
 // hillshade + focal mean, 16 B for hillshade + slope + focal mean (the 65536^2 target pipeline, 24 B unfused).
-// Arithmetic is the stand-alone kernels' (terrain_cells.h; strip.h strip_mean_f32 as in focal_mean_direct_kernel):
-// results are bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
+// Arithmetic is the stand-alone kernels' (terrain_cells.h, focal_mean_direct_kernel): results are
+// bit-identical to separate launches, which tests/test_gpu_parity.py asserts.
 //
 // Any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane).  Masks larger than 5x5 run as
 // the separate launches -- same results, no fusion.
@@ -105,16 +105,47 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
         }
     }
 
-    // ---- focal mean (interior, finite, clustered values: float32 sums of shifted values; otherwise float64 accumulation
-    // in row-major tap order == numba nanmean over the window)
+    // ---- focal mean (float64 accumulation in row-major tap order == numba nanmean over the window).  (Round 2 tried
+    // float32 sums of values shifted by the lane's centre cell: half the VALU cycles, no spills -- and the same 0.57 ms,
+    // because this kernel runs at the streaming ceiling of its 1-read / 2-write traffic mix (experiments/rw_mix.hip); the
+    // float64 sums keep results independent of how a raster is cut into strips, bands or shards.)
     float *fout = a.focal + y0 * a.ld_out + x_tile;
     if (!CAREFUL) {
-        // float32 on values shifted by the lane's centre cell (strip.h: strip_mean_f32); false -> the caller re-runs the
-        // focal part through the float64 NaN-aware body below
-        float m[RB][4];
-        if (!strip_mean_f32<KH, KW, RB, CMASK>(v, a.mask_rows, (float)a.inv_ntaps, m)) return false;
+        double acc[RB][4];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) put4<NT>(fout + r * a.ld_out + loff, m[r]);
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
+#pragma unroll
+        for (int ir = 0; ir < NR; ++ir) {
+            double d[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int orow = ir - ky;
+                if (orow < 0 || orow >= RB) continue;
+                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : a.mask_rows[ky];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    if (bits >> kx & 1u) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
+                    }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
+        if (__any(bad)) return false;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float m[4] = {(float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
+                                (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)};
+            put4<NT>(fout + r * a.ld_out + loff, m);
+        }
     } else {
         // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
         // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
@@ -217,13 +248,16 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     return 0;
 }
 
-// Instantiated product sets.  The focal mean fuses well with hillshade / slope / curvature (measured on
-// 16384^2: hillshade+focal 0.61 ms vs 0.82 ms as two launches, hillshade+slope+focal 0.95 vs 1.31); aspect's
-// atan2 on top of the float64 window sums makes the fused kernel VALU-bound, so aspect is left to terrain.hip.
-constexpr int FUSABLE = OP_SLOPE | OP_CURV | OP_HILL;
+// Instantiated product sets.  The focal mean fuses well with every terrain product (measured on 16384^2:
+// hillshade+focal 0.57 ms vs 0.79 ms as two launches, hillshade+slope+focal 0.84 vs 1.19).  Round 1 left aspect to
+// terrain.hip (its library atan2 on top of float64 Horn sums made the fused kernel VALU-bound); with the float32 Horn
+// sums and atan2_fast of terrain_cells.h it rides along: any set with aspect takes the all-four instantiation (absent
+// products skipped by wave-uniform tests).
+constexpr int FUSABLE = OP_SLOPE | OP_ASPECT | OP_CURV | OP_HILL;
 
 template <int K>
 int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
+    if (ops & OP_ASPECT) return launch_pass<FUSABLE, K>(a, s);
     switch (ops) {
         case OP_HILL: return launch_pass<OP_HILL, K>(a, s);
         case OP_SLOPE: return launch_pass<OP_SLOPE | OP_HILL, K>(a, s);     // (absent hillshade skipped by a wave-uniform test;

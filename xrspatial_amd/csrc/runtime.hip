@@ -22,6 +22,26 @@ __global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, floa
         if (base + 64 * u < n4) stg_stream(dst + base + 64 * u, v[u]);
 }
 
+// The same streaming pattern with ONE plane read and NW planes written: the ceiling for a fused kernel's traffic mix.
+// HBM3E sustains less on write-heavier mixes than on a 1:1 copy (measured, experiments/rw_mix.hip: 6.36 TB/s 1R1W,
+// 5.87 TB/s 1R2W, 5.5 TB/s 1R3W, 5.9 TB/s 1R7W), so a fused pass is compared with the ceiling of ITS mix.
+struct MixArgs { const float4 *src; float4 *dst[8]; long n4, n_chunks; };
+template <int NW>
+__global__ void __launch_bounds__(256) stream_mix_kernel(const MixArgs a) {
+    const long chunk = xcd_tile(blockIdx.x, a.n_chunks);
+    if (chunk < 0) return;
+    const long base = chunk * 1024 + (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + 64 * u < a.n4) v[u] = ldg_stream(a.src + base + 64 * u);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + 64 * u < a.n4) stg_stream(a.dst[w] + base + 64 * u, v[u]);
+}
+
 // `.astype(np.float32)` of the reference's wrappers (e.g. xrspatial/slope.py:82, multispectral.py:834) done in
 // HBM: the host sends the raster in its own dtype (int16 DEMs: half the PCIe bytes of float32) and this kernel
 // converts -- round-to-nearest-even, like NumPy.  Four elements per thread, grid-stride.
@@ -80,6 +100,36 @@ int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream) 
     const long n4 = n >> 2, n_chunks = (n4 + 1023) / 1024;
     hipLaunchKernelGGL(copy_chunk_kernel, dim3((unsigned)xcd_grid(n_chunks)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(src_dev), reinterpret_cast<float4 *>(dst_dev), n4, n_chunks);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int xrs_stream_mix_f32(const float *src_dev, float *const *dsts_dev, int n_dst, int64_t n, void *stream) {
+    if (n < 0 || n_dst < 1 || n_dst > 8) return fail("xrs_stream_mix_f32: 1..8 destination planes");
+    if (n == 0) return 0;
+    if (!src_dev || !dsts_dev) return fail("xrs_stream_mix_f32: null pointer");
+    MixArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = reinterpret_cast<const float4 *>(src_dev);
+    for (int i = 0; i < n_dst; ++i) {
+        if (!dsts_dev[i] || !aligned16(dsts_dev[i])) return fail("xrs_stream_mix_f32: destination %d null or not 16-byte aligned", i);
+        a.dst[i] = reinterpret_cast<float4 *>(dsts_dev[i]);
+    }
+    if (!aligned16(src_dev) || (n & 3)) return fail("xrs_stream_mix_f32: planes must be 16-byte aligned with a multiple of 4 elements");
+    a.n4 = n >> 2;
+    a.n_chunks = (a.n4 + 1023) / 1024;
+    const dim3 grid((unsigned)xcd_grid(a.n_chunks));
+    hipStream_t s = as_stream(stream);
+    switch (n_dst) {
+        case 1: hipLaunchKernelGGL(stream_mix_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(stream_mix_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(stream_mix_kernel<3>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(stream_mix_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(stream_mix_kernel<5>, grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(stream_mix_kernel<6>, grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(stream_mix_kernel<7>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(stream_mix_kernel<8>, grid, dim3(256), 0, s, a); break;
+    }
     XRS_LAUNCH_CHECK();
     return 0;
 }

@@ -92,82 +92,6 @@ __device__ __forceinline__ void load_strip(const Args &a, long x_tile, long y0, 
     }
 }
 
-// Focal mean of an interior strip in float32 on SHIFTED values: d = v - c with c the lane's own centre cell, window sums
-// of d in the tap order of the float64 path, mean = c + S / n.  The reference (numba nanmean over the gathered window,
-// xrspatial/focal.py:226-228) accumulates in float64; with n <= 25 taps the float32 sum of shifted values is off by at
-// most (n - 1) * 2^-24 * max|d| on the mean, and the guard max|d| <= 0.8 |c| (=> max|d| <= 4 |mean|) keeps that below
-// 1e-5 relative; typical errors are ~1e-8.  Returns false -- the caller redoes the strip with the float64 NaN-aware body --
-// when a window holds a NaN / inf or the values are not clustered around c (rasters straddling zero).
-// `v` is overwritten with the shifted values.  CMASK / mask_rows as in the float64 bodies.
-template <int KH, int KW, int RB, unsigned CMASK, typename MaskT>
-__device__ __forceinline__ bool strip_mean_f32(float (&v)[RB + KH - 1][4 + 2 * (KW / 2)], const MaskT *mask_rows,
-                                               float inv_ntaps, float (&m)[RB][4]) {
-    constexpr int NV = 4 + 2 * (KW / 2), NR = RB + KH - 1;
-    const float c = v[NR / 2][NV / 2];
-    float amax = 0.0f;
-#pragma unroll
-    for (int ir = 0; ir < NR; ++ir) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[ir][i] -= c;
-#pragma unroll
-        for (int i = 0; i + 1 < NV; i += 2) amax = amax3(amax, v[ir][i], v[ir][i + 1]);
-        if (NV & 1) amax = amax3(amax, v[ir][NV - 1], 0.0f);
-    }
-    float acc[RB][4];
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[r][o] = 0.0f;
-    if (CMASK) {
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (CMASK >> (ky * KW + kx) & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[orow][o] += v[ir][kx + o];
-                    }
-            }
-        }
-    } else {
-        // run-time mask: taps as 0 / 1 weights in scalar registers, one fma per window cell (a per-tap select costs two
-        // instructions; a non-finite cell outside the mask turns the sum NaN and sends the strip to the float64 body)
-        float w[KH][KW];
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) w[ky][kx] = ((unsigned)mask_rows[ky] >> kx & 1u) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[orow][o] = fmaf(w[ky][kx], v[ir][kx + o], acc[orow][o]);
-                }
-            }
-        }
-    }
-    bool bad = !(amax <= 0.8f * fabsf(c));            // (false for a NaN / inf centre too)
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) bad |= isnan(acc[r][o]);
-    if (__any(bad)) return false;
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) m[r][o] = fmaf(acc[r][o], inv_ntaps, c);
-    return true;
-}
-
 template <int KH, int KW, int RB, typename Args>
 __device__ __forceinline__ bool strip_is_interior(const Args &a, long x_tile, long y0) {
     return x_tile >= 4 && x_tile + 256 + 4 <= a.cols && y0 - KH / 2 >= -(long)a.halo_top &&

@@ -169,6 +169,7 @@ def test_file_rendezvous_ignores_stale_files(tmp_path):
             fh.write(b"stale-token-%d" % r)
     fresh = bytes(range(128))
     got, errs = [None] * world, []
+    joined = threading.Barrier(world)          # stands for ncclCommInitRank: returns once every rank has joined
 
     def run(rank):
         try:
@@ -176,7 +177,7 @@ def test_file_rendezvous_ignores_stale_files(tmp_path):
                 time.sleep(0.15 * rank)                            # ranks arrive at different times
             ident, finish = rendezvous_id(path, world, rank, lambda: fresh, timeout=20)
             got[rank] = ident
-            time.sleep(0.3)                                        # (stands for ncclCommInitRank)
+            joined.wait(25)
             finish()
         except Exception as exc:                                   # noqa: BLE001
             errs.append(repr(exc))

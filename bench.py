@@ -671,7 +671,7 @@ def run_zonal32k(ctx, steps=None, warmup=None, brief=False):
 
     def step():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, stream)
-        L("xrs_zonal_partials_f32", zones.ptr, vals.ptr, rows * cols, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, stream)
+        L("xrs_zonal_partials_f32", zones.ptr, vals.ptr, rows * cols, nz, 0.0, 0, 0.0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, stream)
         if world > 1:
             ctx.zonal_allreduce(zc, zs, zq, zmn, zmx, nz)
 

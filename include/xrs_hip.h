@@ -215,14 +215,17 @@ int xrs_hotspots_classify_f32(const float *mean_array_dev, signed char *out_dev,
  * count (integer-exact), sum and sum of squares (float64), min, max.  Cells with
  * zone index < 0 or >= n_zones, non-finite values, and values == nodata (when
  * has_nodata) are skipped.  The five output arrays (n_zones entries each) are
- * ACCUMULATED into: initialise them with xrs_zonal_init().  These partials are
+ * ACCUMULATED into: initialise them with xrs_zonal_init().  sum / sumsq hold the sums of
+ * (x - shift) and (x - shift)^2 for the caller's `shift` (any value near the data: mean = shift + sum / n,
+ * var = (sumsq - sum^2 / n) / n then stays well conditioned for rasters with a large offset and a small
+ * spread; 0 gives the plain sums).  These partials are
  * the per-block statistics of the reference's dask path (_DASK_BLOCK_STATS,
  * xrspatial/zonal.py:83-89) from which mean/std/var follow (:100-102); the
  * NumPy path they replace is _stats_numpy (:280-332). */
 int xrs_zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                    float *min_dev, float *max_dev, int n_zones, void *stream);
 int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n,
-                           int n_zones, float nodata, int has_nodata,
+                           int n_zones, float nodata, int has_nodata, double shift,
                            uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                            float *min_dev, float *max_dev, void *stream);
 /* Same reduction straight from the RAW int32 zone raster: `lut_dev[id - zone_min]` (zone_range entries, built from
@@ -230,11 +233,11 @@ int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev,
  * window belong to no zone.  Saves materialising the dense index raster (4 B written + 4 B read per cell) when only
  * the partial-sum statistics are wanted (np.unique(zones) + per-zone masks in the reference, zonal.py:290-311). */
 int xrs_zonal_partials_lut_f32(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
-                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata,
+                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata, double shift,
                                uint64_t *count_dev, double *sum_dev, double *sumsq_dev, float *min_dev, float *max_dev,
                                void *stream);
 int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
-                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata,
+                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata, double shift,
                                uint64_t *count_dev, double *sum_dev, double *sumsq_dev, double *min_dev, double *max_dev,
                                void *stream);
 /* float64 values (the reference does not cast `values`: float64 and integer rasters keep
@@ -242,7 +245,7 @@ int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32
 int xrs_zonal_init_f64(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                        double *min_dev, double *max_dev, int n_zones, void *stream);
 int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n,
-                           int n_zones, double nodata, int has_nodata,
+                           int n_zones, double nodata, int has_nodata, double shift,
                            uint64_t *count_dev, double *sum_dev, double *sumsq_dev,
                            double *min_dev, double *max_dev, void *stream);
 

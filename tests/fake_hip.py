@@ -69,13 +69,13 @@ def call(name, *a):
         for i in range(int(a[2])):
             ctypes.memmove(_host_ptr(a[1][i]), _host_ptr(a[0]), int(a[3]) * 4)
     elif name == "xrs_zonal_partials_f32":
-        z, vals, n, nz, nodata, has_nodata, cnt, s1, s2, mn, mx, _ = a
+        z, vals, n, nz, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, _ = a
         idx = _arr(z, n, np.int32)
         v = _arr(vals, n, np.float32)
         ok = (idx >= 0) & (idx < nz) & np.isfinite(v)
         if has_nodata:
             ok &= v != np.float32(nodata)
-        v64 = v[ok].astype(np.float64)
+        v64 = v[ok].astype(np.float64) - shift
         _arr(cnt, nz, np.uint64)[...] += np.bincount(idx[ok], minlength=nz).astype(np.uint64)
         _arr(s1, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64, minlength=nz)
         _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
@@ -166,7 +166,7 @@ def call(name, *a):
         _arr(mn, nz, vt)[...] = np.inf
         _arr(mx, nz, vt)[...] = -np.inf
     elif name in ("xrs_zonal_partials_lut_f32", "xrs_zonal_partials_lut_f64"):
-        z, zmin, rng, lut, vals, n, nz, nodata, has_nodata, cnt, s1, s2, mn, mx, _ = a
+        z, zmin, rng, lut, vals, n, nz, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, _ = a
         vt = np.float64 if name.endswith("f64") else np.float32
         off = _arr(z, n, np.int32).astype(np.int64) - zmin
         inside = (off >= 0) & (off < rng)
@@ -175,7 +175,7 @@ def call(name, *a):
         ok = (idx >= 0) & np.isfinite(v)
         if has_nodata:
             ok &= v != vt(nodata)
-        v64 = v[ok].astype(np.float64)
+        v64 = v[ok].astype(np.float64) - shift
         _arr(cnt, nz, np.uint64)[...] += np.bincount(idx[ok], minlength=nz).astype(np.uint64)
         _arr(s1, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64, minlength=nz)
         _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)

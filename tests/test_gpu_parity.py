@@ -560,6 +560,25 @@ def test_zonal_vs_oracle(scatter, vdtype):
         np.testing.assert_allclose(df[col].to_numpy(), want[col], rtol=RTOL, err_msg=col)
 
 
+def test_zonal_large_offset_small_spread():
+    """Zones whose values sit at 3.0e5 +- 0.05 (float32) / 1e7 +- 1e-3 (float64): the one-pass variance of the partial
+    sums cancels in proportion to (mean / std)^2 ~ 1e13 .. 1e20 unless the moments are taken about a shift near the data
+    (xrs_zonal_partials_*: sums of x - shift).  Against the oracle's two-pass NumPy variance."""
+    rng = np.random.default_rng(8)
+    zones = synth.block_zones(300, 400, n_zones=12, block=23)
+    for dtype, base, spread, tol in ((np.float32, 3.0e5, 0.05, 2e-5), (np.float64, 1.0e7, 1e-3, 1e-6)):
+        vals = (base + rng.normal(0, spread, zones.shape)).astype(dtype)
+        vals[rng.random(vals.shape) < 0.01] = np.nan
+        names = ['mean', 'sum', 'std', 'var', 'count']
+        df = xs.zonal_stats(raster(zones), raster(vals), stats_funcs=names)
+        want = orc.zonal_stats(zones, vals.astype(np.float64), stats_funcs=names)
+        np.testing.assert_array_equal(df['count'].to_numpy(), want['count'])
+        np.testing.assert_allclose(df['mean'].to_numpy(), want['mean'], rtol=1e-12)
+        np.testing.assert_allclose(df['sum'].to_numpy(), want['sum'], rtol=1e-12)
+        np.testing.assert_allclose(df['var'].to_numpy(), want['var'], rtol=tol, err_msg=str(dtype))
+        np.testing.assert_allclose(df['std'].to_numpy(), want['std'], rtol=tol, err_msg=str(dtype))
+
+
 def test_zonal_majority_and_dataarray(golden, golden_tables):
     # majority ties -> smallest value (test_zonal.py:567-590)
     z = np.array([[1, 1, 1, 1], [1, 1, 2, 2], [2, 2, 2, 2]])
@@ -1159,8 +1178,8 @@ def test_rccl_plumbing_single_gpu():
     a = zonal_partials(z, v, 5)
     b = zonal_partials(z, v, 5, comm=comm)
     for i, (x, y) in enumerate(zip(a, b)):
-        if i in (1, 2):      # float64 sums: atomic arrival order differs run to run at the 1e-16 level
-            np.testing.assert_allclose(x, y, rtol=1e-12)
+        if i in (1, 2):      # float64 sums (of x - shift): atomic arrival order differs run to run at the 1e-16 level
+            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12)
         else:                # count, min, max: exact
             np.testing.assert_array_equal(x, y)
     # the generic control-plane reduce rides on the same collective; float64 planes travel as 4-byte words
@@ -1319,6 +1338,27 @@ def test_geodesic_slope_aspect(dtype, backend):
                                                            'lon': xs.DataArray(LON, dims=['y', 'x'])})
     np.testing.assert_allclose(host(xs.slope(agg2, method='geodesic').data), orc.geodesic_slope(elev, LAT, LON),
                                rtol=RTOL, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("backend", ["numpy", "hip"])
+def test_geodesic_closed_form(backend):
+    """The HIP geodesic kernels against surfaces whose slope / aspect are known in closed form (the analytic pin of the
+    geodesic oracle, tests/test_oracle_golden.py::test_geodesic_oracle_matches_closed_form), 1-D and 2-D coordinates."""
+    from tests.test_oracle_golden import GEO_CASES, _analytic_geodesic_case
+    for lat0, g_north, g_east in GEO_CASES:
+        elev, LAT, LON, slope, aspect = _analytic_geodesic_case(lat0, g_north, g_east, shape=(33, 70))
+        for two_d in (False, True):
+            data = xs.DeviceArray.from_numpy(elev.astype(np.float32)) if backend == 'hip' else elev.astype(np.float32)
+            if two_d:
+                agg = xs.DataArray(data, dims=['y', 'x'], coords={'lat': xs.DataArray(LAT, dims=['y', 'x']),
+                                                                  'lon': xs.DataArray(LON, dims=['y', 'x'])})
+            else:
+                agg = xs.DataArray(data, dims=['lat', 'lon'], coords={'lat': LAT[:, 0], 'lon': LON[0, :]})
+            got_s = host(xs.slope(agg, method='geodesic').data)[16, 35]
+            got_a = host(xs.aspect(agg, method='geodesic').data)[16, 35]
+            np.testing.assert_allclose(got_s, slope, rtol=2e-3, err_msg=f"{lat0} {g_north} {g_east} 2d={two_d}")   # float32 elevations
+            assert abs((got_a - aspect + 180.0) % 360.0 - 180.0) < 0.1, (lat0, g_north, g_east, got_a, aspect)
+            parity_log.record("f3 geodesic: closed-form surfaces on WGS84 (analytic pin)", "slope", got_s, slope, tol="rtol 2e-3 (float32 elevations at 1 arc-second)")
 
 
 def test_geodesic_properties_and_validation():

@@ -224,6 +224,22 @@ def test_finalize_stats_from_partials():
         np.testing.assert_allclose(out['std'][k], v[z == k].std(), rtol=1e-9)
         assert out['count'][k] == count[k] and out['max'][k] == mx[k] and out['min'][k] == mn[k]
 
+    # shifted moments: a raster with a large offset and a small spread (1e6 +- 1e-2).  The unshifted one-pass variance
+    # loses ~12 of 16 digits; with the shift it keeps them (zonal.finalize_stats(..., shift))
+    w = 1.0e6 + rng.normal(0, 1e-2, v.shape)
+    shift = float(w.flat[7])
+    d = w - shift
+    cnt = np.array([(z == k).sum() for k in range(4)], dtype=np.int64)
+    sh = zonal.finalize_stats(['mean', 'sum', 'var', 'std'], cnt, np.array([d[z == k].sum() for k in range(4)]),
+                              np.array([(d[z == k] ** 2).sum() for k in range(4)]), mn, mx, None, shift)
+    plain = zonal.finalize_stats(['var'], cnt, np.array([w[z == k].sum() for k in range(4)]),
+                                 np.array([(w[z == k] ** 2).sum() for k in range(4)]), mn, mx)
+    for k in range(4):
+        np.testing.assert_allclose(sh['var'][k], w[z == k].var(), rtol=1e-9)
+        np.testing.assert_allclose(sh['mean'][k], w[z == k].mean(), rtol=1e-15)
+        np.testing.assert_allclose(sh['sum'][k], w[z == k].sum(), rtol=1e-14)
+    assert max(abs(plain['var'][k] / w[z == k].var() - 1) for k in range(4)) > 1e-6      # what the shift is for
+
     # the same partials split over two row shards combine to the same moments (row e1 of SURVEY 8e)
     halves = []
     for rows in (slice(0, 17), slice(17, 40)):

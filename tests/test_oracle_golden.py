@@ -300,3 +300,54 @@ def test_true_color_properties():
     assert out[2, 3, 3] == 0 and out[4, 5, 3] == 0 and (np.delete(out[..., 3].ravel(), [2 * 17 + 3, 4 * 17 + 5]) == 255).all()
     order = np.argsort(b.ravel(), kind='stable')
     assert (np.diff(out[..., 2].ravel()[order].astype(int)) >= 0).all()
+
+
+# ---------------------------------------------------------------- geodesic slope / aspect: an analytic pin
+def _analytic_geodesic_case(lat0_deg, g_north, g_east, h0=350.0, cell_arcsec=1.0, shape=(9, 11)):
+    """Elevations that vary LINEARLY with latitude and longitude around (lat0, 10 E) on the WGS84 ellipsoid:
+        h = h0 + g_north * (M + h0) * dphi + g_east * (N + h0) * cos(phi0) * dlambda
+    (M, N: meridional / prime-vertical radii of curvature).  (M + h0) dphi and (N + h0) cos(phi0) dlambda are the local
+    northing / easting in metres, so the surface has gradient (g_east, g_north) in the tangent plane of its centre cell:
+        slope = atan(hypot(g_east, g_north)),  aspect = compass bearing of steepest DESCENT = atan2(-g_east, -g_north).
+    The reference's sphere-flattening term (e^2 + n^2) / 2R is symmetric and drops out of a centred plane fit; what is
+    left are O(cell size) effects (the rows' differing cos(phi)): ~1e-5 relative at 1 arc-second."""
+    a, b = 6378137.0, 6356752.314245
+    phi0 = np.deg2rad(lat0_deg)
+    w = np.sqrt(a * a * np.cos(phi0) ** 2 + b * b * np.sin(phi0) ** 2)
+    N = a * a / w
+    M = a * a * b * b / w ** 3
+    step = np.deg2rad(cell_arcsec / 3600.0)
+    H, W = shape
+    dphi = -(np.arange(H) - H // 2) * step                   # row 0 is the northernmost (descending latitude)
+    dlam = (np.arange(W) - W // 2) * step
+    LAT = np.rad2deg(phi0 + dphi)[:, None] * np.ones((1, W))
+    LON = (10.0 + np.rad2deg(dlam))[None, :] * np.ones((H, 1))
+    elev = h0 + g_north * (M + h0) * dphi[:, None] + g_east * (N + h0) * np.cos(phi0) * dlam[None, :]
+    slope = np.degrees(np.arctan(np.hypot(g_east, g_north)))
+    aspect = np.degrees(np.arctan2(-g_east, -g_north)) % 360.0
+    return elev, LAT, LON, slope, aspect
+
+
+GEO_CASES = [(0.0, 0.05, 0.0), (45.0, 0.0, 0.08), (45.0, 0.03, -0.04), (-33.0, -0.2, 0.1), (60.0, 0.5, 0.5), (78.0, -0.01, -0.02)]
+
+
+@pytest.mark.parametrize("lat0,g_north,g_east", GEO_CASES)
+def test_geodesic_oracle_matches_closed_form(lat0, g_north, g_east):
+    """Pins the geodesic part of the oracle (xrspatial/geodesic.py:40-229 restated), for which the reference's tests hold
+    properties only: ECEF conversion on WGS84, the East / North / Up frame and its signs, the centred plane fit and the
+    slope / aspect conventions must reproduce a surface whose tangent-plane gradient is known in closed form."""
+    elev, LAT, LON, slope, aspect = _analytic_geodesic_case(lat0, g_north, g_east)
+    got_s = orc.geodesic_slope(elev, LAT, LON)[4, 5]
+    got_a = orc.geodesic_aspect(elev, LAT, LON)[4, 5]
+    np.testing.assert_allclose(got_s, slope, rtol=1e-4)
+    assert abs((got_a - aspect + 180.0) % 360.0 - 180.0) < 0.01, (got_a, aspect)
+    # float32 elevations (what the device path is fed) stay within the same bar at this relief
+    got32 = orc.geodesic_slope(elev.astype(np.float32), LAT, LON)[4, 5]
+    np.testing.assert_allclose(got32, slope, rtol=2e-3)
+
+
+def test_geodesic_oracle_level_surface_is_flat():
+    """A surface of constant elevation follows the ellipsoid: slope 0 (the reference's curvature term), aspect -1."""
+    elev, LAT, LON, _, _ = _analytic_geodesic_case(37.0, 0.0, 0.0, h0=1200.0, cell_arcsec=3.0)
+    s = orc.geodesic_slope(elev, LAT, LON)[1:-1, 1:-1]
+    assert np.all(s < 2e-3)                       # degrees; the WGS84 / mean-sphere mismatch of the correction is what is left

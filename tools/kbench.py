@@ -130,7 +130,7 @@ def main():
 
     def zonal():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
-        L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
+        L("xrs_zonal_partials_f32", zones.ptr, dem.ptr, cells, nz, 0.0, 0, 0.0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
 
     xt = xs.DeviceArray((1000 * 32,), np.uint64)
     cats = zones64 = cats8 = small
@@ -169,11 +169,11 @@ def main():
 
     def zonal5k():
         L("xrs_zonal_init", z5c.ptr, z5s.ptr, z5q.ptr, z5mn.ptr, z5mx.ptr, 5000, S)
-        L("xrs_zonal_partials_f32", zones5k.ptr, dem.ptr, cells, 5000, 0.0, 0, z5c.ptr, z5s.ptr, z5q.ptr, z5mn.ptr, z5mx.ptr, S)
+        L("xrs_zonal_partials_f32", zones5k.ptr, dem.ptr, cells, 5000, 0.0, 0, 0.0, z5c.ptr, z5s.ptr, z5q.ptr, z5mn.ptr, z5mx.ptr, S)
 
     def zonal_scatter():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, S)
-        L("xrs_zonal_partials_f32", zones_sc.ptr, dem.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
+        L("xrs_zonal_partials_f32", zones_sc.ptr, dem.ptr, cells, nz, 0.0, 0, 0.0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, S)
 
     # name -> (callable, algorithmic bytes per cell)
     cases = {

@@ -37,7 +37,7 @@ def main():
 
     def partials():
         L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, None)
-        L("xrs_zonal_partials_f32", zones.ptr, vals.ptr, cells, nz, 0.0, 0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, None)
+        L("xrs_zonal_partials_f32", zones.ptr, vals.ptr, cells, nz, 0.0, 0, 0.0, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, None)
 
     med, mn = Timer().time(partials, 10, warmup=2)
     print(f"zonal partials kernel ({n}x{n}, 1000 zones): {med:.3f} ms = {cells * 8 / med / 1e6:.0f} GB/s, "

@@ -96,14 +96,14 @@ _PROTOTYPES = {
     "xrs_nan_moments_f32": [c_void_p, c_int64, c_void_p, c_void_p],
     "xrs_hotspots_classify_f32": [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p],
     "xrs_zonal_init": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    "xrs_zonal_partials_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
+    "xrs_zonal_partials_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],
-    "xrs_zonal_partials_lut_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
+    "xrs_zonal_partials_lut_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_double, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "xrs_zonal_partials_lut_f64": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p,
+    "xrs_zonal_partials_lut_f64": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_double, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xrs_zonal_init_f64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_void_p,
+    "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],
     "xrs_zonal_scan": [c_void_p, c_int, c_int64, c_void_p, c_void_p],
     "xrs_zonal_scan_presence_i32": [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p],

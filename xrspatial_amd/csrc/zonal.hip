@@ -37,6 +37,7 @@ struct ZonalArgs {
     int nz;
     VT nodata;
     int has_nodata;
+    double shift;                 // sum / sumsq accumulate (x - shift) and (x - shift)^2 (the caller adds it back)
     unsigned long long *count;
     double *sum, *sumsq;
     VT *mn, *mx;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
                 p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
             }
             p.z = z[k];
-            const double d = (double)v[k];
+            const double d = (double)v[k] - a.shift;
             p.c += 1; p.s += d; p.q += d * d;
             p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
         }
@@ -225,7 +226,8 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
         const int z = (a.lut ? zone_of(a, a.zidx[i]) : a.zidx[i]) - a.zbase;
         const VT v = a.vals[i];
         if (cell_ok(a, z, v)) {
-            Part<VT> p; p.z = z; p.c = 1; p.s = (double)v; p.q = (double)v * (double)v; p.mn = v; p.mx = v;
+            const double d = (double)v - a.shift;
+            Part<VT> p; p.z = z; p.c = 1; p.s = d; p.q = d * d; p.mn = v; p.mx = v;
             acc.add(p);
         }
     }
@@ -267,7 +269,7 @@ int zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_
 
 template <typename VT>
 int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n, int n_zones, VT nodata,
-                   int has_nodata, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev,
+                   int has_nodata, double shift, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev,
                    VT *max_dev, void *stream, const int32_t *lut_dev = nullptr, int zmin = 0, int rng = 0) {
     if (n < 0 || n_zones < 0) return fail("xrs_zonal_partials: negative size");
     if (n == 0 || n_zones == 0) return 0;
@@ -277,7 +279,7 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     a.zidx = zone_idx_dev; a.vals = values_dev; a.n = n; a.nz = n_zones;
     a.lut = lut_dev; a.zmin = zmin; a.rng = rng;
     if (lut_dev && rng <= 0) return fail("xrs_zonal_partials_lut: empty id window");
-    a.nodata = nodata; a.has_nodata = has_nodata;
+    a.nodata = nodata; a.has_nodata = has_nodata; a.shift = shift;
     a.count = reinterpret_cast<unsigned long long *>(count_dev);
     a.sum = sum_dev; a.sumsq = sumsq_dev; a.mn = min_dev; a.mx = max_dev;
     const size_t lds_cap = 144 * 1024;                           // of the CU's 160 KiB (one workgroup per CU beyond 64 KiB)
@@ -324,32 +326,32 @@ int xrs_zonal_init_f64(uint64_t *c, double *s, double *q, double *mn, double *mx
     return zonal_init<double>(c, s, q, mn, mx, nz, stream);
 }
 int xrs_zonal_partials_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones,
-                           float nodata, int has_nodata, uint64_t *count_dev, double *sum_dev,
+                           float nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
                            double *sumsq_dev, float *min_dev, float *max_dev, void *stream) {
-    return zonal_partials<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev,
+    return zonal_partials<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, shift, count_dev, sum_dev,
                                  sumsq_dev, min_dev, max_dev, stream);
 }
 int xrs_zonal_partials_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones,
-                           double nodata, int has_nodata, uint64_t *count_dev, double *sum_dev,
+                           double nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
                            double *sumsq_dev, double *min_dev, double *max_dev, void *stream) {
-    return zonal_partials<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev,
+    return zonal_partials<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, shift, count_dev, sum_dev,
                                   sumsq_dev, min_dev, max_dev, stream);
 }
 
 int xrs_zonal_partials_lut_f32(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
-                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata,
+                               const float *values_dev, int64_t n, int n_zones, float nodata, int has_nodata, double shift,
                                uint64_t *count_dev, double *sum_dev, double *sumsq_dev, float *min_dev, float *max_dev,
                                void *stream) {
     if (!lut_dev) return fail("xrs_zonal_partials_lut_f32: null table");
-    return zonal_partials<float>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev, sumsq_dev,
+    return zonal_partials<float>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, shift, count_dev, sum_dev, sumsq_dev,
                                  min_dev, max_dev, stream, lut_dev, zone_min, zone_range);
 }
 int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32_t zone_range, const int32_t *lut_dev,
-                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata,
+                               const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata, double shift,
                                uint64_t *count_dev, double *sum_dev, double *sumsq_dev, double *min_dev, double *max_dev,
                                void *stream) {
     if (!lut_dev) return fail("xrs_zonal_partials_lut_f64: null table");
-    return zonal_partials<double>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, count_dev, sum_dev, sumsq_dev,
+    return zonal_partials<double>(zones_dev, values_dev, n, n_zones, nodata, has_nodata, shift, count_dev, sum_dev, sumsq_dev,
                                   min_dev, max_dev, stream, lut_dev, zone_min, zone_range);
 }
 

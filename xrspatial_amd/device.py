@@ -25,20 +25,37 @@ import numpy as np
 
 from . import _lib
 
-_pool = {}
+_pool = {}                               # nbytes -> [(device pointer, event recorded when the block was freed)]
 _pool_lock = threading.Lock()
 _POOL_MAX_BYTES = 64 << 30
 _pool_bytes = 0
+_spare_events = []
+
+
+def _active_stream():
+    from ._launch import get_stream       # (imported late: _launch imports this module)
+    return get_stream()
 
 
 def _raw_alloc(nbytes: int) -> int:
     global _pool_bytes
     nbytes = max(int(nbytes), 16)
+    entry = None
     with _pool_lock:
         lst = _pool.get(nbytes)
         if lst:
             _pool_bytes -= nbytes
-            return lst.pop()
+            entry = lst.pop()
+    if entry is not None:
+        ptr, ev = entry
+        if ev is not None:
+            # the block was freed while kernels launched on the then-active stream could still be reading it: it may be
+            # handed to ANY stream now (the banded pipeline runs on its own three), so wait for that point of the freeing
+            # stream first -- long past in practice, a few microseconds when it is not
+            _lib.call("xrs_event_sync", ev)
+            with _pool_lock:
+                _spare_events.append(ev)
+        return ptr
     _lib.require_device()
     p = ctypes.c_void_p()
     try:
@@ -53,10 +70,20 @@ def _raw_free(ptr: int, nbytes: int):
     global _pool_bytes
     nbytes = max(int(nbytes), 16)
     with _pool_lock:
-        if _pool_bytes + nbytes <= _POOL_MAX_BYTES:
-            _pool.setdefault(nbytes, []).append(ptr)
+        room = _pool_bytes + nbytes <= _POOL_MAX_BYTES
+        ev = _spare_events.pop() if (room and _spare_events) else None
+    if room:
+        try:
+            if ev is None:
+                ev = ctypes.c_void_p()
+                _lib.call("xrs_event_create", ctypes.byref(ev))
+            _lib.call("xrs_event_record", ev, _active_stream())
+        except Exception:                  # (no device / interpreter shutdown: pool the block without a fence)
+            ev = None
+        with _pool_lock:
+            _pool.setdefault(nbytes, []).append((ptr, ev))
             _pool_bytes += nbytes
-            return
+        return
     _lib.load().xrs_free(ptr)
 
 
@@ -74,7 +101,7 @@ def empty_cache():
         _pinned_pool_bytes = 0
     with _pool_lock:
         for lst in _pool.values():
-            for p in lst:
+            for p, _ev in lst:
                 _lib.load().xrs_free(p)
         _pool.clear()
         _pool_bytes = 0
@@ -82,7 +109,7 @@ def empty_cache():
 
 # ------------------------------------------------------------------ recycled host blocks for results
 _host_pool = {}
-_host_lock = threading.Lock()
+_host_lock = threading.RLock()          # re-entrant: __del__ of a block can run (GC) while the lock is held
 _host_pool_bytes = 0
 _HOST_POOL_MAX_BYTES = int(os.environ.get("XRS_HOST_POOL_MAX_BYTES", 16 << 30))
 _HOST_POOL_MIN_BLOCK = 1 << 20          # smaller results: plain np.empty
@@ -262,7 +289,10 @@ class DeviceArray:
         if np.dtype(dtype) == self.dtype:
             return self
         if np.dtype(dtype) == np.float32 and self.dtype in _CAST_CODE:
-            return _cast_f32_on_device(self, src_is_temporary=False)     # (the caller's array outlives the kernel)
+            # on the ACTIVE stream: the wrappers launch their kernels on _launch.get_stream(), and a non-blocking stream
+            # does not order against the NULL stream the cast would otherwise run on
+            from ._launch import get_stream
+            return _cast_f32_on_device(self, stream=get_stream(), src_is_temporary=False)   # (the caller's array outlives the kernel)
         return DeviceArray.from_numpy(self.get().astype(dtype))
 
     def __repr__(self):
@@ -294,7 +324,8 @@ def to_device_f32(data) -> DeviceArray:
         return data.astype(np.float32)
     host = np.asarray(data)
     if host.dtype != np.float32 and host.dtype in _CAST_CODE and host.size:
-        return _cast_f32_on_device(DeviceArray.from_numpy(host))      # native dtype over PCIe, converted in HBM
+        from ._launch import get_stream
+        return _cast_f32_on_device(DeviceArray.from_numpy(host), stream=get_stream())      # native dtype over PCIe, converted in HBM
     return DeviceArray.from_numpy(host, dtype=np.float32)
 
 

@@ -44,6 +44,16 @@ class PendingResult:
                            "scope closes")
 
     __array__ = get = __getitem__ = __iter__ = _unavailable
+    __array_priority__ = 1000
+    size = property(lambda self: int(np.prod(self.shape, dtype=np.int64)))
+
+    # a duck array for xarray (like DeviceArray): real `xarray.DataArray(PendingResult(...))` must keep the placeholder
+    # wrapped instead of calling np.asarray on it
+    def __array_function__(self, func, types, args, kwargs):
+        return NotImplemented
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return NotImplemented
 
     def __repr__(self):
         return f"<pending fused result {self.shape} {self.dtype}>"

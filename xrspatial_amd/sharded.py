@@ -56,6 +56,15 @@ class ShardedArray:
     size = property(lambda self: self.local.size)
     ptr = property(lambda self: self.local.ptr)
 
+    # duck-array hooks (as on DeviceArray): real xarray keeps objects that define them wrapped instead of np.asarray-ing
+    __array_priority__ = 1000
+
+    def __array_function__(self, func, types, args, kwargs):
+        return NotImplemented
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return NotImplemented
+
     def __repr__(self):
         return f"ShardedArray(rows={self.shape[0]}, cols={self.shape[1]}, dtype={self.dtype}, rank {self.rank}/{self.world})"
 
@@ -142,6 +151,15 @@ class ShardedStack:
     dtype = property(lambda self: self.planes[0].dtype)
     ndim = property(lambda self: 3)
     size = property(lambda self: len(self.planes) * self.planes[0].size)
+
+    # duck-array hooks (as on DeviceArray): real xarray keeps objects that define them wrapped instead of np.asarray-ing
+    __array_priority__ = 1000
+
+    def __array_function__(self, func, types, args, kwargs):
+        return NotImplemented
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return NotImplemented
 
     def __len__(self):
         return len(self.planes)

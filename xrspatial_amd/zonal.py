@@ -141,8 +141,28 @@ def _stage(zone_idx, values):
     return zdev, vdev
 
 
+def _pick_shift(vdev, comm, stream):
+    """A value near the data for the shifted moments (xrs_zonal_partials_*: sums of x - shift and (x - shift)^2): the
+    mean of a few hundred finite cells sampled from three places of the plane; every rank of a sharded run must use the
+    same one, so they take the smallest candidate.  0 when nothing finite was sampled (any value is correct)."""
+    n = int(vdev.size)
+    take = min(256, n)
+    itemsize = vdev.dtype.itemsize
+    sample = np.empty(3 * take, vdev.dtype)
+    for k, start in enumerate((0, max(0, n // 2 - take // 2), max(0, (3 * n) // 4 - take // 2))):
+        start = min(start, n - take)
+        _lib.call("xrs_memcpy_d2h", sample[k * take:(k + 1) * take].ctypes.data, vdev.ptr + start * itemsize, take * itemsize, stream)
+    _lib.call("xrs_stream_sync", stream)
+    good = sample[np.isfinite(sample)]
+    cand = float(np.mean(good, dtype=np.float64)) if good.size else np.inf
+    if comm is not None:
+        cand = float(np.asarray(comm.allreduce(np.array([cand]), 'min')).reshape(-1)[0])
+    return cand if np.isfinite(cand) else 0.0
+
+
 def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, table=None):
-    """Per-zone (count, sum, sumsq, min, max) NumPy arrays for dense `zone_idx` (device or host arrays).
+    """Per-zone (count, sum, sumsq, min, max, shift) for dense `zone_idx` (device or host arrays): NumPy arrays, with
+    sum / sumsq the sums of (x - shift) and (x - shift)^2 (finalize_stats adds the shift back).
 
     `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
     all-reduced over it so every rank returns the global result.
@@ -162,17 +182,18 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     _lib.call("xrs_zonal_init" + sfx, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, n_zones, stream)
     has_nodata = nodata_values is not None
     nodata = float(nodata_values) if has_nodata else 0.0
+    shift = _pick_shift(vdev, comm, stream) if vdev.size else 0.0
     if table is not None:
         zmin, rng, lut_dev = table
         _lib.call("xrs_zonal_partials_lut_f64" if f64 else "xrs_zonal_partials_lut_f32", zdev.ptr, int(zmin), int(rng),
-                  lut_dev.ptr, vdev.ptr, vdev.size, n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr,
+                  lut_dev.ptr, vdev.ptr, vdev.size, n_zones, nodata, int(has_nodata), shift, cnt.ptr, s1.ptr, s2.ptr, mn.ptr,
                   mx.ptr, stream)
     else:
         _lib.call("xrs_zonal_partials_f64" if f64 else "xrs_zonal_partials_f32", zdev.ptr, vdev.ptr, vdev.size,
-                  n_zones, nodata, int(has_nodata), cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
+                  n_zones, nodata, int(has_nodata), shift, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, stream)
     if comm is not None:                 # distributed.Comm (RCCL) or any transport with the same surface
-        return comm.allreduce_zonal(cnt, s1, s2, mn, mx, f64, n_zones, stream)
-    return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream)
+        return tuple(comm.allreduce_zonal(cnt, s1, s2, mn, mx, f64, n_zones, stream)) + (shift,)
+    return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream), shift
 
 
 def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
@@ -191,16 +212,18 @@ def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
     return out.get(stream)
 
 
-def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None):
-    """Per-zone statistics from the partials (formulas of zonal.py:100-102); zones without a valid
-    cell are NaN in every column, count included (zonal.py:153-161 pre-fills NaN)."""
+def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None, shift=0.0):
+    """Per-zone statistics from the partials (formulas of zonal.py:100-102, on moments of x - shift: the one-pass
+    variance sum(d^2) - sum(d)^2 / n cancels in proportion to (mean - shift)^2 / var, so a shift near the data keeps it
+    well conditioned for rasters with a large offset and a small spread); zones without a valid cell are NaN in every
+    column, count included (zonal.py:153-161 pre-fills NaN)."""
     n = count.astype(np.float64)
     empty = count == 0
     with np.errstate(all="ignore"):
-        mean = s1 / n
+        mean = shift + s1 / n
         var = (s2 - s1 * s1 / n) / n
         var = np.where(var < 0, 0.0, var)         # rounding guard; the exact value is >= 0
-    table = {'mean': mean, 'max': mx.astype(np.float64), 'min': mn.astype(np.float64), 'sum': s1,
+    table = {'mean': mean, 'max': mx.astype(np.float64), 'min': mn.astype(np.float64), 'sum': s1 + n * shift,
              'std': np.sqrt(var), 'var': var, 'count': n, 'majority': majority}
     out = {}
     for name in stat_names:
@@ -227,8 +250,8 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
             unique_zones, zmin, rng, lut_dev = tab
             nz = len(unique_zones)
             _, vdev = _stage(zones_data, values_data)
-            count, s1, s2, mn, mx = zonal_partials(zones_data, vdev, nz, nodata_values, comm, table=(zmin, rng, lut_dev))
-            cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None)
+            count, s1, s2, mn, mx, shift = zonal_partials(zones_data, vdev, nz, nodata_values, comm, table=(zmin, rng, lut_dev))
+            cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None, shift)
             if zone_ids is None:
                 keep = np.arange(nz)
             else:
@@ -260,9 +283,9 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
         selected = [z for z in wanted if z in unique_zones]
     nz = len(unique_zones)
     _, vdev = _stage(idx_dev, values_data)
-    count, s1, s2, mn, mx = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
+    count, s1, s2, mn, mx, shift = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
     majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in stat_names else None
-    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, majority)
+    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, majority, shift)
     keep = [i for i, z in enumerate(unique_zones) if z in selected]
     if return_type == 'pandas.DataFrame':
         frame = {'zone': selected}
@@ -322,9 +345,9 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
     unique_zones = (np.flatnonzero(mask).astype(np.float64) + lo).astype(np.int32)
     nz = len(unique_zones)
     vloc = values.local if values.dtype in (np.float32, np.float64) else values.local.astype(np.float64)
-    count, s1, s2, mn, mx = zonal_partials(zloc, vloc, nz, nodata_values, comm if zones.world > 1 else None,
+    count, s1, s2, mn, mx, shift = zonal_partials(zloc, vloc, nz, nodata_values, comm if zones.world > 1 else None,
                                            table=(lo, rng, DeviceArray.from_numpy(lut)))
-    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None)
+    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None, shift)
     keep = np.arange(nz) if zone_ids is None else np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
     frame = {'zone': unique_zones[keep]}
     for name in stat_names:
@@ -461,9 +484,9 @@ def _crosstab_3d(zones_data, values_data, cat_labels, zone_ids, cat_ids, nodata_
         layer = values_data.rows(j, j + 1) if isinstance(values_data, DeviceArray) else values_data[j]
         if isinstance(layer, DeviceArray):
             layer = DeviceArray(layer.shape[1:], layer.dtype, _ptr=layer.ptr, _base=layer)
-        count, s1, s2, mn, mx = zonal_partials(zidx, layer, nz, nodata_values)
+        count, s1, s2, mn, mx, shift = zonal_partials(zidx, layer, nz, nodata_values)
         majority = zonal_majority(zidx, layer, nz, nodata_values) if agg == 'majority' else None
-        col = finalize_stats([agg], count, s1, s2, mn, mx, majority)[agg]
+        col = finalize_stats([agg], count, s1, s2, mn, mx, majority, shift)[agg]
         if agg == 'count':
             col = count.astype(np.int64)
         frame[cat] = col[zrows]

@@ -190,6 +190,13 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
                         const double *kernel, int krows, int kcols, void *work_dev,
                         int halo_top, int halo_bot, void *stream);
 
+/* focal.apply with a user callable (func other than the built-in reducers): the kernel-shaped float32 arrays that
+ * _apply_numpy, xrspatial/focal.py:305-326, builds per cell (NaN, then data[ky, kx] where kernel == 1 and inside the
+ * raster), for the band of rows [y0, y0 + band_rows): windows_dev[band_rows][cols][krows][kcols].  The host calls the
+ * callable on each.  in_dev is the whole raster (rows x cols, pitch ld_in); krows * kcols <= 2048. */
+int xrs_focal_windows_f32(const float *in_dev, float *windows_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                          int64_t y0, int64_t band_rows, const double *kernel, int krows, int kcols, void *stream);
+
 /* focal.mean: fixed 3x3 NaN-skipping mean on a clamped window, float64 out, cells
  * equal to one of `excludes` (NaN matches NaN) are passed through.  One pass;
  * the host loops `passes`.  Replaces _mean_numpy, xrspatial/focal.py:44-67.
@@ -282,6 +289,17 @@ int xrs_zonal_majority_f32(const int32_t *zone_idx_dev, const float *values_dev,
 int xrs_zonal_majority_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones,
                            double nodata, int has_nodata, void *work_dev, size_t work_bytes,
                            double *majority_dev, void *stream);
+/* the valid cells of every zone gathered into one contiguous run, for statistics that are arbitrary host callables
+ * (zonal.stats(stats_funcs={name: callable}): _calc_stats, xrspatial/zonal.py:144-163, slices the argsort-ordered
+ * values per zone and filters non-finite / nodata cells before calling func).  sorted_values_dev[n] receives the cells
+ * ordered by (zone index, value ascending); cells outside [0, n_zones) or with an invalid value come last (as NaN), so
+ * zone z's values are the slice [sum(count[:z]), sum(count[:z+1])) with count from xrs_zonal_partials_*.  Workspace:
+ * xrs_zonal_majority_workspace_bytes(n, n_zones, values_f64).  n < 2^31 cells per call. */
+int xrs_zonal_group_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones, float nodata,
+                        int has_nodata, void *work_dev, size_t work_bytes, float *sorted_values_dev, void *stream);
+int xrs_zonal_group_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones, double nodata,
+                        int has_nodata, void *work_dev, size_t work_bytes, double *sorted_values_dev, void *stream);
+
 /* return_type='xarray.DataArray' of zonal.stats (xrspatial/zonal.py:313-332): out[s][cell] =
  * table[s][zone_idx[cell]] (row-major n_stats x n_zones float64 table), NaN where the cell has no zone. */
 int xrs_zonal_backproject_f64(const int32_t *zone_idx_dev, int64_t n, const double *table_dev, int n_stats,

@@ -513,8 +513,8 @@ def test_focal_all_nan_window_and_device_backend():
     dev = focal_stats(raster(z, backend='hip'), k)
     assert isinstance(dev.data, xs.DeviceArray) and dev.shape == (7, 40, 256)
     np.testing.assert_allclose(dev.data.get(), orc.focal_stats(z, k), rtol=1e-6, atol=1e-9, equal_nan=True)
-    with pytest.raises(NotImplementedError):
-        apply(raster(z), k, func=lambda w: 0)
+    with pytest.raises(TypeError):
+        apply(raster(z), k, func=42)                              # neither a built-in reducer nor a callable
     with pytest.raises(ValueError):
         apply(raster(z), np.ones((4, 6)))
     with pytest.raises(TypeError):
@@ -605,8 +605,111 @@ def test_zonal_majority_and_dataarray(golden, golden_tables):
         want = orc.zonal_stats(zz, vv, stats_funcs=['majority', 'count'], nodata_values=3)
         np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'])
         np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
-    with pytest.raises(NotImplementedError):
-        xs.zonal_stats(zones, values, stats_funcs={'double_sum': lambda a: a.sum() * 2})
+    with pytest.raises(ValueError):
+        xs.zonal_stats(zones, values, stats_funcs={'double_sum': 'not callable'})
+
+
+def test_zonal_custom_callables(golden, golden_tables):
+    """stats_funcs={name: callable} (xrspatial/tests/test_zonal.py:204-237, 497-544): cells grouped by zone on the
+    device (xrs_zonal_group_*), the callable applied on the host to each zone's valid values."""
+    funcs = {'double_sum': lambda v: v.sum() * 2, 'range': lambda v: v.max() - v.min()}
+    zones, values = raster(golden["zonal_zones"]), raster(golden["zonal_values"])
+    z0, v0 = zones.data.copy(), values.data.copy()
+    nodata, ids, exp = (golden_tables["zonal_custom__%d" % i] for i in range(3))
+    df = xs.zonal_stats(zones, values, zone_ids=ids, stats_funcs=funcs, nodata_values=nodata)
+    assert list(df.columns) == ['zone', 'double_sum', 'range']
+    assert df['zone'].tolist() == exp['zone']
+    for col in ('double_sum', 'range'):
+        np.testing.assert_allclose(df[col], exp[col], rtol=1e-6)
+    da = xs.zonal_stats(zones, values, zone_ids=ids, stats_funcs=funcs, nodata_values=nodata, return_type='xarray.DataArray')
+    assert da.dims == ('stats', 'y', 'x') and [str(v) for v in np.asarray(da.coords['stats'])] == ['double_sum', 'range']
+    np.testing.assert_allclose(da.data, golden["zonal_custom_da__2"], equal_nan=True)
+    np.testing.assert_array_equal(zones.data, z0)
+    np.testing.assert_array_equal(values.data, v0)
+    # seeded, order statistics the partial sums cannot give: median / 90th percentile / number of distinct values, on
+    # float32, float64 and integer rasters with NaN and nodata cells and a zone without any valid cell
+    rng = np.random.default_rng(23)
+    zz = rng.integers(-3, 40, size=(300, 517)).astype(np.int64) * 7
+    zz[:5, :9] = 1000                                              # this zone only holds nodata / NaN cells
+    seen = []
+    order = {'median': np.median, 'p90': lambda v: np.percentile(v, 90), 'distinct': lambda v: len(np.unique(v)),
+             'n': lambda v: (seen.append(v.dtype), v.size)[1], 'sorted': lambda v: float(np.all(np.diff(v) >= 0))}
+    for dtype in (np.float32, np.float64, np.int32):
+        vv = (rng.normal(50.0, 20.0, size=zz.shape)).astype(dtype)
+        if dtype != np.int32:
+            vv[rng.random(zz.shape) < 0.03] = np.nan
+            vv[rng.random(zz.shape) < 0.01] = -0.0
+        vv[rng.random(zz.shape) < 0.02] = 7
+        vv[:5, :9] = 7
+        del seen[:]
+        got = xs.zonal_stats(raster(zz), raster(vv), stats_funcs=order, nodata_values=7)
+        assert set(seen) == {np.dtype(dtype)}                      # callables see the caller's dtype
+        uz = np.unique(zz)
+        assert got['zone'].tolist() == uz.tolist()
+        for i, z in enumerate(uz):
+            cell = vv[zz == z]
+            cell = cell[np.isfinite(cell) & (cell != 7)]
+            if cell.size == 0:
+                assert z == 1000 and all(np.isnan(got[c][i]) for c in order)
+                continue
+            assert got['n'][i] == cell.size and got['sorted'][i] == 1.0
+            assert got['median'][i] == np.median(cell) and got['distinct'][i] == len(np.unique(cell))
+            np.testing.assert_allclose(got['p90'][i], np.percentile(cell, 90), rtol=1e-12)
+    # device-resident rasters take the same path
+    dgot = xs.zonal_stats(raster(zz, backend='hip'), raster(vv.astype(np.float32), backend='hip'),
+                          stats_funcs={'median': np.median}, zone_ids=[0, 7, 14])
+    want = [np.median(vv.astype(np.float32)[zz == z]) for z in (0, 7, 14)]
+    assert dgot['zone'].tolist() == [0, 7, 14] and dgot['median'].tolist() == want
+
+
+def test_focal_apply_user_callable(golden):
+    """focal.apply(func=callable) (focal.py:305-326): windows gathered on the device (xrs_focal_windows_f32), the
+    callable applied on the host.  The callable sees exactly the array _apply_numpy builds."""
+    from xrspatial_amd import focal as xfocal
+    rng = np.random.default_rng(5)
+    z = rng.normal(size=(37, 53)).astype(np.float32)
+    z[rng.random(z.shape) < 0.05] = np.nan
+    for k in (circle_kernel(1, 1, 2), np.ones((3, 5)), np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], float)):
+        kr, kc = k.shape
+        seen = []
+
+        def second_largest(w):
+            seen.append((w.shape, w.dtype))
+            v = np.sort(w[np.isfinite(w)])
+            return v[-2] if v.size > 1 else np.nan
+
+        got = apply(raster(z), k, func=second_largest)
+        assert got.dtype == np.float32 and got.shape == z.shape and set(seen) == {((kr, kc), np.dtype(np.float32))}
+        pad = np.full((z.shape[0] + kr - 1, z.shape[1] + kc - 1), np.nan, np.float32)
+        pad[kr // 2:kr // 2 + z.shape[0], kc // 2:kc // 2 + z.shape[1]] = z
+        want = np.zeros_like(z)
+        for y in range(z.shape[0]):
+            for x in range(z.shape[1]):
+                w = np.where(k == 1, pad[y:y + kr, x:x + kc], np.nan).astype(np.float32)
+                v = np.sort(w[np.isfinite(w)])
+                want[y, x] = v[-2] if v.size > 1 else np.nan
+        np.testing.assert_array_equal(got.data, want)
+    # the built-in reducers as plain numpy callables agree with the device reducers (NaN-skipping mean / max)
+    k = circle_kernel(1, 1, 3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        np.testing.assert_allclose(apply(raster(z), k, func=np.nanmean).data, apply(raster(z), k).data, rtol=2e-6, atol=1e-7, equal_nan=True)
+        np.testing.assert_array_equal(apply(raster(z), k, func=np.nanmax).data, apply(raster(z), k, func=xfocal._calc_max).data)
+    # several bands (the band height is derived from a byte budget), device-resident input
+    old = xfocal._WINDOW_BAND_BYTES
+    xfocal._WINDOW_BAND_BYTES = 53 * 9 * 4 * 5                    # 5 rows per band
+    try:
+        got = apply(raster(z, backend='hip'), np.ones((3, 3)), func=lambda w: w[1, 1] + np.isnan(w).sum())
+    finally:
+        xfocal._WINDOW_BAND_BYTES = old
+    nanc = np.zeros(z.shape)
+    pad = np.full((z.shape[0] + 2, z.shape[1] + 2), np.nan)
+    pad[1:-1, 1:-1] = z
+    for dy in range(3):
+        for dx in range(3):
+            nanc += np.isnan(pad[dy:dy + z.shape[0], dx:dx + z.shape[1]])
+    np.testing.assert_array_equal(got.data, (z + nanc).astype(np.float32))
 
 
 @pytest.mark.parametrize("zdtype", [np.int32, np.int64, np.float32, np.float64])

@@ -109,8 +109,8 @@ def test_focal_argument_validation():
         focal.apply(raster(np.zeros((2, 5, 5)), dims=('t', 'y', 'x')), k)
     with pytest.raises(ValueError):
         focal.apply(r, np.ones((2, 3)))
-    with pytest.raises(NotImplementedError):
-        focal.apply(r, k, func=lambda w: 0)              # arbitrary callables have no device form
+    with pytest.raises(TypeError):
+        focal.apply(r, k, func=42)                       # neither a built-in reducer nor a callable
     with pytest.raises(TypeError):
         focal.focal_stats(np.zeros((5, 5)), k)
     with pytest.raises(KeyError):
@@ -176,8 +176,8 @@ def test_zonal_argument_validation():
         zonal.stats(zones, raster(np.zeros((4, 4), dtype=bool)))
     with pytest.raises(ValueError):
         zonal.stats(zones, vals, return_type='dict')
-    with pytest.raises(NotImplementedError):
-        zonal.stats(zones, vals, stats_funcs={'mine': lambda z: 0})
+    with pytest.raises(ValueError):
+        zonal.stats(zones, vals, stats_funcs={'mine': 'median'})     # dict values must be callables
     with pytest.raises((KeyError, ValueError)):
         zonal.stats(zones, vals, stats_funcs=['mode'])
     with pytest.raises(ValueError):

@@ -115,6 +115,9 @@ _PROTOTYPES = {
                                c_void_p],
     "xrs_zonal_majority_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                c_void_p],
+    "xrs_focal_windows_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_void_p],
+    "xrs_zonal_group_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
+    "xrs_zonal_group_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
     "xrs_zonal_backproject_f64": [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrs_comm_unique_id": [c_void_p],
     "xrs_comm_init_rank": [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int],

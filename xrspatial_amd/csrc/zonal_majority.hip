@@ -47,7 +47,7 @@ template <> struct KeyOf<double> {
     }
 };
 
-template <typename VT>
+template <typename VT, bool CANON>
 __global__ void make_keys_kernel(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata,
                                  typename KeyOf<VT>::K *vkey, unsigned *zkey) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -55,7 +55,7 @@ __global__ void make_keys_kernel(const int32_t *zidx, const VT *vals, long n, in
     const int z = zidx[i];
     VT v = vals[i];
     const bool ok = z >= 0 && z < nz && isfinite(v) && !(has_nodata && v == nodata);
-    if (v == (VT)0) v = (VT)0;                   // -0.0 and +0.0 are one value for np.unique
+    if (CANON && v == (VT)0) v = (VT)0;          // -0.0 and +0.0 are one value for np.unique (majority); grouping keeps them
     vkey[i] = ok ? KeyOf<VT>::enc(v) : ~(typename KeyOf<VT>::K)0;
     zkey[i] = ok ? (unsigned)z : (unsigned)nz;
 }
@@ -130,6 +130,14 @@ __global__ void decode_kernel(const unsigned long long *best, const unsigned *po
     majority[z] = (double)KeyOf<VT>::dec(vs[pos[r]]);
 }
 
+// values of the sorted cells back from their keys (xrs_zonal_group_*): cells of invalid zones / values sort last and
+// decode to NaN
+template <typename VT>
+__global__ void decode_values_kernel(const typename KeyOf<VT>::K *vs, long n, VT *out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = KeyOf<VT>::dec(vs[i]);
+}
+
 __global__ void backproject_kernel(const int32_t *zidx, long n, const double *table, int n_stats, int nz,
                                    double *out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -166,6 +174,34 @@ struct Plan {
     }
 };
 
+// cells -> keys -> ordered by (zone, value); returns the sorted key arrays (inside `work`)
+template <typename VT, bool CANON>
+int sort_by_zone_value(const char *who, const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata,
+                       void *work, size_t work_bytes, const Plan<VT> &pl, const unsigned **zs_out,
+                       const typename KeyOf<VT>::K **vs_out, hipStream_t s) {
+    using K = typename KeyOf<VT>::K;
+    if (!zidx || !vals || !work) return fail("%s: null pointer", who);
+    if (work_bytes < pl.total) return fail("%s: workspace too small (%zu < %zu)", who, work_bytes, pl.total);
+    char *w = static_cast<char *>(work);
+    K *vk[2] = {reinterpret_cast<K *>(w + pl.off_vk[0]), reinterpret_cast<K *>(w + pl.off_vk[1])};
+    unsigned *zk[2] = {reinterpret_cast<unsigned *>(w + pl.off_zk[0]), reinterpret_cast<unsigned *>(w + pl.off_zk[1])};
+    void *cub = w + pl.off_cub;
+    size_t cub_bytes = pl.cub_bytes;
+    const unsigned grid_n = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL((make_keys_kernel<VT, CANON>), dim3(grid_n), dim3(256), 0, s, zidx, vals, n, nz, nodata, has_nodata, vk[0], zk[0]);
+    XRS_LAUNCH_CHECK();
+    hipcub::DoubleBuffer<K> dk(vk[0], vk[1]);
+    hipcub::DoubleBuffer<unsigned> dz(zk[0], zk[1]);
+    XRS_HIP(hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, dk, dz, (int)n, 0, (int)sizeof(K) * 8, s));
+    int zbits = 1;
+    while ((1L << zbits) <= nz) ++zbits;
+    cub_bytes = pl.cub_bytes;
+    XRS_HIP(hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, dz, dk, (int)n, 0, zbits, s));
+    *zs_out = dz.Current();
+    *vs_out = dk.Current();
+    return 0;
+}
+
 template <typename VT>
 int majority_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata, void *work,
                   size_t work_bytes, double *majority, hipStream_t s) {
@@ -179,11 +215,12 @@ int majority_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata
         XRS_HIP(hipMemsetAsync(majority, 0xFF, (size_t)nz * sizeof(double), s));
         return 0;
     }
-    if (!zidx || !vals || !work) return fail("xrs_zonal_majority: null pointer");
-    if (work_bytes < pl.total) return fail("xrs_zonal_majority: workspace too small (%zu < %zu)", work_bytes, pl.total);
+    const unsigned *zs;
+    const K *vs;
+    if (int rc = sort_by_zone_value<VT, true>("xrs_zonal_majority", zidx, vals, n, nz, nodata, has_nodata, work, work_bytes,
+                                              pl, &zs, &vs, s))
+        return rc;
     char *w = static_cast<char *>(work);
-    K *vk[2] = {reinterpret_cast<K *>(w + pl.off_vk[0]), reinterpret_cast<K *>(w + pl.off_vk[1])};
-    unsigned *zk[2] = {reinterpret_cast<unsigned *>(w + pl.off_zk[0]), reinterpret_cast<unsigned *>(w + pl.off_zk[1])};
     unsigned char *flags = reinterpret_cast<unsigned char *>(w + pl.off_flags);
     unsigned *pos = reinterpret_cast<unsigned *>(w + pl.off_pos);
     unsigned *nruns = reinterpret_cast<unsigned *>(w + pl.off_nruns);
@@ -191,18 +228,6 @@ int majority_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata
     void *cub = w + pl.off_cub;
     size_t cub_bytes = pl.cub_bytes;
     const unsigned grid_n = (unsigned)((n + 255) / 256);
-
-    hipLaunchKernelGGL((make_keys_kernel<VT>), dim3(grid_n), dim3(256), 0, s, zidx, vals, n, nz, nodata, has_nodata, vk[0], zk[0]);
-    XRS_LAUNCH_CHECK();
-    hipcub::DoubleBuffer<K> dk(vk[0], vk[1]);
-    hipcub::DoubleBuffer<unsigned> dz(zk[0], zk[1]);
-    XRS_HIP(hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, dk, dz, (int)n, 0, (int)sizeof(K) * 8, s));
-    int zbits = 1;
-    while ((1L << zbits) <= nz) ++zbits;
-    cub_bytes = pl.cub_bytes;
-    XRS_HIP(hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, dz, dk, (int)n, 0, zbits, s));
-    const unsigned *zs = dz.Current();
-    const K *vs = dk.Current();
     hipLaunchKernelGGL((head_flags_kernel<K>), dim3(grid_n), dim3(256), 0, s, zs, vs, n, flags);
     XRS_LAUNCH_CHECK();
     cub_bytes = pl.cub_bytes;
@@ -216,9 +241,40 @@ int majority_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata
     return 0;
 }
 
+template <typename VT>
+int group_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata, void *work, size_t work_bytes,
+               VT *sorted, hipStream_t s) {
+    using K = typename KeyOf<VT>::K;
+    if (n < 0 || nz < 0) return fail("xrs_zonal_group: negative size");
+    if (n == 0) return 0;
+    if (n >= (1L << 31)) return fail("xrs_zonal_group: at most 2^31-1 cells per call");
+    if (!sorted) return fail("xrs_zonal_group: null output");
+    Plan<VT> pl(n, nz > 0 ? nz : 1);
+    const unsigned *zs;
+    const K *vs;
+    if (int rc = sort_by_zone_value<VT, false>("xrs_zonal_group", zidx, vals, n, nz, nodata, has_nodata, work, work_bytes, pl,
+                                               &zs, &vs, s))
+        return rc;
+    hipLaunchKernelGGL((decode_values_kernel<VT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vs, n, sorted);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int xrs_zonal_group_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones, float nodata,
+                        int has_nodata, void *work_dev, size_t work_bytes, float *sorted_values_dev, void *stream) {
+    return group_impl<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, work_dev, work_bytes,
+                             sorted_values_dev, as_stream(stream));
+}
+
+int xrs_zonal_group_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones, double nodata,
+                        int has_nodata, void *work_dev, size_t work_bytes, double *sorted_values_dev, void *stream) {
+    return group_impl<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, work_dev, work_bytes,
+                              sorted_values_dev, as_stream(stream));
+}
 
 size_t xrs_zonal_majority_workspace_bytes(int64_t n, int n_zones, int values_f64) {
     if (n <= 0 || n_zones <= 0) return 256;

@@ -186,21 +186,54 @@ def mean(agg, passes=1, excludes=[np.nan], name='mean'):
 
 
 def _reducer_name(func):
+    """The built-in statistic `func` stands for, or None for a user callable."""
     if isinstance(func, _BuiltinReducer):
         return func.stat
     if isinstance(func, str) and func in _STAT_INDEX:
         return func
-    raise NotImplementedError(
-        "apply() on the MI355X backend supports the built-in reducers "
-        "(_calc_mean/_calc_sum/_calc_min/_calc_max/_calc_std/_calc_var/_calc_range); "
-        f"got {func!r}")
+    if callable(func):
+        return None
+    raise TypeError(
+        "apply(): `func` must be one of the built-in reducers (_calc_mean/_calc_sum/_calc_min/_calc_max/_calc_std/"
+        f"_calc_var/_calc_range) or a callable taking the kernel-shaped window; got {func!r}")
+
+
+_WINDOW_BAND_BYTES = 256 << 20          # gathered windows held on the device / crossing PCIe per band
+
+
+def _apply_callable(data, kernel, func):
+    """focal.apply with a user callable (focal.py:305-326): the MI355X gathers, for a band of rows at a time, the
+    kernel-shaped float32 window of every cell (NaN outside the raster and where the kernel is not 1 -- exactly the
+    array _apply_numpy fills); `func` runs on the host on each window.  float32 result, a numpy array."""
+    _lib.require_device()
+    stream = get_stream()
+    src = to_device_f32(data)
+    rows, cols = src.shape
+    k = _kernel_f64(kernel)
+    kr, kc = k.shape
+    out = np.zeros((rows, cols), np.float32)
+    if rows == 0 or cols == 0:
+        return out
+    per_row = cols * kr * kc * 4
+    band = int(max(1, min(rows, _WINDOW_BAND_BYTES // per_row)))
+    wdev = DeviceArray((band, cols, kr, kc), np.float32)
+    for y0 in range(0, rows, band):
+        nb = min(band, rows - y0)
+        _lib.call("xrs_focal_windows_f32", src.ptr, wdev.ptr, rows, cols, cols, y0, nb, k.ctypes.data, kr, kc, stream)
+        win = wdev.get(stream)[:nb]
+        for y in range(nb):
+            row_w, row_o = win[y], out[y0 + y]
+            for x in range(cols):
+                row_o[x] = func(row_w[x])
+    return out
 
 
 def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
     """Reduce the cells under `kernel == 1` around every cell with `func` (default: mean).
 
     Same signature as `xrspatial.focal.apply`; window clipped at the raster edge, NaN
-    cells skipped, float32 result."""
+    cells skipped, float32 result.  The built-in reducers run entirely on the MI355X; any other callable gets the
+    kernel-shaped float32 window of each cell (gathered on the device, `_apply_callable`) and runs on the host."""
     if not isinstance(raster, DataArray):
         raise TypeError("`raster` must be instance of DataArray")
     if raster.ndim != 2:
@@ -210,6 +243,13 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
     scope = fused.current()
     if scope is not None and stat == 'mean':
         return scope.defer('focal_mean', raster, name, {'kernel': _kernel_f64(kernel)})
+
+    if stat is None:
+        if isinstance(raster.data, ShardedArray):
+            raise NotImplementedError("focal.apply with a user callable is not available for row-sharded rasters; "
+                                      "use one of the built-in reducers")
+        out = _apply_callable(raster.data, kernel, func)
+        return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
 
     def run(data, kernel, stat):
         if pipeline_ok(data) and max(np.asarray(kernel).shape) // 2 < 128:

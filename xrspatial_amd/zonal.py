@@ -212,6 +212,49 @@ def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
     return out.get(stream)
 
 
+def zonal_grouped_values(zone_idx, values, n_zones, nodata_values=None):
+    """The valid cells of every zone as one host array ordered by (zone index, value ascending): the device-side
+    replacement of _sort_and_stride (zonal.py:121-141) for statistics that are host callables.  Only the valid cells
+    cross PCIe; zone z's values are out[offsets[z]:offsets[z + 1]] with offsets = cumsum of the valid-cell counts."""
+    _lib.require_device()
+    stream = get_stream()
+    zdev, vdev = _stage(zone_idx, values)
+    f64 = vdev.dtype == np.float64
+    n = int(vdev.size)
+    nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(n, max(n_zones, 1), int(f64)))
+    work = DeviceArray((nbytes,), np.uint8)
+    out = DeviceArray((max(n, 1),), vdev.dtype)
+    has_nodata = nodata_values is not None
+    nodata = float(nodata_values) if has_nodata else 0.0
+    _lib.call("xrs_zonal_group_f64" if f64 else "xrs_zonal_group_f32", zdev.ptr, vdev.ptr, n, n_zones, nodata,
+              int(has_nodata), work.ptr, nbytes, out.ptr, stream)
+    return out, vdev.dtype
+
+
+def _custom_columns(funcs, idx_dev, vdev, nz, count, keep, nodata_values, values_dtype):
+    """Per-zone results of user callables: every callable gets the 1-D array of the zone's valid values (finite and
+    != nodata_values, as _calc_stats zonal.py:157-161 filters them), in ascending order, in the dtype of the caller's
+    raster; zones without a valid cell stay NaN and the callable is not called for them."""
+    sorted_dev, _ = zonal_grouped_values(idx_dev, vdev, nz, nodata_values)
+    offsets = np.concatenate([[0], np.cumsum(count.astype(np.int64))])
+    n_valid = int(offsets[-1])
+    host = np.empty(n_valid, sorted_dev.dtype)
+    if n_valid:
+        stream = get_stream()
+        _lib.call("xrs_memcpy_d2h", host.ctypes.data, sorted_dev.ptr, n_valid * host.dtype.itemsize, stream)
+        _lib.call("xrs_stream_sync", stream)
+    if np.issubdtype(values_dtype, np.integer):
+        host = host.astype(values_dtype)
+    cols = {}
+    for name, func in funcs.items():
+        col = np.full(nz, np.nan)
+        for i in keep:
+            if offsets[i + 1] > offsets[i]:
+                col[i] = func(host[offsets[i]:offsets[i + 1]])
+        cols[name] = col
+    return cols
+
+
 def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None, shift=0.0):
     """Per-zone statistics from the partials (formulas of zonal.py:100-102, on moments of x - shift: the one-pass
     variance sum(d^2) - sum(d)^2 / n cancels in proportion to (mean - shift)^2 / var, so a shift near the data keeps it
@@ -233,11 +276,14 @@ def finalize_stats(stat_names, count, s1, s2, mn, mx, majority=None, shift=0.0):
     return out
 
 
-def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, return_type, comm=None):
+def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, return_type, comm=None, custom=None):
+    """`stat_names`: the output columns in order; `custom`: {name: callable} for the names that are not built in."""
     like_numpy = not isinstance(values_data, DeviceArray)
+    custom = custom or {}
+    builtin = [n for n in stat_names if n not in custom]
     mapped = None
     small_int = zones_data.dtype in (np.int32, np.int16, np.int8, np.uint16, np.uint8)
-    if (small_int and return_type == 'pandas.DataFrame' and 'majority' not in stat_names and int(zones_data.size) > 0
+    if (small_int and return_type == 'pandas.DataFrame' and 'majority' not in stat_names and not custom and int(zones_data.size) > 0
             and (isinstance(zones_data, np.ndarray) or zones_data.dtype == np.int32)):
         # integer zones (<= 32 bit), partial-sum statistics only: the raw ids go to HBM as they are and the reduction
         # kernel maps them through a small table itself -- no pass over the raster on the host and no dense index
@@ -284,9 +330,11 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
     nz = len(unique_zones)
     _, vdev = _stage(idx_dev, values_data)
     count, s1, s2, mn, mx, shift = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
-    majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in stat_names else None
-    cols = finalize_stats(stat_names, count, s1, s2, mn, mx, majority, shift)
+    majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in builtin else None
+    cols = finalize_stats(builtin, count, s1, s2, mn, mx, majority, shift)
     keep = [i for i, z in enumerate(unique_zones) if z in selected]
+    if custom:
+        cols.update(_custom_columns(custom, idx_dev, vdev, nz, count, keep, nodata_values, np.dtype(values_data.dtype)))
     if return_type == 'pandas.DataFrame':
         frame = {'zone': selected}
         for name in stat_names:
@@ -376,8 +424,9 @@ def stats(
 
     Same signature as `xrspatial.zonal.stats`.  All eight default statistics (mean / max / min / sum /
     std / var / count from one streaming partial-sum pass, majority from a device sort), `zone_ids`,
-    `nodata_values`, Dataset `values` and both return types run on the MI355X.  Custom callables
-    (`stats_funcs` as a dict) are arbitrary Python and raise NotImplementedError here."""
+    `nodata_values`, Dataset `values` and both return types run on the MI355X.  `stats_funcs` as a dict of callables
+    (zonal.py:304-310): the cells are grouped by zone on the device and each callable runs on the host on the 1-D array
+    of its zone's valid values (ascending order; the reference hands them over in argsort order)."""
     if isinstance(values, Dataset):
         if return_type != 'pandas.DataFrame':
             raise ValueError("return_type must be 'pandas.DataFrame' when values is a Dataset")
@@ -399,21 +448,30 @@ def stats(
     if len(values.shape) != 2:
         raise ValueError("`values` must be 2D (pass a Dataset for several layers)")
 
+    custom = {}
     if isinstance(stats_funcs, dict):
-        raise NotImplementedError(
-            "custom stats callables cannot run on the MI355X backend; pass a list of names from "
-            f"{list(_DEVICE_STATS)}")
-    names = list(stats_funcs)
-    for name in names:
-        if name not in _DEFAULT_STATS:
-            raise ValueError(f"Invalid stat name. {name} option not supported.")
+        # {column name: callable}: the reference's numpy / cupy form (zonal.py:304-310, :407-411).  The zone's cells are
+        # gathered on the MI355X (one sort by zone), the callable runs on the host on each zone's values.
+        names = list(stats_funcs)
+        for name, func in stats_funcs.items():
+            if not callable(func):
+                raise ValueError(name)
+            custom[name] = func
+        if isinstance(values.data, ShardedArray):
+            raise NotImplementedError("custom stats callables need all cells of a zone in one place and are not "
+                                      "available for row-sharded rasters")
+    else:
+        names = list(stats_funcs)
+        for name in names:
+            if name not in _DEFAULT_STATS:
+                raise ValueError(f"Invalid stat name. {name} option not supported.")
     if return_type not in ('pandas.DataFrame', 'xarray.DataArray'):
         raise ValueError(f"unknown return_type {return_type!r}")
     if isinstance(values.data, ShardedArray):
         return _stats_sharded(zones.data, values.data, zone_ids, names, nodata_values, return_type)
     if not isinstance(values.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(values)))
-    result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type)
+    result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type, custom=custom)
     if return_type == 'xarray.DataArray':
         coords = dict(values.coords.items())
         coords['stats'] = names

@@ -429,7 +429,7 @@ struct WalkConv {
 template <int R, typename Shape>
 __device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, double w, const double *weights) {
     constexpr int K = 2 * R + 1;
-    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
     if (t < 0) return;
     const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -512,7 +512,7 @@ __device__ __forceinline__ void walk_columns(const WalkGeom &g, const WalkOuts &
 
 template <int R, typename Shape, bool F32, bool WANT_SUM, bool WANT_MM, bool F64, bool WANT_VAR = true>
 __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) {
-    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
     if (t < 0) return;
     const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void walk_tile(const WalkGeom &g, const WalkOuts &o) 
 inline int walk_grid(WalkGeom &g, long *grid) {
     g.tiles_x = (g.cols + 255) / 256;
     g.n_tiles = g.tiles_x * ((g.rows + CTH - 1) / CTH);
-    *grid = xcd_grid(g.n_tiles);
+    *grid = xcd_grid(g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
     if (*grid > 0x7fffffffL) return fail("focal circle: raster too large for one launch");
     return 0;
 }

@@ -197,7 +197,7 @@ int xrs_nan_minmax_f32(const float *in_dev, int64_t n, float *minmax_dev, void *
     if (n) {
         long g = (n / 4 + 255) / 256;
         g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
-        hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)xcd_grid(g)), dim3(256), 0, s, in_dev, (long)n, mm);
+        hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)xcd_grid(g, 1)), dim3(256), 0, s, in_dev, (long)n, mm);
     }
     hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1), 0, s, mm);
     XRS_LAUNCH_CHECK();

@@ -87,7 +87,7 @@ __device__ __forceinline__ float plane_to_result(double A, double B, int mode) {
 // Regular grids: one cell per lane, a wave per row, 64 columns x 4 rows per workgroup.
 template <typename ET>
 __global__ void __launch_bounds__(256) geodesic_grid_kernel(const GeoArgs a, const long tiles_x, const long n_tiles) {
-    const long tile = xcd_tile(blockIdx.x, n_tiles);
+    const long tile = xcd_tile(blockIdx.x, n_tiles, XCD_UNIT(XRS_XCD_LDS, tiles_x));
     if (tile < 0) return;
     const long x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
     const long y = (tile / tiles_x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) geodesic_grid_kernel(const GeoArgs a, con
 template <typename ET>
 __global__ void __launch_bounds__(256) geodesic_kernel(const GeoArgs a, const long tiles_x, const long n_tiles) {
     // one workgroup = 64 columns x 4 rows (a wave per row); tiles numbered row-major, dealt to the XCDs in bands
-    const long tile = xcd_tile(blockIdx.x, n_tiles);
+    const long tile = xcd_tile(blockIdx.x, n_tiles, XCD_UNIT(XRS_XCD_LDS, tiles_x));
     if (tile < 0) return;
     const long x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
     const long y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
@@ -272,7 +272,7 @@ int xrs_geodesic_f32(const void *elev_dev, int elev_is_f64, const double *lat_de
     a.inv2r = 1.0 / (2.0 * 6370994.884953014);                  // WGS84 mean radius (geodesic.py:187)
     hipStream_t s = as_stream(stream);
     const long tiles_x = (cols + 63) / 64, n_tiles = tiles_x * ((rows + 3) / 4);
-    const dim3 grid((unsigned)xcd_grid(n_tiles));
+    const dim3 grid((unsigned)xcd_grid(n_tiles, XCD_UNIT(XRS_XCD_LDS, tiles_x)));
     if (!latlon_2d) {
         const long nlat = rows + halo_top + halo_bot;
         double *tab_lat = static_cast<double *>(work_dev);

@@ -175,7 +175,7 @@ int xrs_nan_moments_f32(const float *in_dev, int64_t n, void *moments32_dev, voi
     if (n) {
         long g = (n / 4 + 255) / 256;
         g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
-        hipLaunchKernelGGL(moments_kernel, dim3((unsigned)xcd_grid(g)), dim3(256), 0, s, in_dev, (long)n, m, vec);
+        hipLaunchKernelGGL(moments_kernel, dim3((unsigned)xcd_grid(g, 1)), dim3(256), 0, s, in_dev, (long)n, m, vec);
     }
     hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(1), 0, s, m);
     XRS_LAUNCH_CHECK();
@@ -190,7 +190,7 @@ int xrs_hotspots_classify_f32(const float *mean_array_dev, signed char *out_dev,
     long g = (n / 4 + 255) / 256;
     g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
     const int vec = aligned16(mean_array_dev) && (reinterpret_cast<uintptr_t>(out_dev) & 3u) == 0;
-    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)xcd_grid(g)), dim3(256), 0, as_stream(stream), mean_array_dev,
+    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)xcd_grid(g, 1)), dim3(256), 0, as_stream(stream), mean_array_dev,
                        out_dev, (long)n, global_mean, global_std, vec);
     XRS_LAUNCH_CHECK();
     return 0;

@@ -308,7 +308,7 @@ __device__ __forceinline__ void focal_rows_general(const KxkArgs &a, const float
 template <int KH, int KW, int MODE, bool VEC>
 __global__ void __launch_bounds__(256) focal_stats_kernel(const KxkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * TW, Y0 = ty * a.th;
@@ -327,7 +327,7 @@ template <int KH, int KW>
 __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     constexpr int RPW = TH_FAST / 4, RX = KW / 2, NV = 4 + 2 * RX, NS = (NV + 3) / 4;
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * TW, Y0 = ty * TH_FAST;
@@ -484,7 +484,7 @@ template <int KH, int KW, int RB, unsigned CMASK = 0u>
 #endif
 // (3x3: the three inlined bodies need ~150 VGPRs; at 4 workgroups per CU they spilled 25 registers and ran at half speed)
 __global__ void __launch_bounds__(256, KH == 3 ? 3 : XRS_LB_MEAN) focal_mean_direct_kernel(const KxkArgs a) {
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -586,7 +586,7 @@ __device__ __forceinline__ void focal_stats_direct_rows(const KxkArgs &a, long x
 template <int KH, int KW, int RB>
 __global__ void __launch_bounds__(256) focal_stats_direct_kernel(const KxkArgs a) {
     constexpr int NV = 4 + 2 * (KW / 2), NR = RB + KH - 1;
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(256) focal_stats_direct_kernel(const KxkArgs a
 template <int KH, int KW, int RB>
 __global__ void __launch_bounds__(256) convolve_direct_kernel(const KxkArgs a) {
     constexpr int NV = 4 + 2 * (KW / 2), NR = RB + KH - 1;
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(256) convolve_direct_kernel(const KxkArgs a) {
 template <int KH, int KW, bool VEC>
 __global__ void __launch_bounds__(256) convolve_kernel(const KxkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * TW, Y0 = ty * a.th;
@@ -779,7 +779,7 @@ __device__ __forceinline__ double div9_exact(double s) {
 template <typename InT>
 __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
     constexpr int RB = 4;
-    const long t = xcd_tile(blockIdx.x, n_tiles);
+    const long t = xcd_tile(blockIdx.x, n_tiles, tiles_x);
     if (t < 0) return;
     const long ty = t / tiles_x, tx = t - ty * tiles_x;
     const int lane = threadIdx.x & 63;
@@ -916,7 +916,7 @@ bool vec_ok(const KxkArgs &a, unsigned out_mask) {
 
 template <int KH, int KW, int MODE>
 int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
-    const unsigned grid = (unsigned)xcd_grid(a.n_tiles);
+    const unsigned grid = (unsigned)xcd_grid(a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (vec)
         hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MODE, true>), dim3(grid), dim3(256), lds, s, a);
     else
@@ -927,7 +927,7 @@ int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
 
 template <int KH, int KW>
 int launch_mean_fast(const KxkArgs &a, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((focal_mean_fast_kernel<KH, KW>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((focal_mean_fast_kernel<KH, KW>), dim3((unsigned)xcd_grid(a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x))), dim3(256), lds, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -941,7 +941,7 @@ int launch_mean_direct_rb(KxkArgs a, hipStream_t s) {
     constexpr unsigned BOX = SPECIALISE ? (1u << (KH * KW)) - 1u : 0u;
     unsigned mask = 0;
     for (int ky = 0; ky < KH; ++ky) mask |= (unsigned)a.mask_rows[ky] << (ky * KW);
-    const dim3 grid((unsigned)xcd_grid(a.n_tiles));
+    const dim3 grid((unsigned)xcd_grid(a.n_tiles, a.tiles_x));
     if (SPECIALISE && mask == BOX)
         hipLaunchKernelGGL((focal_mean_direct_kernel<KH, KW, RB, BOX>), grid, dim3(256), 0, s, a);
     else
@@ -962,7 +962,7 @@ int launch_stats_direct(KxkArgs a, hipStream_t s) {
     constexpr int RB = KH >= 5 ? 1 : 2;          // few rows per wave: the 7 output streams dominate traffic, and
                                                  // registers (12 per output + the window) set the occupancy
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
-    hipLaunchKernelGGL((focal_stats_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((focal_stats_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles, a.tiles_x)), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -971,7 +971,7 @@ template <int KH, int KW>
 int launch_convolve_direct(KxkArgs a, hipStream_t s) {
     constexpr int RB = 4;
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
-    hipLaunchKernelGGL((convolve_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((convolve_direct_kernel<KH, KW, RB>), dim3((unsigned)xcd_grid(a.n_tiles, a.tiles_x)), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -1068,7 +1068,7 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     }
     a.tiles_x = (cols + TW - 1) / TW;
     a.n_tiles = a.tiles_x * ((rows + a.th - 1) / a.th);
-    const unsigned grid = (unsigned)xcd_grid(a.n_tiles);
+    const unsigned grid = (unsigned)xcd_grid(a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     const bool vec = vec_ok(a, 1u);
 #define XRS_CONV(KH, KW)                                                                              \
     do {                                                                                              \
@@ -1231,7 +1231,7 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
     const bool vec = true;
     if (vec) {
         const long tiles_x = (cols + TW - 1) / TW, n_tiles = tiles_x * ((rows + 15) / 16);
-        const unsigned g = (unsigned)xcd_grid(n_tiles);
+        const unsigned g = (unsigned)xcd_grid(n_tiles, tiles_x);
         if (in_is_f64)
             hipLaunchKernelGGL(focal_mean3_strip_kernel<double>, dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
         else

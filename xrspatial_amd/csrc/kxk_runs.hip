@@ -53,7 +53,7 @@ __device__ __forceinline__ double rcp_count(int n) {
 // slots while the 74 KiB tile is paid once per 16 waves); wave w produces output row w.
 __global__ void __launch_bounds__(1024, 8) focal_mean_runs_kernel(const RunArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * RTW, Y0 = ty * RTH;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(1024, 8) focal_mean_runs_kernel(const RunArgs 
 __global__ void __launch_bounds__(1024, 4) focal_meanvar_runs_kernel(const RunArgs a) {   // one WG per CU (LDS): 4 waves/SIMD
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned r2max_bits;
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const long X0 = tx * RTW, Y0 = ty * RTH;
@@ -396,7 +396,7 @@ int launch_runs(K kernel_fn, RunArgs &a, size_t bytes_per_cell, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail("hipFuncSetAttribute(max dynamic LDS %zu) failed: %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel_fn, dim3((unsigned)xcd_grid(a.n_tiles)), dim3(1024), lds, s, a);
+    hipLaunchKernelGGL(kernel_fn, dim3((unsigned)xcd_grid(a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x))), dim3(1024), lds, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }

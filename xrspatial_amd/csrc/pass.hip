@@ -76,12 +76,17 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
     if (TERRAIN) {
         const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
         const float qnan = nan_f32();
+        // (slope / aspect: Horn sums cell by cell here -- sharing the differences along the strip, terrain.hip's HornRoller,
+        //  needs 40 more VGPRs next to the focal accumulators and costs this kernel an occupancy step: 0.99 vs 0.87 ms)
+        constexpr bool HORN = (OPS & (OP_SLOPE | OP_ASPECT)) != 0;
+        const SlopeK sk = slope_constants(a.inv8cx, a.inv8cy);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const long y = y0 + r;
             if (!INTERIOR && y >= a.rows) break;
             const bool row_border = !INTERIOR && ((y - 1 < y_lo) || (y + 1 >= y_hi));
             float o_slope[4], o_aspect[4], o_curv[4], o_hill[4];
+            Horn hs[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 const long x = x0 + o;
@@ -91,8 +96,9 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
                 q.nw = v[t][c];     q.n = v[t][c + 1];     q.ne = v[t][c + 2];
                 q.w = v[t + 1][c];  q.c = v[t + 1][c + 1]; q.e = v[t + 1][c + 2];
                 q.sw = v[t + 2][c]; q.s = v[t + 2][c + 1]; q.se = v[t + 2][c + 2];
-                if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_cell(q, a.inv8cx, a.inv8cy);
-                if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_cell(q);
+                if (HORN) hs[o] = horn_cell(q);
+                if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_from_horn(hs[o], sk);
+                if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_from_horn(hs[o]);
                 if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
                 if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
             }
@@ -197,7 +203,7 @@ template <int OPS, int KH, int KW, int RB, bool NT, unsigned CMASK = 0u>
 #define XRS_LB_PASS 4
 #endif
 __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
-    const long t = xcd_tile(blockIdx.x, a.n_tiles);
+    const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -223,7 +229,7 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     constexpr int RB = XRS_PASS_RB;
     a.tiles_x = (a.cols + 255) / 256;
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
-    const long grid = xcd_grid(a.n_tiles);
+    const long grid = xcd_grid(a.n_tiles, a.tiles_x);
     if (grid > 0x7fffffffL) return fail("raster pass: raster too large for one launch");
     // circle_kernel(1, 1, 2): rows 00100 / 01110 / 11111 / 01110 / 00100
     constexpr unsigned CIRCLE5 = 4u | 14u << 5 | 31u << 10 | 14u << 15 | 4u << 20;

@@ -126,12 +126,12 @@ __global__ void __launch_bounds__(256) percell_kernel(const CellArgs q) {
 }
 
 // One-shot streaming variant for 16-byte aligned planes: workgroup b owns one contiguous 16 KiB chunk
-// (256 lanes x 4 float4) of every plane, chunks are dealt to the XCDs in contiguous runs
-// (xrs::xcd_tile), and a lane's four slots are a wave-interleaved 1 KiB apart so every load/store
+// (256 lanes x 4 float4) of every plane, chunks in launch order (XCDs interleaved chunk by chunk: one dense stream
+// through DRAM, xrs::xcd_tile), and a lane's four slots are a wave-interleaved 1 KiB apart so every load/store
 // instruction of a wave covers 1 KiB of consecutive addresses.  All loads are issued before the first use.
 template <int K>
 __global__ void __launch_bounds__(256) percell_chunk_kernel(const CellArgs q, const long n_chunks) {
-    const long chunk = xcd_tile(blockIdx.x, n_chunks);
+    const long chunk = xcd_tile(blockIdx.x, n_chunks, 1);
     if (chunk < 0) return;
     const long n4 = q.n >> 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -172,7 +172,7 @@ int launch(const CellArgs &q, hipStream_t s) {
     const char *variant = getenv("XRS_PERCELL_VARIANT");
     if (vec && !(variant && variant[0] == 'g')) {              // default: one-shot chunks ('g' = grid-stride, for A/B)
         const long n_chunks = ((q.n >> 2) + 1023) / 1024 > 0 ? ((q.n >> 2) + 1023) / 1024 : 1;
-        hipLaunchKernelGGL((percell_chunk_kernel<K>), dim3((unsigned)xcd_grid(n_chunks)), dim3(256), 0, s, q, n_chunks);
+        hipLaunchKernelGGL((percell_chunk_kernel<K>), dim3((unsigned)xcd_grid(n_chunks, 1)), dim3(256), 0, s, q, n_chunks);
         XRS_LAUNCH_CHECK();
         return 0;
     }

@@ -7,10 +7,11 @@ using namespace xrs;
 namespace {
 
 // Streaming copy in the library's own access pattern (one contiguous 16 KiB chunk per workgroup, four
-// wave-interleaved 16-byte slots per lane, chunks dealt to XCDs in contiguous runs): the "achievable copy
+// wave-interleaved 16-byte slots per lane, chunks in launch order -- round 1 dealt them to the XCDs in contiguous runs,
+// which measured 5-7 % slower, experiments/strip_floor.hip): the "achievable copy
 // bandwidth" calibration point that kernel roofline fractions are compared with (tools/kbench.py).
 __global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, float4 *dst, long n4, long n_chunks) {
-    const long chunk = xcd_tile(blockIdx.x, n_chunks);
+    const long chunk = xcd_tile(blockIdx.x, n_chunks, 1);
     if (chunk < 0) return;
     const long base = chunk * 1024 + (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
     float4 v[4];
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(256) copy_chunk_kernel(const float4 *src, floa
 struct MixArgs { const float4 *src; float4 *dst[8]; long n4, n_chunks; };
 template <int NW>
 __global__ void __launch_bounds__(256) stream_mix_kernel(const MixArgs a) {
-    const long chunk = xcd_tile(blockIdx.x, a.n_chunks);
+    const long chunk = xcd_tile(blockIdx.x, a.n_chunks, 1);
     if (chunk < 0) return;
     const long base = chunk * 1024 + (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
     float4 v[4];
@@ -98,7 +99,7 @@ int xrs_copy_f32(const float *src_dev, float *dst_dev, int64_t n, void *stream) 
     if (!aligned16(src_dev) || !aligned16(dst_dev) || (n & 3))
         return fail("xrs_copy_f32: planes must be 16-byte aligned with a multiple of 4 elements");
     const long n4 = n >> 2, n_chunks = (n4 + 1023) / 1024;
-    hipLaunchKernelGGL(copy_chunk_kernel, dim3((unsigned)xcd_grid(n_chunks)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(copy_chunk_kernel, dim3((unsigned)xcd_grid(n_chunks, 1)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(src_dev), reinterpret_cast<float4 *>(dst_dev), n4, n_chunks);
     XRS_LAUNCH_CHECK();
     return 0;
@@ -118,7 +119,7 @@ int xrs_stream_mix_f32(const float *src_dev, float *const *dsts_dev, int n_dst, 
     if (!aligned16(src_dev) || (n & 3)) return fail("xrs_stream_mix_f32: planes must be 16-byte aligned with a multiple of 4 elements");
     a.n4 = n >> 2;
     a.n_chunks = (a.n4 + 1023) / 1024;
-    const dim3 grid((unsigned)xcd_grid(a.n_chunks));
+    const dim3 grid((unsigned)xcd_grid(a.n_chunks, 1));
     hipStream_t s = as_stream(stream);
     switch (n_dst) {
         case 1: hipLaunchKernelGGL(stream_mix_kernel<1>, grid, dim3(256), 0, s, a); break;

@@ -17,8 +17,9 @@
 //     dwords (measured against an LDS-tile variant).
 //   * the NaN border is written by the same kernel (the reference pre-fills the
 //     output with NaN and overwrites the interior: twice the write traffic).
-//   * tiles are numbered row-major and dealt to XCDs in contiguous bands
-//     (xrs::xcd_tile) so vertically adjacent strips share an L2.
+//   * tiles are numbered row-major and dealt to the XCDs one tile ROW at a time
+//     (xrs::xcd_tile): horizontally adjacent strips share an L2, and all XCDs stream
+//     through the same rows of the raster together.
 // A scalar one-thread-per-cell kernel handles rasters whose width / pitch /
 // base address are not multiples of 16 bytes.
 #include "terrain_cells.h"
@@ -58,6 +59,13 @@ __device__ __forceinline__ void store_n(OutT *p, const float (&v)[4], int n) {
     for (int o = 0; o < 4; ++o)
         if (o < n) p[o] = (OutT)v[o];
 }
+
+#ifndef XRS_STRIP_WX
+#define XRS_STRIP_WX 1
+#endif
+#ifndef XRS_HORN_MODE
+#define XRS_HORN_MODE 1      // 1: Horn differences shared along the strip (HornRoller), 0: cell by cell
+#endif
 
 // ---------------------------------------------------------------- fast path
 // INTERIOR: wave-uniform fact that the wave's whole (RB+2) x 258 input window lies inside the raster
@@ -100,12 +108,20 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
     }
 
     const float qnan = nan_f32();
+    // slope / aspect: the strip's Horn sums, differences shared between its cells (terrain_cells.h)
+    constexpr bool HORN = (OPS & (OP_SLOPE | OP_ASPECT)) != 0;
+    const bool horn = HORN && ((a.out[0] && (OPS & OP_SLOPE)) || (a.out[1] && (OPS & OP_ASPECT)));   // wave-uniform
+    HornRoller roll;
+    if (horn && XRS_HORN_MODE == 1) roll.start(&v[0][0], &v[1][0]);
+    const SlopeK sk = slope_constants(a.inv8cx, a.inv8cy);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const long y = y0 + r;
         if (!INTERIOR && y >= a.rows) break;
         const bool row_border = !INTERIOR && ((y - 1 < y_lo) || (y + 1 >= y_hi));
         float o_slope[4], o_aspect[4], o_curv[4], o_hill[4];
+        Horn hs[4];
+        if (horn && XRS_HORN_MODE == 1) roll.step(&v[r + 2][0], hs);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const long x = x0 + o;
@@ -115,8 +131,9 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
             q.w = v[r + 1][o];  q.c = v[r + 1][o + 1]; q.e = v[r + 1][o + 2];
             q.sw = v[r + 2][o]; q.s = v[r + 2][o + 1]; q.se = v[r + 2][o + 2];
             // (a.out[i] tests are wave-uniform: the fused instantiation skips absent products)
-            if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_cell(q, a.inv8cx, a.inv8cy);
-            if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_cell(q);
+            if (HORN && XRS_HORN_MODE == 0) hs[o] = horn_cell(q);
+            if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_from_horn(hs[o], sk);
+            if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_from_horn(hs[o]);
             if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
             if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
         }
@@ -135,16 +152,24 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
     }
 }
 
+// slope / aspect stand-alone: 5 workgroups per CU (96 VGPRs; the allocator wants 104 and spills one address pair).  Same-box
+// A/B (tools/ab_terrain.sh, 16384^2): uncapped 0.410 / 0.423 ms, cap 5: 0.395 / 0.405, cap 6 (80 VGPRs, 24 spilled): 0.434 / 0.427;
+// Horn sums cell by cell (XRS_HORN_MODE=0, 85 VGPRs, no spill): 0.403 / 0.405; hillshade alongside: 0.377-0.389.
+#ifndef XRS_LB_HORN
+#define XRS_LB_HORN 5
+#endif
 template <int OPS, typename HillT, int RB>
-__global__ void __launch_bounds__(256) terrain_strip_kernel(const TerrainArgs a) {
-    const long tile = xcd_tile(blockIdx.x, a.n_tiles);
+__global__ void __launch_bounds__(256, (OPS == OP_SLOPE || OPS == OP_ASPECT) ? XRS_LB_HORN : 1) terrain_strip_kernel(const TerrainArgs a) {
+    const long tile = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (tile < 0) return;
     const long ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int lane = threadIdx.x & 63;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave index as a scalar
-    const long x_tile = tx * 256;
-    const long y0 = ty * (4 * RB) + (long)wy * RB;
-    if (y0 >= a.rows) return;
+    // the 4 waves of a workgroup: XRS_STRIP_WX side by side (256 columns each) x 4 / XRS_STRIP_WX stacked (RB rows each)
+    constexpr int WX = XRS_STRIP_WX, WY = 4 / WX;
+    const long x_tile = (tx * WX + (wy % WX)) * 256;
+    const long y0 = (ty * WY + (wy / WX)) * RB;
+    if (y0 >= a.rows || x_tile >= a.cols) return;
     const bool interior = x_tile >= 4 && x_tile + 256 + 4 <= a.cols &&
                           y0 - 1 >= -(long)a.halo_top && y0 + RB + 1 <= a.rows + a.halo_bot && y0 + RB <= a.rows;
     if (interior) {
@@ -196,10 +221,11 @@ int launch_strip(TerrainArgs &a, hipStream_t s) {
 
 template <int OPS, typename HillT, int RB>
 int launch_strip_rb(TerrainArgs &a, hipStream_t s) {
-    a.tiles_x = (a.cols + 255) / 256;
-    const long tiles_y = (a.rows + 4 * RB - 1) / (4 * RB);
+    constexpr int WX = XRS_STRIP_WX, WY = 4 / WX;
+    a.tiles_x = (a.cols + 256 * WX - 1) / (256 * WX);
+    const long tiles_y = (a.rows + WY * RB - 1) / (WY * RB);
     a.n_tiles = a.tiles_x * tiles_y;
-    const long grid = xcd_grid(a.n_tiles);
+    const long grid = xcd_grid(a.n_tiles, a.tiles_x);
     if (grid > 0x7fffffffL) return fail("terrain: raster too large for one launch");
     hipLaunchKernelGGL((terrain_strip_kernel<OPS, HillT, RB>), dim3((unsigned)grid), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();

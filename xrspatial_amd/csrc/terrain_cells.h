@@ -14,27 +14,54 @@ enum : int { OP_SLOPE = 1, OP_ASPECT = 2, OP_CURV = 4, OP_HILL = 8 };
 // 3x3 neighbourhood, n* = row y-1, s* = row y+1.
 struct Nb { float nw, n, ne, w, c, e, sw, s, se; };
 
-// ---- slope / aspect.  The Horn sums stay in float64 (the reference's arithmetic, exact for any data: an all-float32
-// "differences first + TwoSum" form -- horn3 below, XRS_TERRAIN_HORN32=1 -- is only exact while neighbouring cells are
-// within a factor 2 of each other, costs as many issue slots, and measured no faster: slope 0.43 vs 0.40 ms,
-// profiles/r02); what the library calls cost is the arc tangent: atanf / atan2f carry an exactly rounded division and,
-// for atan2f, a float64 rescaling -- replaced by v_rcp_f32 + a degree-7 polynomial (aspect 0.47 -> 0.42 ms).
-#ifndef XRS_TERRAIN_HORN32
-#define XRS_TERRAIN_HORN32 0
-#endif
+// ---- slope / aspect.  The Horn sums stay in float64, the reference's arithmetic (numba widens `2 * float32` to
+// float64): sums of float32 cells are exact there, for any data.  (An all-float32 "differences first + TwoSum" form is
+// only exact while neighbouring cells are within a factor 2 of each other, costs as many issue slots and measured no
+// faster: slope 0.43 vs 0.40 ms, profiles/r02.)  Differences first, so that a strip shares them between its cells:
+//   gx = (ne + 2e + se) - (nw + 2w + sw) = (ne - nw) + 2 (e - w) + (se - sw)     7 float64 operations per cell
+//   gy = (nw + 2n + ne) - (sw + 2s + se) = (nw - sw) + 2 (n - s) + (ne - se)     instead of 10 + 2 multiplies
+// Every path (strip, fused pass, cell-by-cell) evaluates exactly these operations in this order.
+struct Horn { double gx, gy; };
 
-// (p1 - m1) + 2 (p2 - m2) + (p3 - m3) in float32: differences first (exact between cells within a factor 2 of each
-// other -- Sterbenz), the first addition made error-free (TwoSum) and its error added back at the end.
-__device__ __forceinline__ float horn3(float p1, float m1, float p2, float m2, float p3, float m3) {
-#pragma clang fp contract(off)
-#pragma clang fp reassociate(off)
-    const float a1 = p1 - m1, a2 = p2 - m2, a3 = p3 - m3;
-    const float b = a2 + a2;
-    const float s = a1 + b;
-    const float bb = s - a1;
-    const float e = (a1 - (s - bb)) + (b - bb);          // a1 + b = s + e exactly
-    return (s + a3) + e;
+__device__ __forceinline__ Horn horn_cell(const Nb &q) {
+    const double h0 = (double)q.ne - (double)q.nw, h1 = (double)q.e - (double)q.w, h2 = (double)q.se - (double)q.sw;
+    const double g0 = (double)q.nw - (double)q.sw, g1 = (double)q.n - (double)q.s, g2 = (double)q.ne - (double)q.se;
+    Horn r;
+    r.gx = fma(2.0, h1, h0) + h2;
+    r.gy = fma(2.0, g1, g0) + g2;
+    return r;
 }
+
+// The Horn sums of a strip, one output row of 4 cells at a time, from the rows of the strip's registers (`row` points at
+// the cell one column left of the lane's first output cell): the float64 images of the last two rows and their
+// east - west differences roll along, so a row costs 6 conversions + 4 + 6 + 16 float64 operations (7 operations and
+// 1.5-2.25 conversions per cell) and 20 live doubles -- computing the whole block up front cost 20-70 more VGPRs and an
+// occupancy step in every kernel that uses it.
+struct HornRoller {
+    double dn[6], dc[6], hn[4], hc[4];
+    __device__ __forceinline__ void start(const float *north, const float *centre) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { dn[i] = (double)north[i]; dc[i] = (double)centre[i]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { hn[o] = dn[o + 2] - dn[o]; hc[o] = dc[o + 2] - dc[o]; }
+    }
+    // `south`: the row below the output row; afterwards the roller stands one row further down
+    __device__ __forceinline__ void step(const float *south, Horn (&out)[4]) {
+        double ds[6], hs[4], g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { ds[i] = (double)south[i]; g[i] = dn[i] - ds[i]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            hs[o] = ds[o + 2] - ds[o];
+            out[o].gx = fma(2.0, hc[o], hn[o]) + hs[o];
+            out[o].gy = fma(2.0, g[o + 1], g[o]) + g[o + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { dn[i] = dc[i]; dc[i] = ds[i]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { hn[o] = hc[o]; hc[o] = hs[o]; }
+    }
+};
 
 // atan(z) for 0 <= z <= 1, float32: z + z t p(t), t = z^2, p of degree 7 fitted to (atan(z)/z - 1)/t on [0, 1]
 // (8.3e-8 relative in float32 evaluation, checked against float64 on 2e6 points)
@@ -71,47 +98,59 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
     return __builtin_isunordered(x, y) ? nan_f32() : r;  // (fmax / fmin skip a NaN operand)
 }
 
-__device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double inv8cy) {
-#pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically
-#if XRS_TERRAIN_HORN32
-    const float fx = horn3(q.se, q.sw, q.e, q.w, q.ne, q.nw) * (float)inv8cx;
-    const float fy = horn3(q.nw, q.sw, q.n, q.s, q.ne, q.se) * (float)inv8cy;
-#else
-    // slope.py:64-75: a,b,c = row y+1; g,h,i = row y-1; sums in float64.
-    const double dx = ((((double)q.se + 2.0 * (double)q.e) + (double)q.ne) -
-                       (((double)q.sw + 2.0 * (double)q.w) + (double)q.nw)) * inv8cx;
-    const double dy = ((((double)q.nw + 2.0 * (double)q.n) + (double)q.ne) -
-                       (((double)q.sw + 2.0 * (double)q.s) + (double)q.se)) * inv8cy;
-    const float fx = (float)dx, fy = (float)dy;
-#endif
-    // Hardware square root (v_sqrt_f32, <= 1 ulp: 6e-8 relative against a 1e-5 parity bar) instead of the correctly
-    // rounded library sequence: the kernel is VALU-bound.  v_sqrt_f32 flushes denormal inputs, so the argument is
-    // scaled by 2^64 (exact) and the root by 2^-32: squares down to the smallest denormal stay exact, and squares
-    // above 2^64 (gradient > 4e9, where the slope already rounds to 90 degrees from 1.5e7 on) become inf -> 90.
-    const float r = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) * 0x1p64f) * 0x1p-32f;
-    return atan_pos(r) * 57.29578f;
+// Constants of slope: 2^32 / (8 cellsize) in float32 (the 2^32 keeps the squares below away from the denormals)
+struct SlopeK { float kx, ky; };
+__device__ __forceinline__ SlopeK slope_constants(double inv8cx, double inv8cy) {
+    SlopeK k;
+    k.kx = (float)(inv8cx * 0x1p32);
+    k.ky = (float)(inv8cy * 0x1p32);
+    return k;
 }
 
-__device__ __forceinline__ float aspect_cell(const Nb &q) {
+// slope.py:64-75: atan(sqrt(dz_dx^2 + dz_dy^2)) in degrees.  ONE transcendental: with s = 2^64 (dz_dx^2 + dz_dy^2) and
+// q = v_rsq_f32(s) (1 ulp), the arc tangent's argument folded into [0, 1] is  z = sqrt(s) 2^-32 = s q 2^-32  below 45
+// degrees and  1 / (sqrt(s) 2^-32) = q 2^32  above (atan x = 90 - atan 1/x).  Gradients above 4e9 (s = inf, q = 0) give 90,
+// where the float32 result has rounded to 90 since 1.5e7; below 2.5e-29 (s denormal, flushed by v_rsq) they give at most
+// 1.4e-27 degrees.  atan: atan_unit's polynomial with the radian -> degree factor D folded into the coefficients,
+// D atan(z) = z (D + t D p(t)).
+__device__ __forceinline__ float slope_from_horn(const Horn &g, const SlopeK &k) {
 #pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically
-#if XRS_TERRAIN_HORN32
-    const float fx = horn3(q.ne, q.nw, q.e, q.w, q.se, q.sw);
-    const float fy = horn3(q.sw, q.nw, q.s, q.n, q.se, q.ne);
+    const float a = (float)g.gx * k.kx, b = (float)g.gy * k.ky;
+    const float s = fmaf(a, a, b * b);
+    const float q = __builtin_amdgcn_rsqf(s);
+    const bool steep = s > 0x1p64f;
+    const float m = s * __builtin_fminf(q, 0x1p63f);         // (s = 0: 0 * 2^63, not 0 * inf)
+    const float z = (steep ? q : m) * (steep ? 0x1p32f : 0x1p-32f);
+    const float t = z * z;
+    float p = 2.920402046e-03f * 57.29577951f;
+    p = fmaf(p, t, -1.636684009e-02f * 57.29577951f);
+    p = fmaf(p, t, 4.321022630e-02f * 57.29577951f);
+    p = fmaf(p, t, -7.552088772e-02f * 57.29577951f);
+    p = fmaf(p, t, 1.066595276e-01f * 57.29577951f);
+    p = fmaf(p, t, -1.421104430e-01f * 57.29577951f);
+    p = fmaf(p, t, 1.999377186e-01f * 57.29577951f);
+    p = fmaf(p, t, -3.333315272e-01f * 57.29577951f);
+    const float r = z * fmaf(p, t, 57.29577951f);           // z (D + t D p(t)) = D atan(z)
+    return steep ? 90.0f - r : r;
+}
+
+__device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double inv8cy) {
+    return slope_from_horn(horn_cell(q), slope_constants(inv8cx, inv8cy));
+}
+
+// aspect.py:66-88: compass = 90 - atan2(dy, -dx) wrapped to [0, 360) == atan2(-dx, dy) wrapped, with dx = gx / 8 and
+// dy = -gy / 8: the arc tangent does not see the common factor, and evaluating it this way keeps full relative accuracy
+// near 0 degrees.  Flat cells (both sums zero; a float64 sum of float32 cells that is not zero is at least 2^-149, which
+// float32 holds) are -1.
+__device__ __forceinline__ float aspect_from_horn(const Horn &g) {
+#pragma clang fp contract(off)
+    const float fx = (float)g.gx, fy = (float)g.gy;
     if (fx == 0.0f && fy == 0.0f) return -1.0f;
-#else
-    // aspect.py:66-88: a,b,c = row y-1; g,h,i = row y+1; /8; float64 flat test.
-    const double dx = ((((double)q.ne + 2.0 * (double)q.e) + (double)q.se) -
-                       (((double)q.nw + 2.0 * (double)q.w) + (double)q.sw)) * 0.125;
-    const double dy = ((((double)q.sw + 2.0 * (double)q.s) + (double)q.se) -
-                       (((double)q.nw + 2.0 * (double)q.n) + (double)q.ne)) * 0.125;
-    if (dx == 0.0 && dy == 0.0) return -1.0f;
-    const float fx = (float)dx, fy = (float)dy;
-#endif
-    // compass = 90 - atan2(dy, -dx) wrapped to [0, 360)  ==  atan2(-dx, dy) wrapped:
-    // evaluating it this way keeps full relative accuracy near 0 degrees.
-    const float deg = atan2_fast(-fx, fy) * 57.29577951308232f;
+    const float deg = atan2_fast(-fx, -fy) * 57.29577951308232f;
     return deg < 0.0f ? deg + 360.0f : deg;
 }
+
+__device__ __forceinline__ float aspect_cell(const Nb &q) { return aspect_from_horn(horn_cell(q)); }
 
 __device__ __forceinline__ float curvature_cell(const Nb &q, double scale) {
 #pragma clang fp contract(off)   // every instantiation (stand-alone, fused, edge path) rounds identically

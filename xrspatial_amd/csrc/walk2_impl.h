@@ -306,7 +306,7 @@ template <int R>
 __global__ void __launch_bounds__(256, 2) XRS_WALK_KERNEL(const WalkGeom g, const WalkOuts o) {
     using C = Walk2Cfg<R, XRS_WALK_SHAPE>;
     __shared__ __attribute__((aligned(16))) char lds_rows[4][C::STG * 12];
-    const long t = xcd_tile(blockIdx.x, g.n_tiles);
+    const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
     if (t < 0) return;
     const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
     const int lane = threadIdx.x & 63;
@@ -338,7 +338,7 @@ int launch2(WalkGeom &g, const WalkOuts &o, const double *kernel, hipStream_t s)
     if (!is_shape<R, XRS_WALK_SHAPE>(kernel)) return -1;
     g.tiles_x = (g.cols + 255) / 256;
     g.n_tiles = g.tiles_x * ((g.rows + W2TH - 1) / W2TH);
-    const long grid = xcd_grid(g.n_tiles);
+    const long grid = xcd_grid(g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
     if (grid > 0x7fffffffL) return fail("focal statistics: raster too large for one launch");
     hipLaunchKernelGGL((XRS_WALK_KERNEL<R>), dim3((unsigned)grid), dim3(256), 0, s, g, o);
     XRS_LAUNCH_CHECK();

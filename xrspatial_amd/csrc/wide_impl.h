@@ -373,7 +373,7 @@ template <int R, typename Shape, bool SUM>
 __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const WideArgs a) {
     using C = WideCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float lds_rows[4][C::LDS_WAVE];
-    const long gidx = xcd_tile(blockIdx.x, a.n_groups);
+    const long gidx = xcd_tile(blockIdx.x, a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
     if (gidx < 0) return;
     const long ty = gidx / a.groups_x, gx = gidx - ty * a.groups_x;
     const int lane = threadIdx.x & 63;
@@ -412,7 +412,7 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;
-    const long grid = xcd_grid(a.n_groups);
+    const long grid = xcd_grid(a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
     if (out_mean) {
         a.out = out_mean;

@@ -44,18 +44,43 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// blockIdx -> tile index so that each XCD owns one contiguous run of tiles.
-// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed,
-// used for speed only): with tiles numbered row-major, XCD k then streams through
-// its own horizontal band of the raster and every halo row / halo column it
-// re-reads was fetched into ITS L2 by a neighbouring tile.  Returns -1 for the
-// (< 8) surplus blocks of the padded grid.
-__device__ __forceinline__ long xcd_tile(long block, long n_tiles) {
-    const long per_xcd = (n_tiles + 7) >> 3;
-    const long t = (block & 7) * per_xcd + (block >> 3);
-    return ((block >> 3) < per_xcd && t < n_tiles) ? t : -1;
+// blockIdx -> tile index.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed, used for
+// speed only).  Tiles are numbered row-major and handed out in groups of `unit` consecutive tiles -- one tile ROW for
+// the 2-D kernels (unit = tiles_x): XCD k takes tile rows k, k + 8, ...  All eight XCDs then walk through the same
+// few rows of the raster at the same time (one dense stream through DRAM), and the halo COLUMNS a tile re-reads were
+// fetched into its own L2 by its left / right neighbours; the halo ROWS between tile rows are fetched by two L2s
+// (2 rows in 16 for the 3x3 strip kernels: +6 % traffic at the L2 <-> fabric counters).  Round 1 gave every XCD one
+// contiguous band of the raster instead (all halos in one L2, traffic == algorithmic bytes) -- eight streams 1/8 of the
+// raster apart, and 4-7 % slower on every strip kernel (experiments/strip_floor.hip: 0.352 vs 0.328 ms for the loading
+// pattern of the 3x3 kernels; groups of 2 / 4 / 8+ tile rows: 0.332 / 0.340 / 0.35).  unit = 1: launch order.
+// Returns -1 for the surplus blocks of the padded grid.
+// unit = 0: the round-1 order, one contiguous band of tiles per XCD -- kept for the column walkers (circle_walk.h,
+// walk2_impl.h, wide_impl.h: tall tiles, 100+ rows each; same-box A/B 3-6 % faster in bands) and, unmeasured, the
+// LDS-tile kernels.
+__device__ __forceinline__ long xcd_tile(long block, long n_tiles, long unit) {
+    if (unit == 0) {
+        const long per_xcd = (n_tiles + 7) >> 3;
+        const long t = (block & 7) * per_xcd + (block >> 3);
+        return ((block >> 3) < per_xcd && t < n_tiles) ? t : -1;
+    }
+    const unsigned xcd = (unsigned)block & 7u, j = (unsigned)(block >> 3), u = (unsigned)unit;
+    const unsigned grp = j / u, within = j - grp * u;
+    const long t = ((long)grp * 8 + xcd) * unit + within;
+    return t < n_tiles ? t : -1;
 }
-inline long xcd_grid(long n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
+inline long xcd_grid(long n_tiles, long unit) {
+    if (unit == 0) return ((n_tiles + 7) >> 3) << 3;
+    const long groups = (n_tiles + unit - 1) / unit;
+    return (((groups + 7) >> 3) << 3) * unit;
+}
+// which order a kernel family uses (compile-time, the same expression on the host and in the kernel)
+#ifndef XRS_XCD_WALK
+#define XRS_XCD_WALK 0          // column walkers: bands
+#endif
+#ifndef XRS_XCD_LDS
+#define XRS_XCD_LDS 0           // LDS-tile window kernels, run kernels, geodesic: bands (as measured in round 1)
+#endif
+#define XCD_UNIT(rows, tiles_x) ((rows) ? (long)(tiles_x) : 0L)
 
 __device__ __forceinline__ float nan_f32() { return __int_as_float(0x7fc00000); }
 

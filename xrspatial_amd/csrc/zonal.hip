@@ -293,7 +293,7 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     const long cap = 256L * 8;                                   // 8 chunks per CU
     if (grid > cap) grid = cap;
     if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
-    grid = xcd_grid(grid);                                       // multiple of 8: chunk <-> XCD mapping is a bijection
+    grid = xcd_grid(grid, 1);                                       // multiple of 8: chunk <-> XCD mapping is a bijection
     hipStream_t s = as_stream(stream);
     for (int base = 0; base < n_zones; base += window) {
         const int nzw = n_zones - base < window ? n_zones - base : window;

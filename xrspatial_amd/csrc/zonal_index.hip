@@ -196,7 +196,7 @@ inline unsigned grid_for(long n) {
     long g = (n / 4 + 255) / 256;
     const long cap = 2048;                            // 8 chunks per CU
     g = g > cap ? cap : (g < 1 ? 1 : g);
-    return (unsigned)xcd_grid(g);                     // multiple of 8: chunk <-> XCD mapping is a bijection
+    return (unsigned)xcd_grid(g, 1);                     // multiple of 8: chunk <-> XCD mapping is a bijection
 }
 
 template <typename T>

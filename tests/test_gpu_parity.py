@@ -443,6 +443,41 @@ def test_flat_windows_have_exactly_zero_variance():
 
 
 @pytest.mark.parametrize("shape_kind", ["circle", "box"])
+@pytest.mark.parametrize("radius", [3, 6, 12])
+def test_uniform_weight_convolution_wide_walker(radius, shape_kind):
+    """The float32 fast path of the same case (wide_impl.h, WIDE_CONV): a raster of several tiles, most of them clean --
+    interior and edge tiles stay on the fast path, the tiles that can see one of the few non-finite cells (also through
+    a zero-weight corner of the square window, also from a neighbouring tile's halo) are redone by the exact walker --
+    against the oracle and against round 1's float64 column walker."""
+    K = 2 * radius + 1
+    mask = circle_kernel(1, 1, radius) if shape_kind == "circle" else np.ones((K, K))
+    k = mask / mask.sum()
+    z = synth.smooth_dem((700, 1500), seed=40 + radius)
+    rng = np.random.default_rng(radius)
+    for _ in range(4):
+        z[rng.integers(0, 700), rng.integers(0, 1500)] = np.nan
+    z[300, 700] = np.inf
+    # tile corners: wave tiles are 256 columns wide and 128 + (0..4) rows tall; a cell diagonally outside a tile
+    for ty in (128, 129, 130, 131, 132):
+        z[ty - radius, 512 - radius] = np.nan
+    with np.errstate(all='ignore'):
+        want = corc.convolve_2d(z, k, nthreads=8)
+    got = convolve_2d(z, k)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=0, equal_nan=True)
+    parity_log.record('700x1500', f'convolve_2d uniform {shape_kind} {K}x{K}', got, want)
+    os.environ['XRS_CONV_GEN'] = '1'
+    try:
+        gen1 = convolve_2d(z, k)
+    finally:
+        del os.environ['XRS_CONV_GEN']
+    np.testing.assert_allclose(got, gen1, rtol=2e-6, atol=0, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    # values straddling zero: the error guard sends such tiles to the float64 walker
+    z2 = (synth.smooth_dem((300, 1100), seed=3) - 2000.0).astype(np.float32)
+    np.testing.assert_allclose(convolve_2d(z2, k), corc.convolve_2d(z2, k, nthreads=8), rtol=1e-5, atol=1e-4, equal_nan=True)
+
+
+@pytest.mark.parametrize("shape_kind", ["circle", "box"])
 @pytest.mark.parametrize("radius", [3, 4, 7, 12])
 def test_uniform_weight_convolution_column_walker(radius, shape_kind):
     """convolve_2d with one weight value on a circle / box (normalised circle_kernel, np.ones / k^2 -- what

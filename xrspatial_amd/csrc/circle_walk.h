@@ -426,18 +426,12 @@ struct WalkConv {
     }
 };
 
+// the conv walker over output rows [y0, y_end) of the 64 columns starting at xw (wave-uniform)
 template <int R, typename Shape>
-__device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, double w, const double *weights) {
+__device__ __forceinline__ void walk_conv_columns(const WalkGeom &g, float *out, double w, const double *weights, long xw,
+                                                  int lane, long y0, long y_end) {
     constexpr int K = 2 * R + 1;
-    const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
-    if (t < 0) return;
-    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long xw = tx * 256 + wv * 64;
     const long x = xw + lane;
-    const long y0 = ty * CTH;
-    const long y_end = (y0 + CTH < g.rows ? y0 + CTH : g.rows);
     if (xw >= g.cols) return;
     WalkConv<R, Shape> c;
     c.init(g, y0, x);
@@ -454,6 +448,17 @@ __device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, do
     };
     if (xw >= R && xw + 64 + R <= g.cols) walk(std::false_type{});
     else walk(std::true_type{});
+}
+
+template <int R, typename Shape>
+__device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, double w, const double *weights) {
+    const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));
+    if (t < 0) return;
+    const long ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long y0 = ty * CTH;
+    walk_conv_columns<R, Shape>(g, out, w, weights, tx * 256 + wv * 64, lane, y0, y0 + CTH < g.rows ? y0 + CTH : g.rows);
 }
 
 // host: does `kernel` put ONE weight value on exactly the cells of the shape (zero elsewhere)?

@@ -1058,12 +1058,19 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     XRS_HIP(hipMemcpyAsync(work_dev, kernel, (size_t)krows * kcols * sizeof(double), hipMemcpyHostToDevice, s));
     a.weights = static_cast<const double *>(work_dev);
     if (krows >= 7 && !getenv("XRS_CONV_TAPS")) {
-        // one weight value on a circle / box (normalised circle_kernel, np.ones / k^2): column walker
-        int rc = try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top,
-                                        halo_bot, s);
+        // one weight value on a circle / box (normalised circle_kernel, np.ones / k^2): the wide row walker (wide_impl.h,
+        // float32 on shifted values, guarded); XRS_CONV_GEN=1: round 1's float64 column walker (A/B)
+        const char *gen = getenv("XRS_CONV_GEN");
+        const bool gen1 = gen && gen[0] == '1';
+        int rc = gen1 ? try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
+                                               halo_top, halo_bot, s)
+                      : try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
+                                                    halo_top, halo_bot, s);
         if (rc < 0)
-            rc = try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top,
-                                     halo_bot, s);
+            rc = gen1 ? try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
+                                            halo_top, halo_bot, s)
+                      : try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
+                                                 halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     a.tiles_x = (cols + TW - 1) / TW;

@@ -45,7 +45,9 @@ namespace {
 
 struct WideArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
-    float *out;                   // the mean, or the window sum (template parameter of the kernel)
+    float *out;                   // the mean, the window sum, or the convolution (template parameter of the kernel)
+    double wgt;                   // convolution: the one weight value of the kernel ...
+    const double *weights;        // ... and the whole (2R+1)^2 kernel in device memory (exact path)
     long n_groups;                // workgroups = groups of 4 horizontally adjacent wave tiles
     long groups_x;
 };
@@ -117,9 +119,14 @@ __device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
 }
 
 // EDGE = false: a full tile whose whole input window lies inside the raster (no predicates, see the header);
-// EDGE = true: everything else (predicated loads / stores, clipped counts, partial tiles).  SUM: emit the window sum.
-template <int R, typename Shape, bool EDGE, bool SUM>
+// EDGE = true: everything else (predicated loads / stores, clipped counts, partial tiles).
+// MODE: what is emitted -- the mean, the window sum, or convolve_2d with ONE weight value on the mask (convolution.py:285-313:
+// w * sum over the full window, NaN within R cells of the raster edge, and NaN whenever the SQUARE window holds a
+// non-finite cell, zero weights included: any non-finite cell among those the tile reads sends the tile to the exact walker).
+enum : int { WIDE_MEAN = 0, WIDE_SUM = 1, WIDE_CONV = 2 };
+template <int R, typename Shape, bool EDGE, int MODE>
 struct WideWalk {
+    static constexpr bool SUM = MODE == WIDE_SUM, CONV = MODE == WIDE_CONV;
     using C = WideCfg<R, Shape>;
     static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW;
 
@@ -139,6 +146,7 @@ struct WideWalk {
     long x_tile, y0, y_end, y_first;
     int n_in, lane;
     float c;                       // the shift
+    float wgt;                     // CONV: the weight
     float n_full[NC];              // EDGE: cell count of a window whose rows are all inside, per owned column
 
     __device__ __forceinline__ WideWalk(const WalkGeom &g_, float *out_, float *lds_, long xt, long y0_, long ye, int lane_)
@@ -279,6 +287,7 @@ struct WideWalk {
             // ---- lane-local prefix sums: P[k] = w[0] + .. + w[k]; cell o's centre is w[HL + o]
 #pragma unroll
             for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
+            if (CONV) bad |= !isfinite(w[NV - 1]);            // the lanes' totals cover every cell the tile read in this row
             // ---- every distinct half-width once, into the ring slots of the output rows that see this row with it
 #pragma unroll
             for (int h = 0; h <= R; ++h) {
@@ -308,12 +317,22 @@ struct WideWalk {
 #pragma unroll
             for (int o = 0; o < NC; ++o) {
                 float n = (float)C::NTAPS;
-                if (EDGE) {
+                if (EDGE && !CONV) {
                     const bool rows_in = yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot;   // wave-uniform
                     n = rows_in ? n_full[o]
                                 : (float)clipped_count<R, Shape>(yo, xo + o, -(long)g.halo_top, g.rows + g.halo_bot, g.cols);
                 }
                 const float s = acc[DONE][o];
+                if (CONV) {
+                    // full windows only: NaN within R cells of the raster (or shard halo) edge
+                    const bool full = !EDGE || (yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot &&
+                                                xo + o - R >= 0 && xo + o + R < g.cols);
+                    const float m = fmaf(s, 1.0f / (float)C::NTAPS, c);
+                    res[o] = full ? wgt * fmaf((float)C::NTAPS, c, s) : nan_f32();
+                    bad |= !isfinite(s);
+                    if (full) mmin = fminf(mmin, fabsf(m));
+                    continue;
+                }
                 const float m = EDGE ? c + s / n : fmaf(s, 1.0f / (float)C::NTAPS, c);
                 res[o] = SUM ? fmaf(n, c, s) : m;
                 bad |= !isfinite(s);
@@ -366,7 +385,7 @@ struct WideWalk {
     }
 };
 
-template <int R, typename Shape, bool SUM>
+template <int R, typename Shape, int MODE>
 #ifndef XRS_WIDE_WAVES
 #define XRS_WIDE_WAVES 2
 #endif
@@ -387,13 +406,22 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
                           y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
     bool ok;
     if (interior) {
-        WideWalk<R, Shape, false, SUM> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+        WideWalk<R, Shape, false, MODE> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+        w.wgt = (float)a.wgt;
         ok = w.run();
     } else {
-        WideWalk<R, Shape, true, SUM> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+        WideWalk<R, Shape, true, MODE> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+        w.wgt = (float)a.wgt;
         ok = w.run();
     }
     if (ok) return;
+    constexpr bool SUM = MODE == WIDE_SUM;
+    if (MODE == WIDE_CONV) {
+        // a non-finite cell in reach, or sums too ill-conditioned for float32: the float64 conv walker (tap by tap, in the
+        // reference's order, where a window holds a non-finite cell)
+        for (int q = 0; q < C::NC; ++q) walk_conv_columns<R, Shape>(g, a.out, a.wgt, a.weights, x_tile + 64 * q, lane, y0, y_end);
+        return;
+    }
     // non-finite cells under a window, or sums too ill-conditioned for float32: the float64 column walker (NaN-skipping,
     // counting; mean from float64 sums, the sum with the reference's sequential float32 adds), 64 columns at a time
     const WalkOuts o = {SUM ? a.out : nullptr, nullptr, nullptr, nullptr, SUM ? nullptr : a.out, nullptr, nullptr};
@@ -416,15 +444,47 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
     if (out_mean) {
         a.out = out_mean;
-        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_MEAN>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
     if (out_sum) {
         a.out = out_sum;
-        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_SUM>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
     return 0;
+}
+
+template <int R, typename Shape>
+int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double *weights_dev, hipStream_t s) {
+    using C = WideCfg<R, Shape>;
+    if (!is_uniform_shape<R, Shape>(kernel, &a.wgt)) return -1;
+    WalkGeom &g = a.g;
+    g.tiles_x = (g.cols + C::TW - 1) / C::TW;
+    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
+    g.n_tiles = g.tiles_x * tiles_y;
+    a.groups_x = (g.tiles_x + 3) / 4;
+    a.n_groups = a.groups_x * tiles_y;
+    a.weights = weights_dev;
+    a.out = out;
+    const long grid = xcd_grid(a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
+    if (grid > 0x7fffffffL) return fail("convolve_2d: raster too large for one launch");
+    hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_CONV>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int dispatch_wide_conv(WideArgs &a, float *out, const double *kernel, const double *weights_dev, int r, hipStream_t s) {
+    switch (r) {
+#define XRS_WIDE_CASE(RR) case RR: return launch_wide_conv<RR, XRS_WIDE_SHAPE>(a, out, kernel, weights_dev, s);
+#ifndef XRS_WIDE_PROBE
+        XRS_WIDE_CASE(3) XRS_WIDE_CASE(4) XRS_WIDE_CASE(5) XRS_WIDE_CASE(6) XRS_WIDE_CASE(7) XRS_WIDE_CASE(8)
+        XRS_WIDE_CASE(9) XRS_WIDE_CASE(10) XRS_WIDE_CASE(11)
+#endif
+        XRS_WIDE_CASE(12)
+#undef XRS_WIDE_CASE
+        default: return -1;
+    }
 }
 
 int dispatch_wide(WideArgs &a, float *out_mean, float *out_sum, const double *kernel, int r, hipStream_t s) {
@@ -455,6 +515,18 @@ int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_sum, long rows, 
     a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
     return dispatch_wide(a, out_mean, out_sum, kernel, krows / 2, s);
+}
+
+// convolve_2d with one weight value on this shape (normalised circle_kernel / np.ones): 0 = launched, -1 = not that,
+// > 0 = error.  `weights_dev`: the kernel as float64 in device memory, for windows that hold a non-finite cell.
+int XRS_WIDE_CONV_ENTRY(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
+                        const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
+    if (krows != kcols || !(krows & 1)) return -1;
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
+    a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
+    return dispatch_wide_conv(a, out, kernel, weights_dev, krows / 2, s);
 }
 
 }  // namespace xrs

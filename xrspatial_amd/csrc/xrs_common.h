@@ -222,6 +222,11 @@ int try_launch_focal_wide_circle(const float *in, float *out_mean, float *out_su
 int try_launch_focal_wide_box(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in,
                               long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
                               hipStream_t s);
+// the same TUs: convolve_2d with one weight value on a circle / box of radius 3..12 cells (WIDE_CONV)
+int try_launch_conv_wide_circle(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
+                                const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_conv_wide_box(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
+                             const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 // kxk_circle2.hip / kxk_box2.hip: all seven statistics in one pass, radius 4..12 cells (walk2_impl.h).
 int try_launch_focal_circle2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
                              float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,

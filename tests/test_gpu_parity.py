@@ -413,6 +413,39 @@ def test_wide_row_walker_paths():
         np.testing.assert_allclose(o_mean.get(), want[first:first + n], rtol=1e-6)
 
 
+def test_large_window_statistic_subsets():
+    """Subsets of the seven statistics on 9x9 .. 25x25 masks run the one-pass walker with only the pass they need
+    (walk2_impl.h: extrema only, moments only, both): every subset against the oracle, on clean tiles (fast path), tiles
+    with NaN cells, a block of NaN wider than the window (all-NaN windows: NaN for every statistic, like nanmax / nanmean),
+    +-inf cells and a constant region (exactly zero variance)."""
+    from xrspatial_amd import focal as xfocal
+    subsets = (['max'], ['min', 'range'], ['max', 'min', 'range'], ['std'], ['mean', 'var'], ['sum', 'std'], ['var', 'std', 'mean', 'sum'],
+               ['max', 'std'])
+    for radius, kind, shape in ((12, 'circle', (300, 700)), (5, 'circle', (270, 600)), (4, 'box', (150, 330))):
+        K = 2 * radius + 1
+        k = circle_kernel(1, 1, radius) if kind == 'circle' else np.ones((K, K))
+        z = synth.smooth_dem(shape, seed=radius)
+        z[40:40 + 2 * K + 3, 300:300 + 2 * K + 5] = np.nan          # windows without any valid cell
+        z[shape[0] // 2 + 15, 100] = np.nan
+        z[10, 20] = np.inf
+        z[shape[0] // 2 - 10, 500 if shape[1] > 520 else 250] = -np.inf
+        z[shape[0] - 60:, :200] = 77.25                              # flat: var == std == 0 exactly
+        with np.errstate(all='ignore'):
+            want = {st: corc.focal_apply(z, k, st, nthreads=8) for st in ('mean', 'max', 'min', 'range', 'std', 'var', 'sum')}
+        for names in subsets:
+            got = focal_stats(raster(z), k, stats_funcs=names).data
+            for i, st in enumerate(names):
+                np.testing.assert_allclose(got[i], want[st], rtol=2e-6 if st != 'sum' else 1e-5, atol=0, equal_nan=True,
+                                           err_msg=f"{kind} r={radius} {names} -> {st}")
+                parity_log.record(f'{shape[0]}x{shape[1]}', f'focal_stats {kind}{K} subset {st}', got[i], want[st])
+        for st, fn in (('max', xfocal._calc_max), ('min', xfocal._calc_min), ('range', xfocal._calc_range), ('std', xfocal._calc_std),
+                       ('var', xfocal._calc_var)):
+            np.testing.assert_allclose(apply(raster(z), k, func=fn).data, want[st], rtol=2e-6, atol=0, equal_nan=True,
+                                       err_msg=f"apply {kind} r={radius} {st}")
+        flat = focal_stats(raster(z), k, stats_funcs=['var', 'std']).data[:, shape[0] - 60 + radius:shape[0], :200 - radius]
+        assert (flat == 0).all()
+
+
 def test_flat_windows_have_exactly_zero_variance():
     """A window over equal cells: the reference divides sum by count exactly, so mean == the cell value and
     var == std == 0 exactly -- for every kernel family (3x3 / 5x5 register strips, 7x7 LDS tile, large masks through

@@ -1132,13 +1132,24 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         // several statistics: all of them from one pass of the second-generation column walker (walk2_impl.h); a
         // sequential `sum` comes from its own kernel
         float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
-        int rc = try_launch_focal_circle2(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE],
-                                          a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in,
-                                          ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
-        if (rc < 0)
-            rc = try_launch_focal_box2(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE],
-                                       a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in,
-                                       ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        // only the passes the request needs: extrema (max / min / range), moments (mean / var / std / sum), or both
+        const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
+        const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
+        typedef int (*Walk2Fn)(const float *, float *, float *, float *, float *, float *, float *, float *, long, long, long,
+                               long, const double *, int, int, int, int, hipStream_t);
+        const Walk2Fn circle = want_mm && want_mom ? try_launch_focal_circle2
+                               : want_mm ? try_launch_focal_circle2_mm : try_launch_focal_circle2_mom;
+        const Walk2Fn box = want_mm && want_mom ? try_launch_focal_box2 : want_mm ? try_launch_focal_box2_mm : try_launch_focal_box2_mom;
+        int rc = 0;
+        if (want_mm || want_mom) {
+            rc = circle(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN],
+                        a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                        halo_bot, s);
+            if (rc < 0)
+                rc = box(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN],
+                         a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                         halo_bot, s);
+        }
         if (rc > 0) return rc;
         if (rc == 0) {
             if (!(seq_sum && a.out[XRS_STAT_SUM])) return 0;

@@ -159,7 +159,7 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
 #define XRS_LB_HORN 5
 #endif
 template <int OPS, typename HillT, int RB>
-__global__ void __launch_bounds__(256, (OPS == OP_SLOPE || OPS == OP_ASPECT) ? XRS_LB_HORN : 1) terrain_strip_kernel(const TerrainArgs a) {
+__global__ void __launch_bounds__(256, ((OPS == OP_SLOPE || OPS == OP_ASPECT) && RB == 4) ? XRS_LB_HORN : 1) terrain_strip_kernel(const TerrainArgs a) {
     const long tile = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (tile < 0) return;
     const long ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;

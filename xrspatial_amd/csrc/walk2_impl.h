@@ -22,7 +22,12 @@
 //     exactly rounded sum, always within that bound of the reference and within 1e-5 relative whenever the window does
 //     not cancel.  XRS_FOCAL_SUM=sequential selects the bit-exact sequential kernel (kxk_circle.hip) instead.
 //   * max / min / range: running extrema over centred runs (v_min3 / v_max3), float32, exact.
-// Included by kxk_circle2.hip and kxk_box2.hip, which define XRS_WALK_SHAPE / XRS_WALK_KERNEL / XRS_WALK_ENTRY.
+//   * subsets: the extrema pass and the moments pass are compile-time options (XRS_WALK2_MM / XRS_WALK2_MOM), so
+//     apply(func=_calc_max) or focal_stats(['mean', 'std']) on a 25x25 window pay for one pass only; the extrema-only
+//     variant skips NaN cells like nanmin / nanmax do and only leaves tiles that hold a NaN to the exact walker (an
+//     all-NaN window must come out NaN).
+// Included by kxk_circle2*.hip and kxk_box2*.hip, which define XRS_WALK_SHAPE / XRS_WALK_KERNEL / XRS_WALK_ENTRY and the
+// variant.
 #include "circle_walk.h"
 
 #include <utility>
@@ -32,6 +37,13 @@ using namespace xrs;
 namespace {
 
 constexpr int W2TH = 128;         // output rows per tile
+#ifndef XRS_WALK2_MM
+#define XRS_WALK2_MM 1            // max / min / range
+#endif
+#ifndef XRS_WALK2_MOM
+#define XRS_WALK2_MOM 1           // mean / var / std / sum
+#endif
+static_assert(XRS_WALK2_MM || XRS_WALK2_MOM, "nothing to compute");
 
 template <int R, typename Shape>
 struct Walk2Cfg {
@@ -67,12 +79,14 @@ template <int R, typename Shape, bool EDGE>
 struct Walk2 {
     using C = Walk2Cfg<R, Shape>;
     static constexpr int K = C::K, PFN = C::PFN;
+    static constexpr bool MM = XRS_WALK2_MM != 0, MOM = XRS_WALK2_MOM != 0;
 
-    double sd[K], sq[K];
-    float mn[K], mx[K];
+    double sd[MOM ? K : 1], sq[MOM ? K : 1];
+    float mn[MM ? K : 1], mx[MM ? K : 1];
     float pf_own[PFN], pf_halo[PFN];
-    float vlo, vhi;                // running extrema of everything this lane has seen (guard scale)
-    bool bad, redo;
+    float dmax;                    // largest |v - c| among the cells this lane loaded (guard scale, reduced over the wave at the end)
+    double vmin;                   // smallest unclamped variance this lane emitted
+    bool bad;
     int i;
 
     const WalkGeom &g;
@@ -94,11 +108,11 @@ struct Walk2 {
         const float *p = g.in + yy * g.ld_in + (xw - R);
         if (!EDGE) {
             own = p[lane];
-            halo = 0.0f;
+            halo = cf;                                          // (lanes without a halo cell: d = 0 for the guard scale)
             if (lane < 2 * R) halo = p[64 + lane];
             return;
         }
-        own = halo = 0.0f;                                  // (out-of-raster cells are masked by kmin / kmax, never used)
+        own = halo = cf;                                    // (out-of-raster cells are masked by kmin / kmax, never used)
         const bool row_ok = il < n_in && yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;     // wave-uniform
         if (!row_ok) return;
         const long xa = xw - R + lane, xb = xa + 64;
@@ -108,9 +122,12 @@ struct Walk2 {
 
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < K; ++j) { sd[j] = 0.0; sq[j] = 0.0; mn[j] = INFINITY; mx[j] = -INFINITY; }
-        vlo = INFINITY; vhi = -INFINITY;
-        bad = redo = false;
+        for (int j = 0; j < (MOM ? K : 1); ++j) { sd[j] = 0.0; sq[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < (MM ? K : 1); ++j) { mn[j] = INFINITY; mx[j] = -INFINITY; }
+        dmax = 0.0f;
+        vmin = (double)INFINITY;
+        bad = false;
         i = 0;
         y_first = y0 - R;
         n_in = (int)(y_end - y0) + 2 * R;
@@ -166,12 +183,14 @@ struct Walk2 {
                                    // (issued after this row's reads) cannot overtake them
             double *rowd = reinterpret_cast<double *>(buf);
             float *rowf = reinterpret_cast<float *>(buf + C::STG * 8);
-            rowf[lane] = q;
-            rowd[lane] = (double)q - cd;
+            if (MM) rowf[lane] = q;
+            if (MOM) rowd[lane] = (double)q - cd;
             if (lane < 2 * R) {
-                rowf[64 + lane] = hq;
-                rowd[64 + lane] = (double)hq - cd;
+                if (MM) rowf[64 + lane] = hq;
+                if (MOM) rowd[64 + lane] = (double)hq - cd;
             }
+            if (MOM) dmax = amax3(dmax, q - cf, hq - cf);
+            else bad |= __builtin_isunordered(q, hq);        // a NaN cell: nanmin / nanmax of an all-NaN window is NaN
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                 // (LDS serves one wave's instructions in order)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -181,8 +200,8 @@ struct Walk2 {
             // for min / max (skipped), 0 for the moments.  A NaN INSIDE the raster poisons S and sends the tile to the
             // exact walker.
             const float qnan = nan_f32();
-            float lo, hi;
-            {
+            if (MM) {
+                float lo, hi;
                 float v[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) v[k] = rowf[lane + k];
@@ -208,7 +227,7 @@ struct Walk2 {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
+            if (MOM) {
                 double dv[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) dv[k] = rowd[lane + k];
@@ -220,6 +239,7 @@ struct Walk2 {
                     const double d = in_c ? dv[R] : 0.0;
                     S = d; Q = d * d;
                 }
+                (void)qnan;
 #pragma unroll
                 for (int h = 0; h <= R; ++h) {
                     if (h > 0) {
@@ -240,16 +260,27 @@ struct Walk2 {
                     }
                 }
             }
-            vlo = raw_min(vlo, lo);
-            vhi = raw_max(vhi, hi);
+            if (!MOM) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         // ---- the output row R rows up is complete
         constexpr int DONE = ((PHASE - R) % K + K) % K;
-        if (i >= 2 * R && (!EDGE || x < g.cols)) emit(y0 + (i - 2 * R), sd[DONE], sq[DONE], mn[DONE], mx[DONE]);
-        sd[DONE] = 0.0; sq[DONE] = 0.0; mn[DONE] = INFINITY; mx[DONE] = -INFINITY;
+        constexpr int DM = MOM ? DONE : 0, DX = MM ? DONE : 0;
+        if (i >= 2 * R && (!EDGE || x < g.cols)) emit(y0 + (i - 2 * R), sd[DM], sq[DM], mn[DX], mx[DX]);
+        if (MOM) { sd[DM] = 0.0; sq[DM] = 0.0; }
+        if (MM) { mn[DX] = INFINITY; mx[DX] = -INFINITY; }
     }
 
     __device__ __forceinline__ void emit(long yo, double S, double Q, float lo, float hi) {
+        const long off = yo * g.ld_out + x;
+        if (MM) {
+            if (o.max) st_stream(&o.max[off], hi);
+            if (o.min) st_stream(&o.min[off], lo);
+            if (o.range) st_stream(&o.range[off], hi - lo);
+        }
+        if (!MOM) return;
         int n = C::NTAPS;
         if (EDGE) {
             const bool rows_in = yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot;    // wave-uniform
@@ -259,14 +290,12 @@ struct Walk2 {
         const double dn = (double)n;
         const double inv = EDGE ? walk_rcp(n) : 1.0 / (double)C::NTAPS;
         const double ms = S * inv;
-        double mean = cd + ms;
-        const double ssd = Q - S * ms;
-        double var = (ssd > 0.0 ? ssd : 0.0) * inv;
-        // cancellation guard, as in circle_walk.h: the rounding noise of Q and S^2/n is ~ n * eps * max(d^2)
-        const float am = fmaxf(vhi - cf, cf - vlo);
-        const double guard = 1e-9 * dn * ((double)am * (double)am);
-        redo |= (o.var || o.std) && !(ssd >= guard);        // flat / ill-conditioned window: the exact walker redoes the tile's moments
-        const long off = yo * g.ld_out + x;
+        const double mean = cd + ms;
+        const double v0 = (Q - S * ms) * inv;                // the one-pass variance before clamping
+        const double var = v0 > 0.0 ? v0 : 0.0;
+        // cancellation guard, as in circle_walk.h, evaluated once per tile in run(): the rounding noise of Q and S^2/n is
+        // ~ n * eps * max(d^2), so the smallest variance of the tile must stand clear of 1e-9 * max(d^2)
+        vmin = v0 < vmin ? v0 : vmin;
         if (o.mean) st_stream(&o.mean[off], (float)mean);
         if (o.var) st_stream(&o.var[off], (float)var);
         if (o.std) {
@@ -276,19 +305,14 @@ struct Walk2 {
             st_stream(&o.std[off], sqrtf((float)(tiny ? var * 0x1p+200 : var)) * (tiny ? 0x1p-100f : 1.0f));
         }
         if (o.sum) st_stream(&o.sum[off], (float)fma(dn, cd, S));
-        if (o.max) st_stream(&o.max[off], hi);
-        if (o.min) st_stream(&o.min[off], lo);
-        if (o.range) st_stream(&o.range[off], hi - lo);
     }
 
     template <int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (step<P>(), ...);
         // the round started at a row i0 with ring slot (j - i0) mod K for output row j; the next one starts at i0 + U
-        ring_rotate<K, C::U>(sd);
-        ring_rotate<K, C::U>(sq);
-        ring_rotate<K, C::U>(mn);
-        ring_rotate<K, C::U>(mx);
+        if (MOM) { ring_rotate<MOM ? K : 1, MOM ? C::U : 1>(sd); ring_rotate<MOM ? K : 1, MOM ? C::U : 1>(sq); }
+        if (MM) { ring_rotate<MM ? K : 1, MM ? C::U : 1>(mn); ring_rotate<MM ? K : 1, MM ? C::U : 1>(mx); }
     }
 
     // 0: every result of the tile is good; 1: the exact walker redoes the moments; 2: it redoes everything
@@ -298,7 +322,12 @@ struct Walk2 {
             round(std::make_integer_sequence<int, C::U>{});
             if (__any(bad)) return 2;
         }
-        return __any(redo) ? 1 : 0;
+        if (!MOM || !(o.var || o.std)) return 0;
+        float am = dmax;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) am = fmaxf(am, __shfl_xor(am, sft));
+        const bool redo = !(vmin >= 1e-9 * ((double)am * (double)am));      // flat / ill-conditioned window: the exact walker
+        return __any(redo) ? 1 : 0;                                          // redoes the tile's moments
     }
 };
 
@@ -328,9 +357,10 @@ __global__ void __launch_bounds__(256, 2) XRS_WALK_KERNEL(const WalkGeom g, cons
     if (rc == 0) return;
     // a non-finite cell under one of the tile's windows (2), or a flat / ill-conditioned window (1): the exact
     // NaN-skipping walkers (moments; for 2 also the float32 statistics with the reference's sequential sum)
-    if (o.mean || o.var || o.std) walk_columns<R, XRS_WALK_SHAPE, false, false, false, true, true>(g, o, xw, lane, y0, y_end);
+    if (XRS_WALK2_MOM && (o.mean || o.var || o.std))
+        walk_columns<R, XRS_WALK_SHAPE, false, false, false, true, true>(g, o, xw, lane, y0, y_end);
     if (rc == 2 && (o.sum || o.max || o.min || o.range))
-        walk_columns<R, XRS_WALK_SHAPE, true, true, true, false, false>(g, o, xw, lane, y0, y_end);
+        walk_columns<R, XRS_WALK_SHAPE, true, XRS_WALK2_MOM != 0, XRS_WALK2_MM != 0, false, false>(g, o, xw, lane, y0, y_end);
 }
 
 template <int R>
@@ -359,6 +389,8 @@ int XRS_WALK_ENTRY(const float *in, float *out_sum, float *out_max, float *out_m
     memset(&g, 0, sizeof(g));
     g.in = in; g.rows = rows; g.cols = cols; g.ld_in = ld_in; g.ld_out = ld_out;
     g.halo_top = halo_top; g.halo_bot = halo_bot;
+    if ((!XRS_WALK2_MM && (out_max || out_min || out_range)) || (!XRS_WALK2_MOM && (out_sum || out_mean || out_var || out_std)))
+        return fail("focal statistics: walker variant without the requested pass");
     const WalkOuts o = {out_sum, out_max, out_min, out_range, out_mean, out_var, out_std};
     switch (krows / 2) {
 #ifndef XRS_WALK2_PROBE

@@ -234,5 +234,20 @@ int try_launch_focal_circle2(const float *in, float *out_sum, float *out_max, fl
 int try_launch_focal_box2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
                           float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
                           const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+// kxk_*2_mm.hip / kxk_*2_mom.hip: the same walker with only the extrema pass (max / min / range) or only the moments pass
+// (mean / var / std / sum); the other outputs must be NULL
+int try_launch_focal_circle2_mm(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_focal_box2_mm(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_focal_circle2_mom(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_focal_box2_mom(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
+                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
+                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+
 
 }  // namespace xrs

@@ -418,6 +418,14 @@ def run_headline(ctx):
                                                              kernel.ctypes.data, 5, 5, None, 0, 0, stream), reps=3), 4),
         }
         ok = extra["other_kernels_ms"]
+        w25 = np.ascontiguousarray(k25 / k25.sum())
+        work = xs.DeviceArray((25 * 25,), np.float64)
+        ok["convolve_2d_25x25_normalised_circle"] = round(timed(lambda: L("xrs_convolve2d_f32", dem_ptr, out_hill.ptr, rows, cols, cols, cols,
+                                                                          w25.ctypes.data, 25, 25, work.ptr, 0, 0, stream), reps=3), 4)
+        ok["focal_max_min_range_25x25_circle"] = round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, ptr7, 0b1110, rows, cols, cols, cols,
+                                                                       k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=3), 4)
+        ok["slope_frac_of_hbm_peak"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+        ok["slope_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / copy_gbs, 3)
         ok["focal_mean_25x25_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["focal_mean_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)
         ok["focal_stats7_25x25_frac_of_measured_copy"] = round(32.0 * rows * cols / (ok["focal_stats7_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)
         del outs7, ptr7

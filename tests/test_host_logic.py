@@ -441,3 +441,29 @@ def test_sharded_array_bookkeeping(monkeypatch):
     with pytest.raises(TypeError):
         xa.slope(DataArray(solo, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, 40), 'lon': np.linspace(1, 2, 12)}),
                  method='geodesic')
+
+
+def test_placeholders_and_shards_are_duck_arrays(monkeypatch):
+    """xarray wraps an object without converting it only if it looks like a duck array: shape / dtype / ndim plus
+    __array_function__ and __array_ufunc__ (xarray.core.utils.is_duck_array).  PendingResult (inside fuse()), ShardedArray
+    and ShardedStack must pass that test like DeviceArray does, or real xarray would call np.asarray on them."""
+    from xrspatial_amd import fused
+    from xrspatial_amd.sharded import ShardedArray, ShardedStack
+    from xrspatial_amd.device import DeviceArray
+    from tests import fake_hip
+    fake_hip.install(monkeypatch)
+
+    def is_duck_array(x):                      # the test xarray applies (core/utils.py)
+        return (hasattr(x, "ndim") and hasattr(x, "shape") and hasattr(x, "dtype")
+                and hasattr(x, "__array_function__") and hasattr(x, "__array_ufunc__"))
+
+    for cls in (fused.PendingResult, ShardedArray, ShardedStack, DeviceArray):
+        assert hasattr(cls, "__array_function__") and hasattr(cls, "__array_ufunc__"), cls
+    shard = ShardedArray.from_numpy(np.zeros((4, 8), np.float32))
+    assert is_duck_array(shard)
+    assert shard.__array_function__(np.sum, (ShardedArray,), (shard,), {}) is NotImplemented
+    assert shard.__array_ufunc__(np.add, "__call__", shard, 1) is NotImplemented
+    stack = ShardedStack([shard, shard])
+    assert is_duck_array(stack) and stack.shape == (2, 4, 8)
+    dev = DeviceArray.from_numpy(np.zeros((3, 5), np.float32))
+    assert is_duck_array(dev)

@@ -63,6 +63,9 @@ __device__ __forceinline__ void put4(float *p, const float (&v)[4], int n = 4) {
 // CMASK: the window's taps as a compile-time constant (bit ky * KW + kx), 0 = read them from a.mask_rows at run time.
 // With the mask known, the tap walk is straight-line code: no scalar branch per tap row, and the register allocator
 // sees one basic block (the circular 5x5 mask of `circle_kernel(1, 1, 2)` -- the bench's -- is instantiated this way).
+#ifndef XRS_PASS_RH
+#define XRS_PASS_RH 0          // output rows per walk of the NaN-aware body (0: all RB)
+#endif
 template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, bool TERRAIN, bool NT, unsigned CMASK = 0u>
 __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
@@ -155,43 +158,52 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
     } else {
         // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
         // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
-        // the sum and 0 to a float32 count (exact far beyond 25 taps).  Rows are consumed as they are walked, so this
-        // body needs no more registers than the fast one (the per-output form it replaces spilled).
-        double acc[RB][4];
-        float cnt[RB][4];
+        // the sum and 0 to a float32 count (exact far beyond 25 taps).
+        // This COLD body (strips with a NaN / inf under a window, strips on the raster edge) is where the kernel's
+        // spilled registers live: in the ISA of the bench instantiation every scratch access lies between the fast
+        // body's `s_cbranch_vccz` over the re-run and its target; the hot path touches no scratch (tools/spill_scan.py
+        // reports per kernel, not per path).  Walking RH < RB output rows at a time (XRS_PASS_RH) trims the spill of the
+        // compile-time-mask instantiations (80 -> 52 -> 28 bytes for RH = 4, 2, 1) and quadruples it for the run-time-mask
+        // ones: left at RB.
+        constexpr int RH = XRS_PASS_RH ? XRS_PASS_RH : RB;
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int hb = 0; hb < RB; hb += RH) {
+            double acc[RH][4];
+            float cnt[RH][4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
+            for (int r = 0; r < RH; ++r)
 #pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-            double z[NV];
-            float c[NV];
+                for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const bool okv = !isnan(v[ir][i]);
-                z[i] = okv ? (double)v[ir][i] : 0.0;
-                c[i] = okv ? 1.0f : 0.0f;
+            for (int ir = hb; ir < hb + RH + KH - 1; ++ir) {
+                double z[NV];
+                float c[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const bool okv = !isnan(v[ir][i]);
+                    z[i] = okv ? (double)v[ir][i] : 0.0;
+                    c[i] = okv ? 1.0f : 0.0f;
+                }
+#pragma unroll
+                for (int ky = 0; ky < KH; ++ky) {
+                    const int orow = ir - ky - hb;
+                    if (orow < 0 || orow >= RH) continue;
+                    const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
+#pragma unroll
+                    for (int kx = 0; kx < KW; ++kx)
+                        if (bits >> kx & 1u) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
+                        }
+                }
             }
 #pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (bits >> kx & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
-                    }
+            for (int r = 0; r < RH; ++r) {
+                if (!INTERIOR && y0 + hb + r >= a.rows) break;
+                const float m[4] = {(float)(acc[r][0] * rcp_count((int)cnt[r][0])), (float)(acc[r][1] * rcp_count((int)cnt[r][1])),
+                                    (float)(acc[r][2] * rcp_count((int)cnt[r][2])), (float)(acc[r][3] * rcp_count((int)cnt[r][3]))};
+                put4<NT>(fout + (hb + r) * a.ld_out + loff, m, INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
             }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (!INTERIOR && y0 + r >= a.rows) break;
-            const float m[4] = {(float)(acc[r][0] * rcp_count((int)cnt[r][0])), (float)(acc[r][1] * rcp_count((int)cnt[r][1])),
-                                (float)(acc[r][2] * rcp_count((int)cnt[r][2])), (float)(acc[r][3] * rcp_count((int)cnt[r][3]))};
-            put4<NT>(fout + r * a.ld_out + loff, m, INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
         }
     }
 

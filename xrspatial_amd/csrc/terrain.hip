@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_n(OutT *p, const float (&v)[4], int n) {
 #define XRS_STRIP_WX 1
 #endif
 #ifndef XRS_HORN_MODE
-#define XRS_HORN_MODE 1      // 1: Horn differences shared along the strip (HornRoller), 0: cell by cell
+#define XRS_HORN_MODE 0      // 0: Horn sums cell by cell (horn_cell), 1: differences shared along the strip (HornRoller)
 #endif
 
 // ---------------------------------------------------------------- fast path
@@ -152,11 +152,13 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
     }
 }
 
-// slope / aspect stand-alone: 5 workgroups per CU (96 VGPRs; the allocator wants 104 and spills one address pair).  Same-box
-// A/B (tools/ab_terrain.sh, 16384^2): uncapped 0.410 / 0.423 ms, cap 5: 0.395 / 0.405, cap 6 (80 VGPRs, 24 spilled): 0.434 / 0.427;
-// Horn sums cell by cell (XRS_HORN_MODE=0, 85 VGPRs, no spill): 0.403 / 0.405; hillshade alongside: 0.377-0.389.
+// slope / aspect stand-alone, same-box A/B under the row-interleaved tile order (tools/ab_terrain.sh, 16384^2, four rounds,
+// times relative to hillshade in the same process): Horn sums cell by cell, uncapped (85 VGPRs, 5 waves per SIMD, no
+// scratch) slope 1.07 / aspect 1.12; the same capped at 5 workgroups per CU 1.08 / 1.14; differences shared along the strip
+// (HornRoller: 7 instead of 10 float64 operations per cell, but 104 VGPRs) capped at 5 (96 VGPRs, 13 spilled) 1.09 / 1.16,
+// uncapped (4 waves per SIMD) 1.10 / 1.20.  Occupancy beats operation count here: cell by cell it is.
 #ifndef XRS_LB_HORN
-#define XRS_LB_HORN 5
+#define XRS_LB_HORN 1
 #endif
 template <int OPS, typename HillT, int RB>
 __global__ void __launch_bounds__(256, ((OPS == OP_SLOPE || OPS == OP_ASPECT) && RB == 4) ? XRS_LB_HORN : 1) terrain_strip_kernel(const TerrainArgs a) {

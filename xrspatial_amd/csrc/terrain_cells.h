@@ -17,9 +17,11 @@ struct Nb { float nw, n, ne, w, c, e, sw, s, se; };
 // ---- slope / aspect.  The Horn sums stay in float64, the reference's arithmetic (numba widens `2 * float32` to
 // float64): sums of float32 cells are exact there, for any data.  (An all-float32 "differences first + TwoSum" form is
 // only exact while neighbouring cells are within a factor 2 of each other, costs as many issue slots and measured no
-// faster: slope 0.43 vs 0.40 ms, profiles/r02.)  Differences first, so that a strip shares them between its cells:
-//   gx = (ne + 2e + se) - (nw + 2w + sw) = (ne - nw) + 2 (e - w) + (se - sw)     7 float64 operations per cell
-//   gy = (nw + 2n + ne) - (sw + 2s + se) = (nw - sw) + 2 (n - s) + (ne - se)     instead of 10 + 2 multiplies
+// faster: slope 0.43 vs 0.40 ms, profiles/r02.)  Differences first: 10 float64 operations per cell
+// and no float64 multiplies (a strip CAN share the differences between its cells -- HornRoller below, 7 per cell -- but the
+// registers that takes cost more than the operations save: terrain.hip):
+//   gx = (ne + 2e + se) - (nw + 2w + sw) = (ne - nw) + 2 (e - w) + (se - sw)
+//   gy = (nw + 2n + ne) - (sw + 2s + se) = (nw - sw) + 2 (n - s) + (ne - se)
 // Every path (strip, fused pass, cell-by-cell) evaluates exactly these operations in this order.
 struct Horn { double gx, gy; };
 

@@ -151,7 +151,15 @@ def one_case(rng, max_cells):
                     return desc, None
                 return desc, "oracle raised ZeroDivisionError, device path did not"
             # classes may differ where |z| sits within 1e-5 of a threshold (float32 nanmean / nanstd upstream)
-            got = host(focal.hotspots(agg, k).data).copy()
+            try:
+                got = host(focal.hotspots(agg, k).data).copy()
+            except ZeroDivisionError:
+                # a CONSTANT raster: the device's moments are exact (std == 0 -> the reference's documented error), while
+                # numpy's float32 pairwise sums leave the reference a mean one ulp off and a std of rounding noise
+                z32 = z.astype(np.float32)
+                if float(np.nanmax(z32)) == float(np.nanmin(z32)):
+                    return desc + " (constant raster: device raises like the reference's std == 0 branch)", None
+                raise
             for t in (1.29, 1.65, 1.96, 2.33, 2.58):
                 near = np.abs(np.abs(zscore) - t) < 1e-5
                 got[near] = want[near]
@@ -175,11 +183,19 @@ def one_case(rng, max_cells):
                 want = orc.zonal_stats(zones, z, stats_funcs=names, nodata_values=nodata)
                 if list(np.asarray(got['zone'])) != list(np.asarray(want['zone'])):
                     return desc, f"zone ids differ: {len(got)} vs {len(want['zone'])}"
+                fin = z[np.isfinite(z)] if z.dtype.kind == 'f' else z
+                amax = float(np.abs(fin.astype(np.float64)).max()) if fin.size else 0.0
                 for name in names:
-                    # (float32 values: the reference reduces in float32, the device in float64)
+                    # (float32 values: the reference reduces in float32, the device in float64 -- a zone of a few nearly
+                    #  equal cells has a float32 std / var that is rounding noise of size eps32 * |values|)
                     loose = name in ('std', 'var') or z.dtype == np.float32
+                    atol = 0.0
+                    if name == 'std':
+                        atol = 1e-6 + (2e-7 * amax if z.dtype == np.float32 else 0.0)
+                    elif name == 'var':
+                        atol = 1e-6 + (2e-7 * amax * amax if z.dtype == np.float32 else 0.0)
                     err = close(np.asarray(got[name], dtype=np.float64), np.asarray(want[name], dtype=np.float64),
-                                rtol=1e-5 if loose else 1e-9, atol=1e-6 if name in ('std', 'var') else 0)
+                                rtol=1e-5 if loose else 1e-9, atol=atol)
                     if err:
                         return desc + " " + name, err
                 return desc, None

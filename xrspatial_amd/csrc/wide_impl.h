@@ -4,10 +4,11 @@
 //
 // The "wide" row walker: ONE 16-byte load per lane per input row, neighbours through LDS, float32 arithmetic on
 // shifted values, a register ring with static indices.
-//   * a wave owns a tile of 256 columns x ~128 output rows and walks DOWN its input rows; a lane owns 4 adjacent
-//     columns.  Every input row reaches LDS once (256 + 2*HL cells: one 16-byte and one 4-byte transfer per lane) and
-//     every lane reads back the 4 + 2*HL consecutive cells its four windows cover as aligned ds_read_b128 (conflict
-//     free), minus a wave-uniform shift c (the cell at the tile centre).
+//   * a wave owns a tile of 64 NC columns x ~130 output rows and walks DOWN its input rows; a lane owns NC adjacent
+//     columns (NC = 2 since the end of round 2: half the registers of NC = 4 and a third wave per SIMD are worth more than
+//     the shared halo cells).  Every input row reaches LDS once (64 NC + 2*HL cells) and every lane reads back the
+//     NC + 2*HL consecutive cells its windows cover as aligned vector reads (conflict free), minus a wave-uniform shift c
+//     (the cell at the tile centre).
 //   * a lane-local prefix sum over those cells turns every centred run of the mask into ONE subtraction,
 //     S_h(x) = P[x + h] - P[x - h - 1]; a circle of radius 12 has only 9 distinct half-widths.
 //   * the 2R+1 output rows in flight live in a register ring, acc[(row - dy) mod (2R+1)]; the row loop is unrolled U = 5
@@ -43,6 +44,9 @@ using namespace xrs;
 
 namespace {
 
+#ifndef XRS_WIDE_NO_FALLBACK
+#define XRS_WIDE_NO_FALLBACK 0
+#endif
 struct WideArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
     float *out;                   // the mean, the window sum, or the convolution (template parameter of the kernel)
@@ -56,9 +60,11 @@ template <int R, typename Shape>
 struct WideCfg {
     static constexpr int K = 2 * R + 1;
 #ifndef XRS_WIDE_NC
-#define XRS_WIDE_NC 4
+#define XRS_WIDE_NC 2
 #endif
-    static constexpr int NC = XRS_WIDE_NC;                 // columns per lane (2: 128-column wave tiles, half the registers)
+    static constexpr int NC = XRS_WIDE_NC;                 // columns per lane.  4 (256-column wave tiles): 250 VGPRs, 2 waves per SIMD, 25x25
+                                                           // mean 0.65 ms; 2 (128-column tiles): 161 VGPRs, 3 waves, 0.57 ms although a lane
+                                                           // then reads 26 cells for 2 outputs instead of 28 for 4 (profiles/r02/r02o_ab_wide_nc.log)
     static constexpr int TW = 64 * NC;                     // columns per wave tile
     static constexpr int HL = NC * ((R + NC - 1) / NC);    // halo columns each side, rounded up to whole lane groups
     static constexpr int NV = NC + 2 * HL;                 // cells a lane reads back per row
@@ -74,7 +80,7 @@ struct WideCfg {
 #define XRS_WIDE_D 8
 #endif
     static constexpr int D = XRS_WIDE_D;                   // interior tiles: rows in flight by LDS-DMA; D + 1 row buffers per wave
-    static constexpr int RBF = STG > 320 ? STG : 320;      // floats per ring row (the 16-byte DMA writes a whole KiB, the dword one 256 B)
+    static constexpr int RBF = (TW + 2 * HL > 256) ? (STG > 320 ? STG : 320) : 256;   // floats per ring row (the 16-byte DMA writes a whole KiB, the dword one 256 B more)
     static constexpr int LDS_WAVE = (D + 1) * RBF;    // floats of LDS per wave (a DMA writes whole KiB)
     static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: a whole number of rounds
     static constexpr int WTH = NIN - 2 * R;                // output rows per wave tile (128 .. 128 + U - 1)
@@ -387,7 +393,7 @@ struct WideWalk {
 
 template <int R, typename Shape, int MODE>
 #ifndef XRS_WIDE_WAVES
-#define XRS_WIDE_WAVES 2
+#define XRS_WIDE_WAVES 3        // workgroups per CU = waves per SIMD (4 spills at radius 12: 2.2 ms)
 #endif
 __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const WideArgs a) {
     using C = WideCfg<R, Shape>;
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
         w.wgt = (float)a.wgt;
         ok = w.run();
     }
-    if (ok) return;
+    if (ok || XRS_WIDE_NO_FALLBACK) return;
     constexpr bool SUM = MODE == WIDE_SUM;
     if (MODE == WIDE_CONV) {
         // a non-finite cell in reach, or sums too ill-conditioned for float32: the float64 conv walker (tap by tap, in the

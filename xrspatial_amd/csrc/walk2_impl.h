@@ -44,6 +44,9 @@ constexpr int W2TH = 128;         // output rows per tile
 #define XRS_WALK2_MOM 1           // mean / var / std / sum
 #endif
 static_assert(XRS_WALK2_MM || XRS_WALK2_MOM, "nothing to compute");
+#ifndef XRS_WALK2_WAVES
+#define XRS_WALK2_WAVES 2         // workgroups per CU = waves per SIMD
+#endif
 
 template <int R, typename Shape>
 struct Walk2Cfg {
@@ -332,7 +335,7 @@ struct Walk2 {
 };
 
 template <int R>
-__global__ void __launch_bounds__(256, 2) XRS_WALK_KERNEL(const WalkGeom g, const WalkOuts o) {
+__global__ void __launch_bounds__(256, XRS_WALK2_WAVES) XRS_WALK_KERNEL(const WalkGeom g, const WalkOuts o) {
     using C = Walk2Cfg<R, XRS_WALK_SHAPE>;
     __shared__ __attribute__((aligned(16))) char lds_rows[4][C::STG * 12];
     const long t = xcd_tile(blockIdx.x, g.n_tiles, XCD_UNIT(XRS_XCD_WALK, g.tiles_x));

@@ -181,6 +181,54 @@ def call(name, *a):
         _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
         np.minimum.at(_arr(mn, nz, vt), idx[ok], v[ok])
         np.maximum.at(_arr(mx, nz, vt), idx[ok], v[ok])
+    elif name == "xrs_zonal_index":
+        z, code, n, zmin, rng, lut, idx, _ = a
+        assert code == 0
+        off = _arr(z, n, np.int32).astype(np.int64) - int(zmin)
+        inside = (off >= 0) & (off < rng)
+        _arr(idx, n, np.int32)[...] = np.where(inside, _arr(lut, rng, np.int32)[np.clip(off, 0, rng - 1)], -1)
+    elif name in ("xrs_zonal_partials_f64",):
+        z, vals, n, nz, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, _ = a
+        idx = _arr(z, n, np.int32)
+        v = _arr(vals, n, np.float64)
+        ok = (idx >= 0) & (idx < nz) & np.isfinite(v)
+        if has_nodata:
+            ok &= v != nodata
+        d = v[ok] - shift
+        _arr(cnt, nz, np.uint64)[...] += np.bincount(idx[ok], minlength=nz).astype(np.uint64)
+        _arr(s1, nz, np.float64)[...] += np.bincount(idx[ok], weights=d, minlength=nz)
+        _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=d * d, minlength=nz)
+        np.minimum.at(_arr(mn, nz, np.float64), idx[ok], v[ok])
+        np.maximum.at(_arr(mx, nz, np.float64), idx[ok], v[ok])
+    elif name in ("xrs_zonal_group_f32", "xrs_zonal_group_f64"):
+        # cells ordered by (zone index, value); invalid cells last, as NaN
+        z, vals, n, nz, nodata, has_nodata, _work, _wb, out, _ = a
+        vt = np.float64 if name.endswith("f64") else np.float32
+        idx = _arr(z, n, np.int32).astype(np.int64)
+        v = _arr(vals, n, vt)
+        ok = (idx >= 0) & (idx < nz) & np.isfinite(v)
+        if has_nodata:
+            ok &= v != vt(nodata)
+        key_zone = np.where(ok, idx, nz)
+        order = np.lexsort((np.where(ok, v, np.inf), key_zone))
+        res = np.where(ok, v, np.nan)[order]
+        _arr(out, n, vt)[...] = res
+    elif name == "xrs_zonal_backproject_f64":
+        z, n, table, n_stats, nz, out, _ = a
+        idx = _arr(z, n, np.int32)
+        tab = _arr(table, n_stats * nz, np.float64).reshape(n_stats, nz)
+        ok = (idx >= 0) & (idx < nz)
+        res = np.where(ok[None, :], tab[:, np.clip(idx, 0, nz - 1)], np.nan)
+        _arr(out, n_stats * n, np.float64)[...] = res.ravel()
+    elif name == "xrs_focal_windows_f32":
+        # the arrays _apply_numpy builds per cell (focal.py:305-326) for rows [y0, y0 + band_rows)
+        src, dst, rows, cols, ld, y0, nb, kernel, kr, kc, _ = a
+        k = _kernel(kernel, kr, kc)
+        plane = _plane(src, rows, cols, ld, 0, 0)
+        pad = np.full((rows + kr - 1, cols + kc - 1), np.nan, np.float32)
+        pad[kr // 2:kr // 2 + rows, kc // 2:kc // 2 + cols] = plane
+        win = np.lib.stride_tricks.sliding_window_view(pad, (kr, kc))[y0:y0 + nb]
+        _arr(dst, nb * cols * kr * kc, np.float32)[...] = np.where(k == 1, win, np.float32(np.nan)).ravel()
     else:
         raise NotImplementedError(f"fake_hip: {name} is not emulated")
 
@@ -189,6 +237,10 @@ class _FakeLib:
     @staticmethod
     def xrs_kxk_workspace_bytes(kr, kc):
         return 16
+
+    @staticmethod
+    def xrs_zonal_majority_workspace_bytes(n, nz, f64):
+        return 256
 
     @staticmethod
     def xrs_free(ptr):

@@ -467,3 +467,55 @@ def test_placeholders_and_shards_are_duck_arrays(monkeypatch):
     assert is_duck_array(stack) and stack.shape == (2, 4, 8)
     dev = DeviceArray.from_numpy(np.zeros((3, 5), np.float32))
     assert is_duck_array(dev)
+
+
+def test_user_callables_host_logic(monkeypatch, golden, golden_tables):
+    """zonal.stats(stats_funcs={name: callable}) and focal.apply(func=callable): the HOST side of both -- zone slices from
+    the grouped values and the valid-cell counts, dtype hand-over, zone_ids selection, DataFrame / back-projection; window
+    bands -- over the C-ABI emulation (the device kernels: tests/test_gpu_parity.py).  Reference fixtures:
+    xrspatial/tests/test_zonal.py:204-237, 497-544."""
+    from tests import fake_hip
+    fake_hip.install(monkeypatch)
+    funcs = {'double_sum': lambda v: v.sum() * 2, 'range': lambda v: v.max() - v.min()}
+    zones = raster(np.nan_to_num(golden["zonal_zones"], nan=-9).astype(np.int32))
+    values = raster(golden["zonal_values"])
+    nodata, ids, exp = (golden_tables["zonal_custom__%d" % i] for i in range(3))
+    df = zonal.stats(zones, values, zone_ids=ids, stats_funcs=funcs, nodata_values=nodata)
+    assert list(df.columns) == ['zone', 'double_sum', 'range'] and df['zone'].tolist() == exp['zone']
+    for col in ('double_sum', 'range'):
+        np.testing.assert_allclose(df[col], exp[col], rtol=1e-12)
+    da = zonal.stats(zones, values, zone_ids=ids, stats_funcs=funcs, nodata_values=nodata, return_type='xarray.DataArray')
+    np.testing.assert_allclose(np.asarray(da.data), golden["zonal_custom_da__2"], equal_nan=True)
+    # order statistics, integer values handed over in their own dtype, a zone without valid cells
+    rng = np.random.default_rng(1)
+    zz = rng.integers(0, 9, size=(40, 61)).astype(np.int32)
+    vv = rng.integers(-20, 21, size=zz.shape).astype(np.int16)
+    vv[zz == 4] = 3
+    seen = []
+    got = zonal.stats(raster(zz), raster(vv), nodata_values=3,
+                      stats_funcs={'median': np.median, 'n': lambda v: (seen.append(v.dtype), v.size)[1]})
+    assert set(seen) == {np.dtype(np.int16)}
+    for i, z in enumerate(np.unique(zz)):
+        cell = vv[(zz == z) & (vv != 3)]
+        if z == 4:
+            assert np.isnan(got['median'][i]) and np.isnan(got['n'][i])
+        else:
+            assert got['median'][i] == np.median(cell) and got['n'][i] == cell.size
+    with pytest.raises(ValueError):
+        zonal.stats(raster(zz), raster(vv), stats_funcs={'bad': 'median'})
+
+    # focal.apply with a callable, several bands
+    z = rng.normal(size=(23, 17)).astype(np.float32)
+    z[3, 4] = np.nan
+    k = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], float)
+    monkeypatch.setattr(focal, "_WINDOW_BAND_BYTES", 17 * 9 * 4 * 4)          # 4 rows per band
+    got = focal.apply(raster(z), k, func=lambda w: np.nansum(w) + np.isnan(w).sum())
+    pad = np.full((25, 19), np.nan, np.float32)
+    pad[1:-1, 1:-1] = z
+    want = np.zeros_like(z)
+    for y in range(23):
+        for x in range(17):
+            w = np.where(k == 1, pad[y:y + 3, x:x + 3], np.nan).astype(np.float32)
+            want[y, x] = np.nansum(w) + np.isnan(w).sum()
+    np.testing.assert_array_equal(got.data, want)
+    assert got.data.dtype == np.float32

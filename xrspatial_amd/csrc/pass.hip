@@ -211,10 +211,15 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
 }
 
 template <int OPS, int KH, int KW, int RB, bool NT, unsigned CMASK = 0u>
+// instantiations with slope / aspect: 2 (the allocator then takes 156-168 VGPRs = 3 waves per SIMD without scratch; capped at
+// 4 workgroups per CU they spill 31-45 registers in the hot path: hillshade + slope + 5x5 mean 0.81 -> 1.18 ms)
+#ifndef XRS_LB_PASS_HORN
+#define XRS_LB_PASS_HORN 2
+#endif
 #ifndef XRS_LB_PASS
 #define XRS_LB_PASS 4
 #endif
-__global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? 2 : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
+__global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? XRS_LB_PASS_HORN : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;

@@ -669,10 +669,34 @@ def test_zonal_majority_and_dataarray(golden, golden_tables):
         if dtype != np.int64:
             vv[rng.random(zz.shape) < 0.02] = np.nan
             vv[vv == 0] *= -1.0                                   # some -0.0
-        got = xs.zonal_stats(raster(zz), raster(vv), stats_funcs=['majority', 'count'], nodata_values=3)
+        if dtype == np.float64:
+            vv[5, 7] = np.inf
+            vv[9, 1] = -np.inf
         want = orc.zonal_stats(zz, vv, stats_funcs=['majority', 'count'], nodata_values=3)
-        np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'])
-        np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+        # integral values in a bounded range are counted (crosstab kernel); XRS_ZONAL_MAJORITY=sort forces the two radix
+        # sorts every other raster takes; halves (vv / 2) are not integral and sort by themselves
+        for mode in ('', 'sort'):
+            os.environ['XRS_ZONAL_MAJORITY'] = mode
+            try:
+                got = xs.zonal_stats(raster(zz), raster(vv), stats_funcs=['majority', 'count'], nodata_values=3)
+            finally:
+                del os.environ['XRS_ZONAL_MAJORITY']
+            np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'], err_msg=f"{dtype} {mode!r}")
+            np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+        if dtype != np.int64:
+            half = (vv / 2).astype(dtype)
+            got = xs.zonal_stats(raster(zz), raster(half), stats_funcs=['majority'], nodata_values=1.5)
+            want = orc.zonal_stats(zz, half, stats_funcs=['majority'], nodata_values=1.5)
+            np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'])
+    # a zone whose cells are all nodata / NaN has no majority; device-resident values
+    zz2 = np.repeat(np.arange(6, dtype=np.int32), 50).reshape(6, 50)
+    vv2 = rng.integers(0, 4, size=zz2.shape).astype(np.float32)
+    vv2[2] = 7
+    vv2[4] = np.nan
+    got = xs.zonal_stats(raster(zz2, backend='hip'), raster(vv2, backend='hip'), stats_funcs=['majority'], nodata_values=7)
+    want = orc.zonal_stats(zz2, vv2, stats_funcs=['majority'], nodata_values=7)
+    np.testing.assert_array_equal(got['majority'].to_numpy(), want['majority'])
+    assert np.isnan(got['majority'][2]) and np.isnan(got['majority'][4])
     with pytest.raises(ValueError):
         xs.zonal_stats(zones, values, stats_funcs={'double_sum': 'not callable'})
 

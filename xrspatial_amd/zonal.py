@@ -7,6 +7,7 @@ reference's own dask path, zonal.py:83-102), from which mean / std / var follow.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Union
 
 import numpy as np
@@ -196,11 +197,46 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream), shift
 
 
+_MAJORITY_TABLE_LIMIT = 1 << 22      # (zones x distinct values) counters of the counting path
+
+
+def _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream):
+    """`majority` for CATEGORICAL values (integral, bounded range -- land-cover classes, integer DEMs): the values get
+    dense category indices through the same scan / presence / index kernels as zone ids, (zone, category) pairs are
+    counted by the crosstab kernel, and the arg-max of each zone's row (first maximum = smallest value, as
+    _stats_majority's np.unique + argmax, zonal.py:56-68) is the answer: four streaming passes instead of two radix
+    sorts of the whole raster.  None when the values are not categorical (the caller sorts)."""
+    cat = _dense_zone_index_device(vdev)
+    if cat is None:
+        return None
+    cats, cidx = cat
+    nc = len(cats)
+    out = np.full(n_zones, np.nan)
+    if nc == 0 or n_zones == 0:
+        return out
+    if n_zones * nc > _MAJORITY_TABLE_LIMIT:
+        return None
+    cdev = DeviceArray((n_zones * nc,), np.uint64)
+    _lib.call("xrs_memset", cdev.ptr, 0, cdev.nbytes, stream)
+    _lib.call("xrs_crosstab_counts", zdev.ptr, cidx.ptr, zdev.size, n_zones, nc, cdev.ptr, stream)
+    counts = cdev.get(stream).reshape(n_zones, nc)
+    if nodata_values is not None:
+        counts[:, np.asarray(cats, dtype=np.float64) == float(nodata_values)] = 0
+    best = counts.argmax(axis=1)
+    has = counts[np.arange(n_zones), best] > 0
+    out[has] = np.asarray(cats, dtype=np.float64)[best[has]]
+    return out
+
+
 def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
     """Per-zone most frequent valid value (ties -> smallest), float64, NaN for empty zones."""
     _lib.require_device()
     stream = get_stream()
     zdev, vdev = _stage(zone_idx, values)
+    if os.environ.get("XRS_ZONAL_MAJORITY", "") != "sort":          # (A/B and tests: force the sorting path)
+        counted = _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream)
+        if counted is not None:
+            return counted
     f64 = vdev.dtype == np.float64
     out = DeviceArray((n_zones,), np.float64)
     nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(vdev.size, n_zones, int(f64)))

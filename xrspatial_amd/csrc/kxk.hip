@@ -814,9 +814,7 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
         if (!__any(bad)) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                double *q = a.out + (y0 + r) * a.ld_out + x_tile + loff;
-                store_d2u(q, res[r][0], res[r][1]);
-                store_d2u(q + 2, res[r][2], res[r][3]);
+                store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[r][0], res[r][1], res[r][2], res[r][3]);
             }
             return;
         }
@@ -846,9 +844,7 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
                 const double c = w[1][o + 1];
                 m[o] = is_excluded(a, c) ? c : s / (double)n;           // 0/0 -> NaN like the reference
             }
-            double *q = a.out + (y0 + r) * a.ld_out + x_tile + loff;
-            store_d2u(q, m[0], m[1]);
-            store_d2u(q + 2, m[2], m[3]);
+            store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, m[0], m[1], m[2], m[3]);
         }
         return;
     }

@@ -142,7 +142,12 @@ __device__ __forceinline__ void terrain_strip_body(const TerrainArgs &a, long x_
             if ((OPS & OP_SLOPE) && a.out[0]) store4(static_cast<float *>(a.out[0]) + off + loff, o_slope);
             if ((OPS & OP_ASPECT) && a.out[1]) store4(static_cast<float *>(a.out[1]) + off + loff, o_aspect);
             if ((OPS & OP_CURV) && a.out[2]) store4(static_cast<float *>(a.out[2]) + off + loff, o_curv);
-            if ((OPS & OP_HILL) && a.out[3]) store4(static_cast<HillT *>(a.out[3]) + off + loff, o_hill);
+            if ((OPS & OP_HILL) && a.out[3]) {
+                if (INTERIOR && sizeof(HillT) == 8)     // float64 hillshade (the numpy path): whole-KiB store instructions
+                    store_wave_row_f4_as_d(reinterpret_cast<double *>(a.out[3]) + off, lane, o_hill[0], o_hill[1], o_hill[2], o_hill[3]);
+                else
+                    store4(static_cast<HillT *>(a.out[3]) + off + loff, o_hill);
+            }
         } else {
             if ((OPS & OP_SLOPE) && a.out[0]) store_n(static_cast<float *>(a.out[0]) + off + loff, o_slope, nown);
             if ((OPS & OP_ASPECT) && a.out[1]) store_n(static_cast<float *>(a.out[1]) + off + loff, o_aspect, nown);

@@ -168,6 +168,32 @@ __device__ __forceinline__ void store_d2u(double *p, double x, double y) {    //
     *reinterpret_cast<xrs_d2u *>(p) = q;
 #endif
 }
+// A wave's 256 adjacent float64 results (4 per lane, lane l owns columns 4l .. 4l+3) as TWO store instructions that
+// each write 1 KiB of consecutive bytes: lane pairs are transposed through ds_bpermute first.  Every lane storing its own
+// 32 bytes as two 16-byte halves makes each store instruction touch 64 x 16 B at a 32-byte stride -- two instructions
+// writing alternate halves of the same 2 KiB -- and costs a third of the bandwidth (experiments/f64_store.hip: 0.856 ->
+// 0.584 ms for a float32 -> float64 plane).  `row` = address of the wave's first result; ALL 64 lanes must be active
+// (wave-uniform control flow).
+__device__ __forceinline__ void store_wave_row_d4(double *row, int lane, double x, double y, double z, double w) {
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        // store k writes doubles [128 k + 2 lane, + 2): columns (2 lane, 2 lane + 1) of half k, owned by lane 32 k + lane / 2
+        const int src = 32 * k + (lane >> 1);
+        const double a0 = __shfl(x, src), a1 = __shfl(y, src), a2 = __shfl(z, src), a3 = __shfl(w, src);
+        store_d2u(row + 128 * k + 2 * lane, odd ? a2 : a0, odd ? a3 : a1);
+    }
+}
+// the same for float32 results that leave as float64 (converted after the exchange: half the shuffles)
+__device__ __forceinline__ void store_wave_row_f4_as_d(double *row, int lane, float x, float y, float z, float w) {
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int src = 32 * k + (lane >> 1);
+        const float a0 = __shfl(x, src), a1 = __shfl(y, src), a2 = __shfl(z, src), a3 = __shfl(w, src);
+        store_d2u(row + 128 * k + 2 * lane, (double)(odd ? a2 : a0), (double)(odd ? a3 : a1));
+    }
+}
 typedef float xrs_v4fu_st __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void store_f4u(float *p, float x, float y, float z, float w) {
 #if XRS_NT_STENCIL_STORES

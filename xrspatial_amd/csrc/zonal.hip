@@ -121,8 +121,10 @@ struct Acc {
     }
 };
 
-template <typename VT, bool LDS, bool VEC>
-__global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
+// NT threads per workgroup: 256, or 1024 when the zone table leaves room for only ONE workgroup per CU (more than 64 KiB of
+// LDS: 2 300+ zones) -- 16 waves then share the table instead of 4 (5 000 zones: 1.51 -> 1.36 ms; the rest is the flush of every workgroup's table with device atomics)
+template <typename VT, bool LDS, bool VEC, int NT = 256>
+__global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Acc<VT, LDS> acc;
     if (LDS) {
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
         acc.mn = reinterpret_cast<VT *>(acc.q + a.nz);
         acc.mx = acc.mn + a.nz;
         acc.c32 = reinterpret_cast<unsigned *>(acc.mx + a.nz);
-        for (int z = threadIdx.x; z < a.nz; z += 256) {
+        for (int z = threadIdx.x; z < a.nz; z += NT) {
             acc.s[z] = 0.0; acc.q[z] = 0.0; acc.c32[z] = 0u;
             acc.mn[z] = INFINITY; acc.mx[z] = -INFINITY;
         }
@@ -142,18 +144,19 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
     }
 
     const long n4 = VEC ? (a.n >> 2) : 0;
-    const long stride = (long)gridDim.x * 256;
+    const long stride = (long)gridDim.x * NT;
     // Each workgroup streams ONE contiguous chunk of the raster (chunks dealt to XCDs in contiguous runs),
     // not a grid-strided comb: contiguous chunks measured 1.3x faster on the per-cell kernels, and a chunk
     // of a real zone raster touches few zones, so the LDS flush at the end is short.
     const long n_chunks = gridDim.x;                                           // a multiple of 8
     const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
-    const long per_chunk = ((n4 + n_chunks - 1) / n_chunks + 1023) & ~1023L;    // multiple of one workgroup trip
+    constexpr long TRIP = (long)NT * 4;                                        // 16-byte slots of one workgroup trip (U = 4)
+    const long per_chunk = (((n4 + n_chunks - 1) / n_chunks + TRIP - 1) / TRIP) * TRIP;
     const long c_begin = my_chunk * per_chunk;
     const long c_end = (my_chunk < n_chunks && c_begin < n4) ? (c_begin + per_chunk < n4 ? c_begin + per_chunk : n4) : c_begin;
     constexpr int U = 4;                    // 16-byte slots per lane per trip, 64 slots apart: a wave covers 1024
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // consecutive cells per load instruction
-    for (long i0 = c_begin; i0 < c_end; i0 += 256 * U) {
+    for (long i0 = c_begin; i0 < c_end; i0 += NT * U) {
         // (whole waves stay converged for the reductions: the loop bound is wave-uniform)
         int z[4 * U];
         VT v[4 * U];
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
     }
 
     // scalar tail (n % 4 cells, or everything when the buffers are not 16-byte aligned)
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += stride) {
         const int z = (a.lut ? zone_of(a, a.zidx[i]) : a.zidx[i]) - a.zbase;
         const VT v = a.vals[i];
         if (cell_ok(a, z, v)) {
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) zonal_kernel(const ZonalArgs<VT> a) {
 
     if (LDS) {
         __syncthreads();
-        for (int z = threadIdx.x; z < a.nz; z += 256) {
+        for (int z = threadIdx.x; z < a.nz; z += NT) {
             const unsigned c = acc.c32[z];
             if (c) {
                 atomicAdd(&a.count[z], (unsigned long long)c);
@@ -289,11 +292,6 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     // 21 ms for the same raster.
     const int window = (int)(lds_cap / per_zone);
     const bool vec = aligned16(zone_idx_dev) && aligned16(values_dev);
-    long grid = ((vec ? (n + 3) / 4 : n) + 255) / 256;
-    const long cap = 256L * 8;                                   // 8 chunks per CU
-    if (grid > cap) grid = cap;
-    if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
-    grid = xcd_grid(grid, 1);                                       // multiple of 8: chunk <-> XCD mapping is a bijection
     hipStream_t s = as_stream(stream);
     for (int base = 0; base < n_zones; base += window) {
         const int nzw = n_zones - base < window ? n_zones - base : window;
@@ -301,15 +299,25 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
         a.count = reinterpret_cast<unsigned long long *>(count_dev) + base;
         a.sum = sum_dev + base; a.sumsq = sumsq_dev + base; a.mn = min_dev + base; a.mx = max_dev + base;
         const size_t smem = (size_t)nzw * per_zone;
-        if (smem > 64 * 1024) {
+        const bool big = smem > 64 * 1024;                        // one workgroup per CU: make it 1024 threads
+        const int nt = big ? 1024 : 256;
+        long grid = ((vec ? (n + 3) / 4 : n) + nt - 1) / nt;
+        const long cap = big ? 256L * 2 : 256L * 8;               // chunks: 8 (2) per CU
+        if (grid > cap) grid = cap;
+        if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
+        grid = xcd_grid(grid, 1);                                 // multiple of 8: chunk <-> XCD mapping is a bijection
+        if (big) {
             // (idempotent per instantiation; a race only repeats the call)
-            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true>),
+            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true, 1024>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, false>),
+            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, false, 1024>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+            if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
+            else hipLaunchKernelGGL((zonal_kernel<VT, true, false, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
+        } else {
+            if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true>), dim3((unsigned)grid), dim3(256), smem, s, a);
+            else hipLaunchKernelGGL((zonal_kernel<VT, true, false>), dim3((unsigned)grid), dim3(256), smem, s, a);
         }
-        if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true>), dim3((unsigned)grid), dim3(256), smem, s, a);
-        else hipLaunchKernelGGL((zonal_kernel<VT, true, false>), dim3((unsigned)grid), dim3(256), smem, s, a);
     }
     XRS_LAUNCH_CHECK();
     return 0;

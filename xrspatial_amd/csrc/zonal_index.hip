@@ -286,32 +286,33 @@ int xrs_zonal_index(const void *zones_dev, int zone_dtype, int64_t n, double zmi
 // workgroup in LDS when the zone x category table fits (<= 36864 cells = 144 KiB), flushed once with device atomics.
 namespace {
 
-template <bool LDS>
-__global__ void __launch_bounds__(256) crosstab_kernel(const int32_t *zidx, const int32_t *cidx, long n, int nz, int nc,
+// NT threads per workgroup: 1024 when the table is so large (> 64 KiB) that only one workgroup fits a CU
+template <bool LDS, int NT = 256>
+__global__ void __launch_bounds__(NT) crosstab_kernel(const int32_t *zidx, const int32_t *cidx, long n, int nz, int nc,
                                                        unsigned long long *counts, const int vec) {
     extern __shared__ unsigned local[];
     const int cells = nz * nc;
     if (LDS) {
-        for (int i = threadIdx.x; i < cells; i += 256) local[i] = 0u;
+        for (int i = threadIdx.x; i < cells; i += NT) local[i] = 0u;
         __syncthreads();
     }
     const long n4 = vec ? n >> 2 : 0;
-    const long stride = (long)gridDim.x * 256;
+    const long stride = (long)gridDim.x * NT;
     auto bump = [&](int z, int c) {
         if (z >= 0 && z < nz && c >= 0 && c < nc) {
             if (LDS) atomicAdd(&local[z * nc + c], 1u);
             else atomicAdd(&counts[(long)z * nc + c], 1ull);
         }
     };
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
         const int4 z = reinterpret_cast<const int4 *>(zidx)[i];
         const int4 c = reinterpret_cast<const int4 *>(cidx)[i];
         bump(z.x, c.x); bump(z.y, c.y); bump(z.z, c.z); bump(z.w, c.w);
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bump(zidx[i], cidx[i]);
+    for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += stride) bump(zidx[i], cidx[i]);
     if (LDS) {
         __syncthreads();
-        for (int i = threadIdx.x; i < cells; i += 256)
+        for (int i = threadIdx.x; i < cells; i += NT)
             if (local[i]) atomicAdd(&counts[i], (unsigned long long)local[i]);
     }
 }
@@ -334,19 +335,23 @@ extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *c
         // per-workgroup counters in LDS: up to 144 KiB of the CU's 160 KiB (one workgroup per CU then; the table of a
         // 1000-zone x 32-class crosstab fits, and global atomics on it measured 40x slower)
         if (cells > 16384) {
+            // more than 64 KiB: one workgroup per CU -- 1024 threads so that 16 waves share the table (1000 x 32: 1.07 ms with 256)
             static bool raised = false;        // (idempotent; a race only repeats the call)
             if (!raised) {
-                XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&crosstab_kernel<true>),
+                XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&crosstab_kernel<true, 1024>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
                 raised = true;
             }
             if (grid > 256 * 2) grid = 256 * 2;
+            hipLaunchKernelGGL((crosstab_kernel<true, 1024>), dim3((unsigned)grid), dim3(1024), (size_t)cells * 4, as_stream(stream),
+                               zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
+        } else {
+            hipLaunchKernelGGL((crosstab_kernel<true>), dim3((unsigned)grid), dim3(256), (size_t)cells * 4, as_stream(stream),
+                               zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
         }
-        hipLaunchKernelGGL(crosstab_kernel<true>, dim3((unsigned)grid), dim3(256), (size_t)cells * 4, as_stream(stream),
-                           zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
     }
     else
-        hipLaunchKernelGGL(crosstab_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL((crosstab_kernel<false>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
                            zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
     XRS_LAUNCH_CHECK();
     return 0;

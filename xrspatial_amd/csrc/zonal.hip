@@ -302,7 +302,7 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
         const bool big = smem > 64 * 1024;                        // one workgroup per CU: make it 1024 threads
         const int nt = big ? 1024 : 256;
         long grid = ((vec ? (n + 3) / 4 : n) + nt - 1) / nt;
-        const long cap = big ? 256L * 2 : 256L * 8;               // chunks: 8 (2) per CU
+        const long cap = big ? 256L : 256L * 8;                   // chunks: 8 per CU, or one (a second one would only flush a second table)
         if (grid > cap) grid = cap;
         if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
         grid = xcd_grid(grid, 1);                                 // multiple of 8: chunk <-> XCD mapping is a bijection

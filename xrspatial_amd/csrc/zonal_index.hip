@@ -342,7 +342,7 @@ extern "C" int xrs_crosstab_counts(const int32_t *zone_idx_dev, const int32_t *c
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
                 raised = true;
             }
-            if (grid > 256 * 2) grid = 256 * 2;
+            if (grid > 256) grid = 256;            // one workgroup per CU: a second one would only flush a second table
             hipLaunchKernelGGL((crosstab_kernel<true, 1024>), dim3((unsigned)grid), dim3(1024), (size_t)cells * 4, as_stream(stream),
                                zone_idx_dev, cat_idx_dev, (long)n, n_zones, n_cats, counts, vec);
         } else {

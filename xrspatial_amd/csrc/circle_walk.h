@@ -94,6 +94,39 @@ __device__ __forceinline__ void ring_rotate(float (&a)[K][N]) {                /
     }
 }
 
+
+// Work order of the third-generation walkers (ext_impl.h, mom_impl.h): the workgroups on the rim of the raster first,
+// then the interior in one contiguous band per XCD.  A rim workgroup runs its predicated edge walk 2-3x longer than an
+// interior one; left where the row-major order puts them, the bottom row of tiles is the last thing one XCD starts and the
+// whole launch waits for it (measured on the 25x25 moments kernel: 1.85 ms -> see DESIGN.md), and the top row delays
+// another.  Dealt out first, round-robin over the XCDs, they are spread evenly and their tails hide behind interior work.
+// (gy, gx) of workgroup `block` in a gw x gh grid of workgroup tiles; false for the surplus blocks of the padded grid.
+struct RimFirst {
+    long gw, gh, n_rim, n_all;
+    __host__ __device__ RimFirst(long gw_, long gh_) : gw(gw_), gh(gh_) {
+        n_all = gw * gh;
+        n_rim = (gw <= 2 || gh <= 2) ? n_all : 2 * gw + 2 * (gh - 2);
+    }
+    __host__ long grid() const { return n_rim + xcd_grid(n_all - n_rim, 0); }
+    __device__ __forceinline__ bool locate(long block, long &gy, long &gx) const {
+        if (block < n_rim) {
+            if (n_rim == n_all) { gy = block / gw; gx = block - gy * gw; return true; }
+            if (block < gw) { gy = 0; gx = block; return true; }
+            if (block < 2 * gw) { gy = gh - 1; gx = block - gw; return true; }
+            const long r = block - 2 * gw;
+            gy = 1 + (r >> 1);
+            gx = (r & 1) ? gw - 1 : 0;
+            return true;
+        }
+        const long iw = gw - 2, ih = gh - 2;
+        const long t = xcd_tile(block - n_rim, iw * ih, 0);
+        if (t < 0) return false;
+        gy = 1 + t / iw;
+        gx = 1 + (t - (gy - 1) * iw);
+        return true;
+    }
+};
+
 struct WalkGeom {
     const float *in;
     long rows, cols, ld_in, ld_out;

@@ -1125,10 +1125,44 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
         if (rc >= 0) return rc;
     }
     if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
-        // several statistics: all of them from one pass of the second-generation column walker (walk2_impl.h); a
-        // sequential `sum` comes from its own kernel
+        // several statistics on a circle / box: the extrema walker (ext_impl.h: max / min / range) and the moments walker
+        // (mom_impl.h: mean / var / std / sum), each one pass; a sequential `sum` comes from its own kernel.
+        // XRS_FOCAL_GEN=2: round 2's one-pass float64 column walker (walk2_impl.h) for A/B runs.
         float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
-        // only the passes the request needs: extrema (max / min / range), moments (mean / var / std / sum), or both
+        const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
+        const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
+        const bool gen2 = gen && gen[0] == '2';
+        if (!gen2) {
+            int rc = 0;
+            if (want_mom) {
+                rc = try_launch_focal_mom_circle(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD],
+                                                 rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+                if (rc < 0)
+                    rc = try_launch_focal_mom_box(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD],
+                                                  rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            }
+            if (rc == 0 && want_mm) {
+                rc = try_launch_focal_ext_circle(in_dev, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], rows,
+                                                 cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+                if (rc < 0)
+                    rc = try_launch_focal_ext_box(in_dev, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], rows,
+                                                  cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+            }
+            if (rc > 0) return rc;
+            if (rc == 0) {
+                if (!(seq_sum && a.out[XRS_STAT_SUM])) return 0;
+                float *only_sum[XRS_NUM_STATS] = {nullptr};
+                only_sum[XRS_STAT_SUM] = a.out[XRS_STAT_SUM];
+                const int rc2 = try_walk_f32(in_dev, only_sum, false, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
+                                             halo_bot, s);
+                if (rc2 >= 0) return rc2;
+                return fail("xrs_focal_stats_f32: no sequential-sum kernel for this mask");
+            }
+            // (rc < 0: neither a circle nor a box of radius 4..12 -- the kernels below)
+        }
+    }
+    if (gen && gen[0] == '2' && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
+        float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
         const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
         const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
         typedef int (*Walk2Fn)(const float *, float *, float *, float *, float *, float *, float *, float *, long, long, long,

@@ -1,0 +1,524 @@
+// Focal mean / var / std / sum over large circular / box masks in ONE pass -- focal_stats(agg, circle_kernel(...),
+// ['mean', 'std', 'var', 'sum']) with 9x9 .. 25x25 windows (xrspatial/focal.py:782-797 runs one apply() pass per statistic,
+// each gathering the window per cell for a numba reducer, :226-258: nanmean / nanvar / nanstd with float64 accumulators,
+// nansum in the array dtype).
+//
+// Third generation of the moments walk (first: circle_walk.h WalkF64, second: walk2_impl.h's moments pass: float64 sums
+// of values shifted by one constant per wave tile -- ~100 float64 instructions per cell and row, which on gfx950 issue
+// at half the rate of v_add_f32 / v_mul_f32: experiments/valu_rate2.hip).  Here everything per row is a float32 add,
+// subtract or multiply, and what float32 cannot hold is kept out of the sums by construction:
+//   * the wide row walk of wide_impl.h: a wave owns 64 NC columns x ~130 output rows and walks down; rows arrive in a
+//     private LDS ring by LDS-DMA (lds_dma.h), D rows ahead; a lane owns NC adjacent columns, reads the NC + 2 HL cells
+//     under their windows, subtracts ITS shift c, squares, and builds lane-local prefix sums of w and w^2: every distinct
+//     half-width of the mask is then ONE subtraction per cell and moment, added into the register ring of the 2R+1
+//     output rows in flight (compile-time indices: U = 5 rows per unrolled round, ring rotated once per round);
+//   * the shift TRAILS the walk.  One constant per tile makes sum w^2 ~ n (var + m^2) with m the distance between the
+//     window mean and the shift: on a slope of g per cell m reaches 70 g at the end of a tile against var = 36 g^2 for
+//     a radius-12 circle, and float32 loses 7 bits to the cancellation.  Instead every lane re-centres once per round:
+//     c' = c + (mean of the widest run of the round's first row) -- a value of the lane's own columns a few rows behind
+//     the walk -- and the 2R+1 partial sums move with it by exact algebra, S' = S - N d, Q' = Q - d (S + S'), N = the
+//     (compile-time) number of cells the slot has seen and d = c' - c.  sum w^2 then stays within a small multiple of
+//     n var: the emulation of these exact operations (experiments/f32_moments_emul.py) gives var within 8e-7 of a
+//     float64 two-pass reference on the steep parity-stress DEM, 4e-7 on the benchmark DEM; with one shift per tile 5e-3;
+//   * a guard per output decides whether float32 was good enough: with B = Q + n max(d^2 of the slot's re-centrings)
+//     bounding every partial sum the slot went through, var is accepted if n var >= B / 5 (amplification <= 5: error
+//     <~ 30 u 5 < 1e-5) and mean / sum if mean^2 >= 0.04 B / n; otherwise -- flat windows next to relief, values
+//     straddling zero, NaN / inf anywhere under a window (the comparisons fail on non-finite sums) -- the whole tile
+//     is redone by the exact float64 NaN-skipping walker of circle_walk.h, like the tiles at the raster edge.
+//     A window over equal cells passes with S = Q = 0 exactly (its shift has converged onto the value) or is redone;
+//   * sum = n c + S (one fma), mean = c + S / n, var = (Q - S^2 / n) / n, std = sqrt(var) in float32.
+// Included by kxk_mom_circle.hip / kxk_mom_box.hip, which define XRS_MOM_SHAPE / XRS_MOM_ENTRY.
+#include "circle_walk.h"
+#include "lds_dma.h"
+
+#include <utility>
+
+using namespace xrs;
+
+namespace {
+
+struct MomArgs {
+    WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
+    float *out_sum, *out_mean, *out_var, *out_std;
+    long n_groups, groups_x;      // workgroups = groups of 4 horizontally adjacent wave tiles
+};
+
+template <int R, typename Shape>
+struct MomCfg {
+    static constexpr int K = 2 * R + 1;
+#ifndef XRS_MOM_NC
+#define XRS_MOM_NC 2
+#endif
+    static constexpr int NC = XRS_MOM_NC;                  // columns per lane
+    static constexpr int TW = 64 * NC;                     // columns per wave tile
+    static constexpr int HL = NC * ((R + NC - 1) / NC);    // halo columns each side, whole lane groups
+    static constexpr int NV = NC + 2 * HL;                 // cells a lane reads back per row
+    static constexpr int NQ = NV / NC;
+    static constexpr int CELLS = TW + 2 * HL;
+    static_assert(CELLS <= 256, "one 16-byte DMA per row");
+    static constexpr int NTAPS = shape_taps<Shape>(R);
+#ifndef XRS_MOM_U
+#define XRS_MOM_U 5
+#endif
+    static constexpr int U = XRS_MOM_U;                    // rows per unrolled round = rows between two re-centrings
+#ifndef XRS_MOM_D
+#define XRS_MOM_D 8
+#endif
+    static constexpr int D = XRS_MOM_D;                    // rows in flight by LDS-DMA; D + 1 row buffers per wave
+    static constexpr int RBF = 256;                        // floats per row buffer (the 16-byte DMA writes a whole KiB)
+    static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: whole rounds
+    static constexpr int WTH = NIN - 2 * R;                // output rows per wave tile
+    // How much of a re-centring by d is still inside the partial sums of the rows about to be emitted: a row emitted k
+    // rounds later was at most K - (k - 1) U - 1 input rows old when it happened, i.e. held that fraction of its cells
+    // (radius 12, U = 5: 1, 0.84, 0.6, 0.33, 0.09, 0).  Kept as two numbers: d^2 of the last re-centring and a decaying
+    // maximum of the older ones (x 0.85, then x 0.7 per round: 0.85, 0.6, 0.42, 0.29 ... -- never below the table).
+    static constexpr float HIST_FIRST = 0.85f, HIST_DECAY = 0.7f;
+    static constexpr bool level_used(int h) {
+        for (int dy = 0; dy <= R; ++dy)
+            if (Shape::hw(R, dy) == h) return true;
+        return false;
+    }
+    // cells a ring slot has accumulated at a round boundary: the slot that the next row will hit at offset dy_next
+    // has seen the rows at offsets -R .. dy_next - 1
+    static constexpr int seen(int idx) {
+        const int dy_next = idx <= R ? -idx : K - idx;
+        int n = 0;
+        for (int dy = -R; dy < dy_next; ++dy) n += 2 * Shape::hw(R, dy < 0 ? -dy : dy) + 1;
+        return n;
+    }
+};
+
+// number of in-raster cells under the window centred on (yo, x): rows [y_lo, y_hi), columns [0, cols)
+template <int R, typename Shape>
+__device__ __forceinline__ int mom_clipped_count(long yo, long x, long y_lo, long y_hi, long cols) {
+    int n = 0;
+    for (int dy = -R; dy <= R; ++dy) {
+        const long yr = yo + dy;
+        if (yr < y_lo || yr >= y_hi) continue;
+        const int h = Shape::hw(R, dy < 0 ? -dy : dy);
+        const long a = x - h < 0 ? 0 : x - h, b = x + h > cols - 1 ? cols - 1 : x + h;
+        n += b >= a ? (int)(b - a + 1) : 0;
+    }
+    return n;
+}
+
+// OM: the outputs the launch writes (bit 0 sum, 1 mean, 2 var, 3 std) as a compile-time set, or 0 = whatever pointers are
+// non-null at run time.  The common sets are compiled in because the run-time form keeps its "is this plane wanted" flags
+// in vector registers this kernel does not have (one spilled flag = one scratch reload + s_waitcnt vmcnt(0) per round,
+// which drains the DMA ring); it also sets the vmcnt bookkeeping of the ring (assuming fewer stores than the truth is safe).
+enum : int { MOM_SUM = 1, MOM_MEAN = 2, MOM_VAR = 4, MOM_STD = 8 };
+// EDGE = false: a full tile whose whole input window lies inside the raster (LDS-DMA ring, no predicates, trailing shift);
+// EDGE = true: tiles at the raster / shard edge and partial tiles: predicated loads staged through LDS with NaN for the
+// cells outside (a reader turns them into w = 0), divisors = the geometric count of in-raster cells under each window,
+// ONE shift per lane for the whole tile (no re-centring: the number of cells a partial sum has seen is not a compile-time
+// constant here).  The guard is the same, so on steep relief an edge tile is more likely to end in the exact walker.
+template <int R, typename Shape, int OM, bool EDGE>
+struct MomWalk {
+    static constexpr int NO = OM == 0 ? 1 : ((OM & 1) + (OM >> 1 & 1) + (OM >> 2 & 1) + (OM >> 3 & 1));
+    __device__ __forceinline__ bool want(int bit, const float *p) const { return OM ? (OM & bit) != 0 : p != nullptr; }
+    using C = MomCfg<R, Shape>;
+    static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW, D = C::D;
+
+    float accS[K][NC], accQ[K][NC];
+    float c, c_next;               // the lane's shift and its successor (taken at the first row of the round)
+    float dq_last, dq_old;         // d^2 of the last re-centring; decaying maximum of the older ones
+    float dqn;                     // NTAPS * max of both: what the re-centrings added to the partial sums of squares
+    int slot_in, slot_out;
+    unsigned ring_addr;
+    float pf_own[EDGE ? U : 1][NC], pf_halo[EDGE ? U : 1];     // EDGE: the rows of the current round, loaded up front
+    float n_full[NC];              // EDGE: cell count of a window whose rows are all inside, per owned column
+    long y_end;
+    int n_in;
+    unsigned long long badm;       // lanes with an output that failed its guard (wave-uniform)
+    float gm;                      // 0.04 / n if mean or sum is requested, else 0 (that guard always passes)
+    int t;
+
+    const MomArgs &a;
+    const WalkGeom &g;
+    float *lds;
+    long x_tile, y0, y_first;
+    int lane;
+
+    __device__ __forceinline__ MomWalk(const MomArgs &a_, float *lds_, long xt, long y0_, long ye, int lane_)
+        : a(a_), g(a_.g), lds(lds_), x_tile(xt), y0(y0_), lane(lane_) { y_end = ye; }
+
+    // EDGE: staged cell s <-> raster column x_tile - HL + s; lane owns s = NC*lane .. NC*lane+NC-1, the 2*HL halo cells
+    // s = TW + lane come from the first 2*HL lanes.  NaN outside the raster; a NaN cell INSIDE it cannot be told from that
+    // by the readers, so the loader reports it (the tile then goes to the exact walker, which skips and counts)
+    __device__ __forceinline__ void load_row(int il, float (&own)[NC], float &halo) {
+        const long yy = y_first + il;
+        const long xs = x_tile - HL + NC * lane;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) own[e] = nan_f32();
+        halo = nan_f32();
+        const bool row_ok = il < n_in && yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;     // wave-uniform
+        if (!row_ok) return;
+        const float *p = g.in + yy * g.ld_in;
+        bool hole = false;
+#pragma unroll
+        for (int e = 0; e < NC; ++e)
+            if (xs + e >= 0 && xs + e < g.cols) { own[e] = p[xs + e]; hole |= own[e] != own[e]; }
+        const long xh = x_tile - HL + TW + lane;
+        if (lane < 2 * HL && xh >= 0 && xh < g.cols) { halo = p[xh]; hole |= halo != halo; }
+        badm |= __builtin_amdgcn_ballot_w64(hole);
+    }
+
+    __device__ __forceinline__ void dma_row(int il, int slot) const {
+        const int ilc = il < C::NIN ? il : C::NIN - 1;
+        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - HL));
+        constexpr int QMAX = C::CELLS / 4 - 1;
+        glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), ring_addr + (unsigned)slot * (C::RBF * 4));
+    }
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int o = 0; o < NC; ++o) { accS[j][o] = 0.0f; accQ[j][o] = 0.0f; }
+        dq_last = dq_old = dqn = 0.0f;
+        badm = 0;
+        gm = (want(MOM_MEAN, a.out_mean) || want(MOM_SUM, a.out_sum)) ? 0.04f / (float)C::NTAPS : 0.0f;
+        t = 0;
+        y_first = y0 - R;
+        n_in = EDGE ? (int)(y_end - y0) + 2 * R : C::NIN;
+        ring_addr = lds_addr(lds);
+        if (EDGE) {
+            // the one shift of an edge tile: the mean of the lane's own columns in eight rows spread over the tile (a single
+            // cell of a noisy raster is off the window means by the noise itself, and sum w^2 pays for it: var + m^2)
+            const long h8 = (y_end - y0) / 8;
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const long yr = y0 + (y_end - y0) / 16 + r * h8;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    const long xc = x_tile + NC * lane + o < g.cols ? x_tile + NC * lane + o : g.cols - 1;
+                    acc += g.in[yr * g.ld_in + xc];
+                }
+            }
+            acc *= 1.0f / (float)(8 * NC);
+            c = isfinite(acc) ? acc : 0.0f;
+            c_next = c;
+#pragma unroll
+            for (int o = 0; o < NC; ++o)
+                n_full[o] = (float)mom_clipped_count<R, Shape>(0, x_tile + NC * lane + o, -(long)R, (long)R + 1, g.cols);
+            return;
+        }
+        // first shift: the mean of four cells of the lane's own columns in the first two rows (any finite value works and
+        // the first re-centring replaces it before any output row is complete; a single noisy cell would make that first
+        // step large enough to trip the guard of the tile's first output rows)
+        const float *p0 = g.in + y_first * g.ld_in + x_tile + NC * lane;
+        const float c0 = 0.25f * ((p0[0] + p0[NC - 1]) + (p0[g.ld_in] + p0[g.ld_in + NC - 1]));
+        c = isfinite(c0) ? c0 : 0.0f;
+        c_next = c;
+        for (int r = 0; r < D; ++r) dma_row(r, r);
+        slot_in = D;
+        slot_out = 0;
+    }
+
+    typedef float ldsNC __attribute__((ext_vector_type(NC)));
+    typedef float stNC __attribute__((ext_vector_type(NC), aligned(4)));
+
+    // NC results per lane to the wave-uniform row address `p` (streaming store, scalar base + 32-bit lane offset: the
+    // compiler otherwise keeps a 64-bit lane address per output plane alive across the walk)
+    __device__ __forceinline__ void store_row(float *p, stNC v) const {
+        const unsigned lane_b = (unsigned)(NC * 4) * (unsigned)lane;
+        if (NC == 2) { lds_dma_v2f q; q[0] = v[0]; q[1] = v[NC - 1]; st_row_nt(uniform_ptr(p), lane_b, q); }
+        else if (NC == 1) st_row_nt(uniform_ptr(p), lane_b, v[0]);
+        else __builtin_nontemporal_store(v, reinterpret_cast<stNC *>(reinterpret_cast<char *>(p) + lane_b));
+    }
+
+    template <int PHASE, bool SQ>
+    __device__ __forceinline__ void moment_pass(unsigned row_addr) {
+        float w[NV];
+        typedef __attribute__((address_space(3))) const ldsNC lds_cvec;
+        lds_cvec *row = (lds_cvec *)(size_t)row_addr;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            const ldsNC v = row[b];
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+                float d = v[e] - c;
+                if (EDGE) d = d == d ? d : 0.0f;                  // a cell outside the raster
+                w[NC * b + e] = SQ ? d * d : d;
+            }
+        }
+        float w0[NC];                                         // the centre cells themselves (half-width 0)
+#pragma unroll
+        for (int o = 0; o < NC; ++o) w0[o] = w[HL + o];
+#pragma unroll
+        for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
+#pragma unroll
+        for (int h = 0; h <= R; ++h) {
+            if (!C::level_used(h)) continue;
+            float S[NC];
+#pragma unroll
+            for (int o = 0; o < NC; ++o) {
+                const int hi = HL + o + h, lo = HL + o - h - 1;
+                S[o] = h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
+            }
+            if (!EDGE && !SQ && PHASE == 0 && h == R) c_next = fmaf(S[0], 1.0f / (float)K, c);       // (hw(0) == R for every shape)
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int dy = j - R;
+                if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
+                const int idx = ((PHASE - dy) % K + K) % K;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    if (SQ) accQ[idx][o] += S[o];
+                    else accS[idx][o] += S[o];
+                }
+            }
+        }
+    }
+
+    template <int PHASE>
+    __device__ __forceinline__ void step() {
+        const int i = t + PHASE;
+        unsigned row;                  // LDS byte address of the lane's first cell in the staged row
+        if (EDGE) {
+            if (i >= n_in) return;
+            float *stage = lds;    // ONE row buffer: LDS serves a wave's instructions in order, so the next row's writes
+                                   // (issued after this row's reads) cannot overtake them
+            ldsNC q;
+#pragma unroll
+            for (int e = 0; e < NC; ++e) q[e] = pf_own[PHASE][e];
+            *reinterpret_cast<ldsNC *>(stage + NC * lane) = q;
+            stage[TW + lane] = pf_halo[PHASE];                   // (lanes >= 2*HL: a slot nobody reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            row = ring_addr + (unsigned)(NC * 4) * (unsigned)lane;
+        } else {
+            dma_row(i + D, slot_in);
+            slot_in = slot_in + 1 == D + 1 ? 0 : slot_in + 1;
+            // row i was issued D steps ago; younger: D DMAs and -- once the walk emits, from row 2R on -- NO stores per step
+            if (i >= 2 * R + D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D * (1 + NO)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");
+            row = ring_addr + (unsigned)slot_out * (C::RBF * 4) + (unsigned)(NC * 4) * (unsigned)lane;
+            slot_out = slot_out + 1 == D + 1 ? 0 : slot_out + 1;
+        }
+
+        // ---- the NV cells under the lane's windows about the lane's shift, lane-local prefix sums, and every distinct
+        // half-width once into the ring slots of the output rows that see this row with it: first the values, then their
+        // squares.  (The compiler merges the two passes' reads and subtractions.  Forcing a second set of reads with a
+        // memory barrier between the passes -- XRS_MOM_SPLIT_READS -- should need 26 registers less; this compiler then
+        // spills 53 instead.)
+        asm volatile("" : "+v"(row));                         // (one base register + immediate offsets for the reads)
+        moment_pass<PHASE, false>(row);
+#ifdef XRS_MOM_SPLIT_READS
+        asm volatile("" ::: "memory");
+#endif
+#ifndef XRS_MOM_T_NOQ
+        moment_pass<PHASE, true>(row);
+#endif
+
+        if (EDGE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- the output row R rows up is complete
+        constexpr int DONE = ((PHASE - R) % K + K) % K;
+        if (EDGE && i >= 2 * R) {
+            const long yo = y0 + (i - 2 * R);
+            const long xo = x_tile + NC * lane;
+            const bool rows_in = yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot;       // wave-uniform
+#pragma unroll
+            for (int o = 0; o < NC; ++o) {
+                const float n = rows_in ? n_full[o]
+                                        : (float)mom_clipped_count<R, Shape>(yo, xo + o, -(long)g.halo_top, g.rows + g.halo_bot, g.cols);
+                const float S = accS[DONE][o], Q = accQ[DONE][o];
+                const float ms = S / n;
+                const float mean = c + ms;
+                const float e = Q - S * ms;
+                const bool live = xo + o < g.cols;
+                badm |= __builtin_amdgcn_ballot_w64(live && !(e >= 0.2f * Q));
+                badm |= __builtin_amdgcn_ballot_w64(live && !(mean * mean * n >= (gm * (float)C::NTAPS) * Q));
+                const float var = e / n;
+                if (live) {
+                    const long off = yo * g.ld_out + xo + o;
+                    if (want(MOM_MEAN, a.out_mean)) a.out_mean[off] = mean;
+                    if (want(MOM_VAR, a.out_var)) a.out_var[off] = var;
+                    if (want(MOM_STD, a.out_std)) a.out_std[off] = sqrtf(var);
+                    if (want(MOM_SUM, a.out_sum)) a.out_sum[off] = fmaf(n, c, S);
+                }
+            }
+        }
+        if (!EDGE && i >= 2 * R) {
+            // (row base in scalar registers + one 32-bit lane offset; written as inline asm because the compiler otherwise
+            // keeps a 64-bit lane address per output plane alive across the whole walk: 8 registers this kernel does not have)
+            const long rowoff = (y0 + (i - 2 * R)) * g.ld_out + x_tile;
+            constexpr float inv = 1.0f / (float)C::NTAPS;
+            stNC r_sum, r_mean, r_var, r_std;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) {
+                const float S = accS[DONE][o], Q = accQ[DONE][o];
+                const float ms = S * inv;
+                const float mean = c + ms;
+                const float e = Q - S * ms;                   // n * variance
+                const float B = Q + dqn;                      // bounds every partial sum of squares of this output row
+                // (negated comparisons: a non-finite sum fails them)
+                // (ballots: the verdicts stay in scalar registers)
+                badm |= __builtin_amdgcn_ballot_w64(!(e >= 0.2f * B));
+                badm |= __builtin_amdgcn_ballot_w64(!(mean * mean >= gm * B));
+                const float var = e * inv;
+                r_mean[o] = mean;
+                r_var[o] = var;
+                r_std[o] = sqrtf(var);
+                r_sum[o] = fmaf((float)C::NTAPS, c, S);
+            }
+            if (want(MOM_MEAN, a.out_mean)) store_row(a.out_mean + rowoff, r_mean);
+            if (want(MOM_VAR, a.out_var)) store_row(a.out_var + rowoff, r_var);
+            if (want(MOM_STD, a.out_std)) store_row(a.out_std + rowoff, r_std);
+            if (want(MOM_SUM, a.out_sum)) store_row(a.out_sum + rowoff, r_sum);
+        }
+#pragma unroll
+        for (int o = 0; o < NC; ++o) { accS[DONE][o] = 0.0f; accQ[DONE][o] = 0.0f; }
+    }
+
+    // the partial sums of every output row in flight, moved from shift c to c_next (ring already rotated: slot idx will be
+    // hit next at offset -idx or K - idx and has seen C::seen(idx) cells)
+    template <int... J>
+    __device__ __forceinline__ void recentre(std::integer_sequence<int, J...>) {
+        const float d = c_next - c;
+        auto one = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr float N = (float)C::seen(j);
+            if (C::seen(j) == 0) return;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) {
+                const float S = accS[j][o];
+                const float S2 = S - N * d;
+                accQ[j][o] -= d * (S + S2);
+                accS[j][o] = S2;
+            }
+        };
+        (one(std::integral_constant<int, J>{}), ...);
+        c = c_next;
+        dq_old = fmaxf(dq_last * C::HIST_FIRST, dq_old * C::HIST_DECAY);
+        dq_last = d * d;
+        dqn = (float)C::NTAPS * fmaxf(dq_last, dq_old);
+    }
+
+    template <int... P>
+    __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
+        if (EDGE) (load_row(t + P, pf_own[P], pf_halo[P]), ...);      // edge tiles: all loads of the round first
+        (step<P>(), ...);
+        ring_rotate<K, U>(accS);
+        ring_rotate<K, U>(accQ);
+        t += U;
+#ifndef XRS_MOM_T_NORECENTRE
+        if (!EDGE) recentre(std::make_integer_sequence<int, K>{});
+#endif
+    }
+
+    // true: every result of the tile is good; false: the caller redoes the tile with the float64 walker
+    __device__ __forceinline__ bool run() {
+        init();
+        while (t < n_in) {
+            round(std::make_integer_sequence<int, U>{});
+            if (badm) return false;
+        }
+        return true;
+    }
+};
+
+// raster edges, non-finite cells under a window, sums too ill-conditioned for float32: the exact float64 column walker
+// (NaN-skipping, counting, the reference's two-pass variance where it matters), 64 columns at a time.  
+template <int R, typename Shape>
+__device__ __forceinline__ void mom_exact_tile(const MomArgs &a, long x_tile, int lane, long y0, long y_end) {
+    using C = MomCfg<R, Shape>;
+    const WalkGeom &g = a.g;
+    const WalkOuts o = {a.out_sum, nullptr, nullptr, nullptr, a.out_mean, a.out_var, a.out_std};
+    for (int q = 0; q < C::NC; ++q) {
+        if (a.out_mean || a.out_var || a.out_std) {
+            if (a.out_var || a.out_std) walk_columns<R, Shape, false, false, false, true, true>(g, o, x_tile + 64 * q, lane, y0, y_end);
+            else walk_columns<R, Shape, false, false, false, true, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
+        }
+        if (a.out_sum) walk_columns<R, Shape, true, true, false, false, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
+    }
+}
+
+#ifndef XRS_MOM_WAVES
+#define XRS_MOM_WAVES 2           // workgroups per CU = waves per SIMD
+#endif
+template <int R, typename Shape, int OM>
+__global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const MomArgs a) {
+    using C = MomCfg<R, Shape>;
+    __shared__ __attribute__((aligned(16))) float lds_rows[4][(C::D + 1) * C::RBF];
+    long ty, gx;
+    if (!RimFirst(a.groups_x, a.n_groups / a.groups_x).locate(blockIdx.x, ty, gx)) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long x_tile = (gx * 4 + wv) * C::TW;
+    const long y0 = ty * C::WTH;
+    const WalkGeom &g = a.g;
+    if (x_tile >= g.cols) return;
+    const long y_end = y0 + C::WTH < g.rows ? y0 + C::WTH : g.rows;
+    const bool interior = x_tile - C::HL >= 0 && x_tile + C::TW + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
+                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
+    if (interior) {
+        MomWalk<R, Shape, OM, false> w(a, lds_rows[wv], x_tile, y0, y_end, lane);
+        if (w.run()) return;
+    } else {
+#ifdef XRS_MOM_T_SKIPEDGE
+        return;
+#endif
+        MomWalk<R, Shape, OM, true> w(a, lds_rows[wv], x_tile, y0, y_end, lane);
+        if (w.run()) return;
+    }
+#ifdef XRS_MOM_NO_FALLBACK
+    return;
+#endif
+    mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end);
+}
+
+template <int R, typename Shape>
+int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
+    using C = MomCfg<R, Shape>;
+    if (!is_shape<R, Shape>(kernel)) return -1;
+    WalkGeom &g = a.g;
+    g.tiles_x = (g.cols + C::TW - 1) / C::TW;
+    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
+    g.n_tiles = g.tiles_x * tiles_y;
+    a.groups_x = (g.tiles_x + 3) / 4;
+    a.n_groups = a.groups_x * tiles_y;
+    const long grid = RimFirst(a.groups_x, tiles_y).grid();
+    if (grid > 0x7fffffffL) return fail("focal moments: raster too large for one launch");
+    const int om = (a.out_sum ? MOM_SUM : 0) | (a.out_mean ? MOM_MEAN : 0) | (a.out_var ? MOM_VAR : 0) | (a.out_std ? MOM_STD : 0);
+    constexpr int ALL = MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD, MVS = MOM_MEAN | MOM_VAR | MOM_STD;
+    if (om == ALL) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, ALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (om == MVS) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, MVS>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((focal_mom_kernel<R, Shape, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+namespace xrs {
+
+// 0 = launched, -1 = not this shape with a radius of 4..12 cells (caller takes another kernel), > 0 = error.
+int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows, long cols,
+                  long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                  hipStream_t s) {
+    if (krows != kcols || !(krows & 1)) return -1;
+    if (!out_sum && !out_mean && !out_var && !out_std) return 0;
+    MomArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
+    a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
+    a.out_sum = out_sum; a.out_mean = out_mean; a.out_var = out_var; a.out_std = out_std;
+    switch (krows / 2) {
+#define XRS_MOM_CASE(RR) case RR: return launch_mom<RR, XRS_MOM_SHAPE>(a, kernel, s);
+#ifndef XRS_MOM_PROBE
+        XRS_MOM_CASE(4) XRS_MOM_CASE(5) XRS_MOM_CASE(6) XRS_MOM_CASE(7) XRS_MOM_CASE(8) XRS_MOM_CASE(9) XRS_MOM_CASE(10) XRS_MOM_CASE(11)
+#endif
+        XRS_MOM_CASE(12)
+#undef XRS_MOM_CASE
+        default: return -1;
+    }
+}
+
+}  // namespace xrs

@@ -37,6 +37,7 @@
 // vs the one-column walker this replaces for `mean`: 25 dword loads + ~270 VALU instructions per cell and row ->
 // 0.3 loads + ~50.  HBM-bound by construction (8 B per cell); measured numbers in DESIGN.md.
 #include "circle_walk.h"
+#include "lds_dma.h"
 
 #include <utility>
 
@@ -104,24 +105,6 @@ __device__ __forceinline__ int clipped_count(long yo, long x, long y_lo, long y_
         n += (int)(b - a + 1);
     }
     return n;
-}
-
-// global -> LDS without registers: every lane supplies its own source address, the destination is the wave-uniform LDS
-// byte address `lds_dst` + lane * size (M0 is saved and restored around the instruction: the compiler owns it)
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds8(const void *gsrc, unsigned lds_dst) {      // (gfx950 has no 8-byte LDS-DMA: two dwords)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // EDGE = false: a full tile whose whole input window lies inside the raster (no predicates, see the header);

@@ -275,5 +275,20 @@ int try_launch_focal_box2_mom(const float *in, float *out_sum, float *out_max, f
                           float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
                           const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 
+// kxk_ext_circle.hip / kxk_ext_box.hip (ext_impl.h): max / min / range, radius 4..12 cells, two input rows per step.
+int try_launch_focal_ext_circle(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols,
+                                long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
+                                int halo_bot, hipStream_t s);
+int try_launch_focal_ext_box(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols,
+                             long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                             hipStream_t s);
+// kxk_mom_circle.hip / kxk_mom_box.hip (mom_impl.h): mean / var / std / sum, radius 4..12 cells, float32 sums about a
+// shift that trails the walk, guarded; exact float64 walker for the tiles that fail the guard.
+int try_launch_focal_mom_circle(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows,
+                                long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
+                                int halo_bot, hipStream_t s);
+int try_launch_focal_mom_box(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows,
+                             long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
+                             int halo_bot, hipStream_t s);
 
 }  // namespace xrs

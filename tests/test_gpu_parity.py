@@ -413,6 +413,65 @@ def test_wide_row_walker_paths():
         np.testing.assert_allclose(o_mean.get(), want[first:first + n], rtol=1e-6)
 
 
+def test_third_generation_walkers_interior_and_rim_tiles():
+    """The round-3 large-window kernels (mom_impl.h: float32 moments about a shift that trails the walk, guarded;
+    ext_impl.h: extrema with two input rows per ring operation) on rasters of several tiles in both directions -- most
+    tiles interior (LDS-DMA ring, re-centring every 5 rows), a rim of edge tiles (predicated walk), a partial last tile --
+    against the oracle: the steep parity-stress DEM (where one shift per tile loses 7 bits of the variance), the
+    benchmark DEM, values straddling zero (the guard hands those tiles to the exact walker), and interior tiles holding a
+    NaN cell, a NaN block larger than the window (all-NaN windows), +-inf and a flat block (variance exactly 0)."""
+    from xrspatial_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(11)
+    for radius, kind, shape in ((12, 'circle', (560, 1330)), (12, 'box', (420, 800)), (7, 'circle', (450, 900)),
+                                (4, 'circle', (300, 700)), (5, 'box', (431, 1025))):
+        K = 2 * radius + 1
+        k = circle_kernel(1, 1, radius) if kind == 'circle' else np.ones((K, K))
+        steep = synth.smooth_dem(shape, seed=radius)
+        holes = steep.copy()
+        holes[200, 300] = np.nan
+        holes[150:150 + 2 * K + 3, 500:500 + 2 * K + 5] = np.nan
+        holes[260, 200] = np.inf
+        holes[170, 650] = -np.inf
+        holes[220:220 + 3 * K, 30:30 + 3 * K] = 1234.5
+        cases = {'steep': steep, 'asv': synth.asv_dem(*shape), 'holes': holes,
+                 'zero-mean': rng.normal(0, 3, shape).astype(np.float32)}
+        for name, z in cases.items():
+            with np.errstate(all='ignore'):
+                want = {st: corc.focal_apply(z, k, st, nthreads=8) for st in ('mean', 'max', 'min', 'range', 'std', 'var', 'sum')}
+            got = focal_stats(raster(z), k).data
+            for i, st in enumerate(('mean', 'max', 'min', 'range', 'std', 'var', 'sum')):
+                msg = f"{kind} r={radius} {name} {st}"
+                if st == 'sum':
+                    check_window_sum(got[i], z, k, msg)
+                elif st in ('max', 'min', 'range'):
+                    np.testing.assert_array_equal(got[i], want[st], err_msg=msg)
+                else:
+                    # var: 3e-6 (float32 sums of squares about a shift within a few rows of the window: measured <= 1.3e-6
+                    # on this DEM; the contract is 1e-5); mean / std 1.5e-6; zero-mean data: the exact path, 1e-5 as elsewhere
+                    tol = 1e-5 if name == 'zero-mean' else 3e-6 if st == 'var' else 1.5e-6
+                    np.testing.assert_allclose(got[i], want[st], rtol=tol, atol=0, equal_nan=True, err_msg=msg)
+                    parity_log.record(f'{shape[0]}x{shape[1]}', f'walk3 {kind}{K} {name} {st}', got[i], want[st])
+            if name == 'holes':
+                flat = (slice(220 + radius, 220 + 3 * K - radius), slice(30 + radius, 30 + 3 * K - radius))
+                assert (got[5][flat] == 0).all() and (got[4][flat] == 0).all() and (got[0][flat] == np.float32(1234.5)).all()
+    # a row shard with halo rows: interior tiles reach into the halos
+    k = circle_kernel(1, 1, 12)
+    kk = np.ascontiguousarray(k, dtype=np.float64)
+    z = synth.smooth_dem((700, 640), seed=5)
+    want = {st: corc.focal_apply(z, k, st, nthreads=8) for st in ('max', 'std')}
+    full = xs.DeviceArray.from_numpy(z)
+    for first, n, ht, hb in ((100, 500, 12, 12), (0, 350, 0, 12), (300, 400, 12, 0)):
+        o_max, o_std = xs.DeviceArray((n, 640), np.float32), xs.DeviceArray((n, 640), np.float32)
+        ptrs = (ctypes.c_void_p * 7)()
+        ptrs[1], ptrs[4] = o_max.ptr, o_std.ptr
+        _lib.call("xrs_focal_stats_f32", full.ptr + first * 640 * 4, ptrs, (1 << 1) | (1 << 4), n, 640, 640, 640,
+                  kk.ctypes.data, 25, 25, None, ht, hb, None)
+        _lib.call("xrs_stream_sync", None)
+        np.testing.assert_array_equal(o_max.get(), want['max'][first:first + n])
+        np.testing.assert_allclose(o_std.get(), want['std'][first:first + n], rtol=1.5e-6)
+
+
 def test_large_window_statistic_subsets():
     """Subsets of the seven statistics on 9x9 .. 25x25 masks run the one-pass walker with only the pass they need
     (walk2_impl.h: extrema only, moments only, both): every subset against the oracle, on clean tiles (fast path), tiles

@@ -12,6 +12,7 @@
 #include "xrs_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace xrs {
@@ -101,6 +102,17 @@ __device__ __forceinline__ void ring_rotate(float (&a)[K][N]) {                /
 // whole launch waits for it (measured on the 25x25 moments kernel: 1.85 ms -> see DESIGN.md), and the top row delays
 // another.  Dealt out first, round-robin over the XCDs, they are spread evenly and their tails hide behind interior work.
 // (gy, gx) of workgroup `block` in a gw x gh grid of workgroup tiles; false for the surplus blocks of the padded grid.
+// Output rows per tile of the third-generation walkers.  Every tile pays 2R rows of run-in before its first output row:
+// 128-row tiles walk 1.19 input rows per output row at radius 12, 256-row tiles 1.09 -- but a raster must be tall enough
+// to still give every CU several tiles.  XRS_WALK_TILE_ROWS overrides (A/B runs).
+inline int walk3_tile_base(long rows, int radius) {
+    const char *e = getenv("XRS_WALK_TILE_ROWS");
+    if (e && atoi(e) >= 16) return atoi(e);
+    // measured on 16384^2 (profiles/r03): radius 12 moments 1.65 ms with 128-row tiles, 1.36 with 256, 2.2 with 384 (too
+    // few workgroups per CU); radius 6 is faster with 128 (its lighter kernels run 3 workgroups per CU)
+    return rows >= 8192 && radius >= 10 ? 256 : 128;
+}
+
 struct RimFirst {
     long gw, gh, n_rim, n_all;
     __host__ __device__ RimFirst(long gw_, long gh_) : gw(gw_), gh(gh_) {

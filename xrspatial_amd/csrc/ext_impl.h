@@ -31,6 +31,7 @@ namespace {
 struct ExtArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot; tiles_x / n_tiles: workgroup tiles
     float *out_max, *out_min, *out_range;
+    int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
 };
 
 template <int R, typename Shape>
@@ -50,8 +51,8 @@ struct ExtCfg {
     static constexpr int CELLS = 64 + 2 * R;               // staged cells per row: raster columns xw - R .. xw + 63 + R
     static constexpr int RBF = 128;                        // floats per row buffer (two dword DMAs of 64 lanes)
     static_assert(2 * R <= 64, "the halo cells are loaded by one lane each");
-    static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: whole rounds
-    static constexpr int WTH = NIN - 2 * R;                // output rows per tile
+    // input rows a full tile walks: whole rounds covering `base` output rows + the 2R rows of run-in
+    static constexpr int nin(int base) { return ((base + 2 * R + U - 1) / U) * U; }
 };
 
 __device__ __forceinline__ float ext_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -94,7 +95,7 @@ struct ExtWalk {
 
     // interior: input row `il` (clamped past the tile) -> ring slot `slot`; staged cell s <-> raster column xw - R + s
     __device__ __forceinline__ void dma_row(int il, int slot) const {
-        const int ilc = il < C::NIN ? il : C::NIN - 1;
+        const int ilc = il < n_in ? il : n_in - 1;
         const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (xw - R));
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
         glds4_s(p, 4u * (unsigned)lane, dst);
@@ -106,7 +107,7 @@ struct ExtWalk {
         for (int j = 0; j < K; ++j) { mn[j] = 0.0f; mx[j] = 0.0f; }        // (every slot is assigned before its first use)
         t = 0;
         y_first = y0 - R;
-        n_in = EDGE ? (int)(y_end - y0) + 2 * R : C::NIN;
+        n_in = (int)(y_end - y0) + 2 * R;                // (interior tiles: a whole number of rounds)
         ring_addr = lds_addr(lds);
         if (!EDGE) {
             for (int r = 0; r < D; ++r) dma_row(r, r);
@@ -234,11 +235,11 @@ __global__ void __launch_bounds__(256, XRS_EXT_WAVES) focal_ext_kernel(const Ext
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long xw = tx * 256 + wv * 64;
-    const long y0 = ty * C::WTH;
+    const long y0 = ty * a.tile_rows;
     if (xw >= g.cols) return;
-    const long y_end = y0 + C::WTH < g.rows ? y0 + C::WTH : g.rows;
+    const long y_end = y0 + a.tile_rows < g.rows ? y0 + a.tile_rows : g.rows;
     const bool interior = xw - R >= 0 && xw + 64 + R <= g.cols && y0 - R >= -(long)g.halo_top &&
-                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
+                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == a.tile_rows;
     if (interior) {
         ExtWalk<R, Shape, false, NO> w(a, lds_rows[wv], xw, y0, y_end, lane);
         w.run();
@@ -254,7 +255,8 @@ int launch_ext(ExtArgs &a, const double *kernel, hipStream_t s) {
     if (!is_shape<R, Shape>(kernel)) return -1;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + 255) / 256;
-    g.n_tiles = g.tiles_x * ((g.rows + C::WTH - 1) / C::WTH);
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    g.n_tiles = g.tiles_x * ((g.rows + a.tile_rows - 1) / a.tile_rows);
     const long grid = RimFirst(g.tiles_x, g.n_tiles / g.tiles_x).grid();
     if (grid > 0x7fffffffL) return fail("focal max / min: raster too large for one launch");
     const int n_out = (a.out_max != nullptr) + (a.out_min != nullptr) + (a.out_range != nullptr);

@@ -41,6 +41,7 @@ struct MomArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
     float *out_sum, *out_mean, *out_var, *out_std;
     long n_groups, groups_x;      // workgroups = groups of 4 horizontally adjacent wave tiles
+    int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
 };
 
 template <int R, typename Shape>
@@ -66,8 +67,8 @@ struct MomCfg {
 #endif
     static constexpr int D = XRS_MOM_D;                    // rows in flight by LDS-DMA; D + 1 row buffers per wave
     static constexpr int RBF = 256;                        // floats per row buffer (the 16-byte DMA writes a whole KiB)
-    static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: whole rounds
-    static constexpr int WTH = NIN - 2 * R;                // output rows per wave tile
+    // input rows a full tile walks: whole rounds covering `base` output rows + the 2R rows of run-in
+    static constexpr int nin(int base) { return ((base + 2 * R + U - 1) / U) * U; }
     // How much of a re-centring by d is still inside the partial sums of the rows about to be emitted: a row emitted k
     // rounds later was at most K - (k - 1) U - 1 input rows old when it happened, i.e. held that fraction of its cells
     // (radius 12, U = 5: 1, 0.84, 0.6, 0.33, 0.09, 0).  Kept as two numbers: d^2 of the last re-centring and a decaying
@@ -164,7 +165,7 @@ struct MomWalk {
     }
 
     __device__ __forceinline__ void dma_row(int il, int slot) const {
-        const int ilc = il < C::NIN ? il : C::NIN - 1;
+        const int ilc = il < n_in ? il : n_in - 1;
         const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - HL));
         constexpr int QMAX = C::CELLS / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), ring_addr + (unsigned)slot * (C::RBF * 4));
@@ -180,7 +181,7 @@ struct MomWalk {
         gm = (want(MOM_MEAN, a.out_mean) || want(MOM_SUM, a.out_sum)) ? 0.04f / (float)C::NTAPS : 0.0f;
         t = 0;
         y_first = y0 - R;
-        n_in = EDGE ? (int)(y_end - y0) + 2 * R : C::NIN;
+        n_in = (int)(y_end - y0) + 2 * R;                // (interior tiles: a whole number of rounds)
         ring_addr = lds_addr(lds);
         if (EDGE) {
             // the one shift of an edge tile: the mean of the lane's own columns in eight rows spread over the tile (a single
@@ -452,12 +453,12 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = (gx * 4 + wv) * C::TW;
-    const long y0 = ty * C::WTH;
+    const long y0 = ty * a.tile_rows;
     const WalkGeom &g = a.g;
     if (x_tile >= g.cols) return;
-    const long y_end = y0 + C::WTH < g.rows ? y0 + C::WTH : g.rows;
+    const long y_end = y0 + a.tile_rows < g.rows ? y0 + a.tile_rows : g.rows;
     const bool interior = x_tile - C::HL >= 0 && x_tile + C::TW + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
-                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
+                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == a.tile_rows;
     if (interior) {
         MomWalk<R, Shape, OM, false> w(a, lds_rows[wv], x_tile, y0, y_end, lane);
         if (w.run()) return;
@@ -480,7 +481,8 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     if (!is_shape<R, Shape>(kernel)) return -1;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
-    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;

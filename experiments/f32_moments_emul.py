@@ -49,6 +49,7 @@ def emulate(z, R=12, NC=2, period=10, lead=None, qring64=False, shift_mode="trai
     c = z[0, x0].astype(f32).copy()
     snap = np.zeros(nl, f32)
     snap_ms = np.zeros(nl, f32)
+    snap_sum = np.zeros(nl, f32)
     idx_cols = x0[:, None] - HL + np.arange(NV)[None, :]
     for t in range(H):
         if t % period == 0 and t > 0:
@@ -59,6 +60,10 @@ def emulate(z, R=12, NC=2, period=10, lead=None, qring64=False, shift_mode="trai
             elif shift_mode == "rowmean":
                 # the widest centred run of row t - R + lead, as the kernel has it (a float32 sum about the old shift)
                 cn = (c + (snap * f32(1.0 / (2 * R + 1))).astype(f32)).astype(f32)
+            elif shift_mode == "roundmean":
+                # mean of the widest runs of all `period` rows of the round just walked
+                cn = (c + (snap_sum * f32(1.0 / ((2 * R + 1) * period))).astype(f32)).astype(f32)
+                snap_sum = np.zeros(nl, f32)
             elif shift_mode == "avg":
                 # mean of that row's widest run and of the window that completed with it (centred R rows higher)
                 cn = (c + (f32(0.5) * ((snap * f32(1.0 / (2 * R + 1))).astype(f32) + snap_ms)).astype(f32)).astype(f32)
@@ -108,6 +113,7 @@ def emulate(z, R=12, NC=2, period=10, lead=None, qring64=False, shift_mode="trai
             lev_S[h], lev_Q[h] = s, q
         if snap_now:
             snap = lev_S[R][:, 0].copy()
+        snap_sum = (snap_sum + lev_S[R][:, 0]).astype(f32)
         # ring: slot for output row yo is yo % K; this row contributes to yo = t - dy
         for dy in range(-R, R + 1):
             yo = t - dy

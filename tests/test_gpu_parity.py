@@ -447,9 +447,10 @@ def test_third_generation_walkers_interior_and_rim_tiles():
                 elif st in ('max', 'min', 'range'):
                     np.testing.assert_array_equal(got[i], want[st], err_msg=msg)
                 else:
-                    # var: 3e-6 (float32 sums of squares about a shift within a few rows of the window: measured <= 1.3e-6
-                    # on this DEM; the contract is 1e-5); mean / std 1.5e-6; zero-mean data: the exact path, 1e-5 as elsewhere
-                    tol = 1e-5 if name == 'zero-mean' else 3e-6 if st == 'var' else 1.5e-6
+                    # var: 5e-6 (float32 sums of squares about a shift within a few rows of the window: measured <= 1.3e-6
+                    # on this DEM, the guard allows ~6e-6; the contract is 1e-5); mean / std 2.5e-6; zero-mean data: the
+                    # exact path, 1e-5 as elsewhere
+                    tol = 1e-5 if name == 'zero-mean' else 5e-6 if st == 'var' else 2.5e-6
                     np.testing.assert_allclose(got[i], want[st], rtol=tol, atol=0, equal_nan=True, err_msg=msg)
                     parity_log.record(f'{shape[0]}x{shape[1]}', f'walk3 {kind}{K} {name} {st}', got[i], want[st])
             if name == 'holes':
@@ -469,7 +470,7 @@ def test_third_generation_walkers_interior_and_rim_tiles():
                   kk.ctypes.data, 25, 25, None, ht, hb, None)
         _lib.call("xrs_stream_sync", None)
         np.testing.assert_array_equal(o_max.get(), want['max'][first:first + n])
-        np.testing.assert_allclose(o_std.get(), want['std'][first:first + n], rtol=1.5e-6)
+        np.testing.assert_allclose(o_std.get(), want['std'][first:first + n], rtol=2.5e-6)
 
 
 def test_large_window_statistic_subsets():

@@ -115,12 +115,23 @@ inline int walk3_tile_base(long rows, int radius) {
 
 struct RimFirst {
     long gw, gh, n_rim, n_all;
-    __host__ __device__ RimFirst(long gw_, long gh_) : gw(gw_), gh(gh_) {
+    // mode 1: rim first; 0: row-major tiles in one contiguous band per XCD (rounds 1-2: XRS_RIM_FIRST=0, A/B runs)
+    __host__ __device__ RimFirst(long gw_, long gh_, int mode = 1) : gw(gw_), gh(gh_) {
         n_all = gw * gh;
-        n_rim = (gw <= 2 || gh <= 2) ? n_all : 2 * gw + 2 * (gh - 2);
+        n_rim = mode == 0 ? -1 : (gw <= 2 || gh <= 2) ? n_all : 2 * gw + 2 * (gh - 2);
     }
-    __host__ long grid() const { return n_rim + xcd_grid(n_all - n_rim, 0); }
+    static int mode_from_env() {
+        const char *e = getenv("XRS_RIM_FIRST");
+        return e && e[0] == '0' ? 0 : 1;
+    }
+    __host__ long grid() const { return n_rim < 0 ? xcd_grid(n_all, 0) : n_rim + xcd_grid(n_all - n_rim, 0); }
     __device__ __forceinline__ bool locate(long block, long &gy, long &gx) const {
+        if (n_rim < 0) {
+            const long t = xcd_tile(block, n_all, 0);
+            if (t < 0) return false;
+            gy = t / gw; gx = t - gy * gw;
+            return true;
+        }
         if (block < n_rim) {
             if (n_rim == n_all) { gy = block / gw; gx = block - gy * gw; return true; }
             if (block < gw) { gy = 0; gx = block; return true; }

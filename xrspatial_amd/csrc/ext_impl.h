@@ -32,6 +32,7 @@ struct ExtArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot; tiles_x / n_tiles: workgroup tiles
     float *out_max, *out_min, *out_range;
     int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
+    int rim_first;                // work order (circle_walk.h RimFirst)
 };
 
 template <int R, typename Shape>
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256, XRS_EXT_WAVES) focal_ext_kernel(const Ext
     __shared__ __attribute__((aligned(16))) float lds_rows[4][C::RB * C::RBF];
     const WalkGeom &g = a.g;
     long ty, tx;
-    if (!RimFirst(g.tiles_x, g.n_tiles / g.tiles_x).locate(blockIdx.x, ty, tx)) return;
+    if (!RimFirst(g.tiles_x, g.n_tiles / g.tiles_x, a.rim_first).locate(blockIdx.x, ty, tx)) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long xw = tx * 256 + wv * 64;
@@ -257,7 +258,8 @@ int launch_ext(ExtArgs &a, const double *kernel, hipStream_t s) {
     g.tiles_x = (g.cols + 255) / 256;
     a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
     g.n_tiles = g.tiles_x * ((g.rows + a.tile_rows - 1) / a.tile_rows);
-    const long grid = RimFirst(g.tiles_x, g.n_tiles / g.tiles_x).grid();
+    a.rim_first = RimFirst::mode_from_env();
+    const long grid = RimFirst(g.tiles_x, g.n_tiles / g.tiles_x, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal max / min: raster too large for one launch");
     const int n_out = (a.out_max != nullptr) + (a.out_min != nullptr) + (a.out_range != nullptr);
     if (n_out == 3) hipLaunchKernelGGL((focal_ext_kernel<R, Shape, 3>), dim3((unsigned)grid), dim3(256), 0, s, a);

@@ -15,14 +15,16 @@
 //   * the shift TRAILS the walk.  One constant per tile makes sum w^2 ~ n (var + m^2) with m the distance between the
 //     window mean and the shift: on a slope of g per cell m reaches 70 g at the end of a tile against var = 36 g^2 for
 //     a radius-12 circle, and float32 loses 7 bits to the cancellation.  Instead every lane re-centres once per round:
-//     c' = c + (mean of the widest run of the round's first row) -- a value of the lane's own columns a few rows behind
-//     the walk -- and the 2R+1 partial sums move with it by exact algebra, S' = S - N d, Q' = Q - d (S + S'), N = the
+//     c' = c + (mean of the widest runs of the round's five rows: 5 (2R+1) cells of the lane's own columns just behind
+//     the walk; one row alone jitters enough on a noisy raster to trip the guard of 11x11 windows in 13 % of the tiles) -- and the 2R+1 partial sums move with it by exact algebra, S' = S - N d, Q' = Q - d (S + S'), N = the
 //     (compile-time) number of cells the slot has seen and d = c' - c.  sum w^2 then stays within a small multiple of
 //     n var: the emulation of these exact operations (experiments/f32_moments_emul.py) gives var within 8e-7 of a
 //     float64 two-pass reference on the steep parity-stress DEM, 4e-7 on the benchmark DEM; with one shift per tile 5e-3;
 //   * a guard per output decides whether float32 was good enough: with B = Q + n max(d^2 of the slot's re-centrings)
-//     bounding every partial sum the slot went through, var is accepted if n var >= B / 5 (amplification <= 5: error
-//     <~ 30 u 5 < 1e-5) and mean / sum if mean^2 >= 0.04 B / n; otherwise -- flat windows next to relief, values
+//     bounding every partial sum the slot went through, var is accepted if n var >= B / 5 (amplification <= 5: the
+//     emulation and the GPU runs put the error at <= 2e-6 there; a bound of 10 let 1.5e-5 through on windows that straddle
+//     a cliff, where several large re-centrings follow each other) and mean / sum
+//     if mean^2 >= 0.04 B / n; otherwise -- flat windows next to relief, values
 //     straddling zero, NaN / inf anywhere under a window (the comparisons fail on non-finite sums) -- the whole tile
 //     is redone by the exact float64 NaN-skipping walker of circle_walk.h, like the tiles at the raster edge.
 //     A window over equal cells passes with S = Q = 0 exactly (its shift has converged onto the value) or is redone;
@@ -42,6 +44,7 @@ struct MomArgs {
     float *out_sum, *out_mean, *out_var, *out_std;
     long n_groups, groups_x;      // workgroups = groups of 4 horizontally adjacent wave tiles
     int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
+    int rim_first;                // work order (circle_walk.h RimFirst)
 };
 
 template <int R, typename Shape>
@@ -121,7 +124,7 @@ struct MomWalk {
     static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW, D = C::D;
 
     float accS[K][NC], accQ[K][NC];
-    float c, c_next;               // the lane's shift and its successor (taken at the first row of the round)
+    float c, c_next;               // the lane's shift; sum of the round's widest runs about it (-> its successor)
     float dq_last, dq_old;         // d^2 of the last re-centring; decaying maximum of the older ones
     float dqn;                     // NTAPS * max of both: what the re-centrings added to the partial sums of squares
     int slot_in, slot_out;
@@ -258,7 +261,7 @@ struct MomWalk {
                 const int hi = HL + o + h, lo = HL + o - h - 1;
                 S[o] = h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
             }
-            if (!EDGE && !SQ && PHASE == 0 && h == R) c_next = fmaf(S[0], 1.0f / (float)K, c);       // (hw(0) == R for every shape)
+            if (!EDGE && !SQ && h == R) c_next = PHASE == 0 ? S[0] : c_next + S[0];       // (hw(0) == R for every shape)
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int dy = j - R;
@@ -382,7 +385,8 @@ struct MomWalk {
     // hit next at offset -idx or K - idx and has seen C::seen(idx) cells)
     template <int... J>
     __device__ __forceinline__ void recentre(std::integer_sequence<int, J...>) {
-        const float d = c_next - c;
+        c_next = fmaf(c_next, 1.0f / (float)(K * U), c);      // (c_next was the sum of the round's widest runs about c)
+        const float d = c_next - c;                           // exact: the step the walk really takes
         auto one = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr float N = (float)C::seen(j);
@@ -449,7 +453,7 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
     using C = MomCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float lds_rows[4][(C::D + 1) * C::RBF];
     long ty, gx;
-    if (!RimFirst(a.groups_x, a.n_groups / a.groups_x).locate(blockIdx.x, ty, gx)) return;
+    if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = (gx * 4 + wv) * C::TW;
@@ -486,7 +490,8 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;
-    const long grid = RimFirst(a.groups_x, tiles_y).grid();
+    a.rim_first = RimFirst::mode_from_env();
+    const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal moments: raster too large for one launch");
     const int om = (a.out_sum ? MOM_SUM : 0) | (a.out_mean ? MOM_MEAN : 0) | (a.out_var ? MOM_VAR : 0) | (a.out_std ? MOM_STD : 0);
     constexpr int ALL = MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD, MVS = MOM_MEAN | MOM_VAR | MOM_STD;

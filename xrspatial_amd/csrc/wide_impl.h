@@ -53,6 +53,8 @@ struct WideArgs {
     float *out;                   // the mean, the window sum, or the convolution (template parameter of the kernel)
     double wgt;                   // convolution: the one weight value of the kernel ...
     const double *weights;        // ... and the whole (2R+1)^2 kernel in device memory (exact path)
+    int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
+    int rim_first;                // work order (circle_walk.h RimFirst)
     long n_groups;                // workgroups = groups of 4 horizontally adjacent wave tiles
     long groups_x;
 };
@@ -83,8 +85,9 @@ struct WideCfg {
     static constexpr int D = XRS_WIDE_D;                   // interior tiles: rows in flight by LDS-DMA; D + 1 row buffers per wave
     static constexpr int RBF = (TW + 2 * HL > 256) ? (STG > 320 ? STG : 320) : 256;   // floats per ring row (the 16-byte DMA writes a whole KiB, the dword one 256 B more)
     static constexpr int LDS_WAVE = (D + 1) * RBF;    // floats of LDS per wave (a DMA writes whole KiB)
-    static constexpr int NIN = ((128 + 2 * R + U - 1) / U) * U;        // input rows a full tile walks: a whole number of rounds
-    static constexpr int WTH = NIN - 2 * R;                // output rows per wave tile (128 .. 128 + U - 1)
+    // input rows a full tile walks: whole rounds covering `base` output rows + the 2R rows of run-in (round 3: the
+    // tile height is chosen at launch, walk3_tile_base)
+    static constexpr int nin(int base) { return ((base + 2 * R + U - 1) / U) * U; }
     static constexpr int NE = 2 * R;                       // the first input row whose completion emits an output row
     static constexpr bool level_used(int h) {
         for (int dy = 0; dy <= R; ++dy)
@@ -171,7 +174,7 @@ struct WideWalk {
         bad = false;
         t = 0;
         y_first = y0 - R;
-        n_in = EDGE ? (int)(y_end - y0) + 2 * R : C::NIN;
+        n_in = (int)(y_end - y0) + 2 * R;                // (interior tiles: a whole number of rounds)
         // shift: the cell at the tile centre (any finite value works; a nearby one keeps |v - c| small)
         const long yc = y0 + (y_end - y0) / 2, xc = (x_tile + TW / 2 < g.cols ? x_tile + TW / 2 : g.cols - 1);
         const float c0 = g.in[yc * g.ld_in + xc];
@@ -192,12 +195,12 @@ struct WideWalk {
     // interior: input row `il` (clamped past the tile) -> ring slot `slot`, as a linear image of the TW + 2*HL staged cells
     __device__ __forceinline__ void dma_row(int il, int slot) const {
         constexpr int CELLS = TW + 2 * HL;
-        const int ilc = il < C::NIN ? il : C::NIN - 1;
-        const float *p = g.in + (y_first + ilc) * g.ld_in + (x_tile - HL);
+        const int ilc = il < n_in ? il : n_in - 1;
+        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - HL));     // (scalar base + lane offset)
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
         constexpr int QMAX = (CELLS < 256 ? CELLS : 256) / 4 - 1;
-        glds16(p + 4 * (lane < QMAX ? lane : QMAX), dst);
-        if (CELLS > 256) glds4(p + 256 + (lane < CELLS - 257 ? lane : CELLS - 257), dst + 1024);
+        glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), dst);
+        if (CELLS > 256) glds4_s(p, 4u * (unsigned)(256 + (lane < CELLS - 257 ? lane : CELLS - 257)), dst + 1024);
     }
     static constexpr int NDMA = (TW + 2 * HL > 256) ? 2 : 1;       // DMA instructions per row
 
@@ -381,18 +384,17 @@ template <int R, typename Shape, int MODE>
 __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const WideArgs a) {
     using C = WideCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float lds_rows[4][C::LDS_WAVE];
-    const long gidx = xcd_tile(blockIdx.x, a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
-    if (gidx < 0) return;
-    const long ty = gidx / a.groups_x, gx = gidx - ty * a.groups_x;
+    long ty, gx;                   // (rim tiles first: circle_walk.h)
+    if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = (gx * 4 + wv) * C::TW;
-    const long y0 = ty * C::WTH;
+    const long y0 = ty * a.tile_rows;
     const WalkGeom &g = a.g;
     if (x_tile >= g.cols) return;
-    const long y_end = y0 + C::WTH < g.rows ? y0 + C::WTH : g.rows;
+    const long y_end = y0 + a.tile_rows < g.rows ? y0 + a.tile_rows : g.rows;
     const bool interior = x_tile - C::HL >= 0 && x_tile + C::TW + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
-                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == C::WTH;
+                          y_end + R <= g.rows + g.halo_bot && y_end - y0 == a.tile_rows;
     bool ok;
     if (interior) {
         WideWalk<R, Shape, false, MODE> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
@@ -425,11 +427,13 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     using C = WideCfg<R, Shape>;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
-    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;
-    const long grid = xcd_grid(a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
+    a.rim_first = RimFirst::mode_from_env();
+    const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
     if (out_mean) {
         a.out = out_mean;
@@ -450,13 +454,15 @@ int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double
     if (!is_uniform_shape<R, Shape>(kernel, &a.wgt)) return -1;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
-    const long tiles_y = (g.rows + C::WTH - 1) / C::WTH;
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
     a.n_groups = a.groups_x * tiles_y;
     a.weights = weights_dev;
     a.out = out;
-    const long grid = xcd_grid(a.n_groups, XCD_UNIT(XRS_XCD_WALK, a.groups_x));
+    a.rim_first = RimFirst::mode_from_env();
+    const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("convolve_2d: raster too large for one launch");
     hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_CONV>), dim3((unsigned)grid), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();

@@ -71,9 +71,17 @@ class Ctx:
                          "(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N)")
             args.gpus = self.world
         os.environ.setdefault("XRS_DEVICE", str(self.local_rank))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if self.world > 1:
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # single node: RCCL bootstrap over loopback
+        # The multi-process environment is the launcher's business: nothing is set here unless asked for.
+        #   XRS_BENCH_SET_RCCL_ENV=1  -> defaults for a single node whose launcher exported nothing:
+        #                                HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) and NCCL_SOCKET_IFNAME=lo (bootstrap
+        #                                over loopback); existing values are never overridden.
+        # The effective values are printed in config.rccl_env of every N > 1 line and by --dry-rccl.
+        self.env_set = []
+        if self.world > 1 and os.environ.get("XRS_BENCH_SET_RCCL_ENV", "") == "1":
+            for k, v in (("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ("NCCL_SOCKET_IFNAME", "lo")):
+                if k not in os.environ:
+                    os.environ[k] = v
+                    self.env_set.append(k)
         if not os.path.exists(os.path.join(ROOT, "xrspatial_amd", "libxrs_hip.so")):
             import __graft_entry__
             __graft_entry__.build()
@@ -84,20 +92,49 @@ class Ctx:
         self.stream = ctypes.c_void_p()
         self.L("xrs_stream_create", ctypes.byref(self.stream))
         self.comm = None
+        self.connect_s = None
         self.host_group = None        # torch.distributed (gloo), only with --allow-host-halo after RCCL failed
         self.halo_via = None
         if self.world > 1:
             self._connect()
         self._ms = ctypes.c_float()
 
+    def rccl_env(self):
+        keys = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "NCCL_DEBUG", "NCCL_P2P_DISABLE", "NCCL_SHM_DISABLE",
+                "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT", "XRS_RDZV_FILE")
+        env = {k: os.environ[k] for k in keys if k in os.environ}
+        env["set_by_bench"] = self.env_set
+        return env
+
     def _connect(self):
         from xrspatial_amd.distributed import Comm
         err = ""
+        t0 = time.perf_counter()
         try:
             self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
             self.halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
         except Exception as exc:                      # noqa: BLE001
             err = repr(exc)[:300]
+        if self.comm is None and not self.env_set and os.environ.get("XRS_BENCH_SET_RCCL_ENV", "") != "0":
+            # One retry with the single-node defaults, if the launcher exported none and the first attempt returned an
+            # ERROR (every rank sees the same failure, so every rank retries; a hang is the timeout's business).  The
+            # line says so: config.rccl_env.set_by_bench.
+            missing = [(k, v) for k, v in (("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ("NCCL_SOCKET_IFNAME", "lo")) if k not in os.environ]
+            if missing:
+                sys.stderr.write(f"[bench rank {self.rank}] RCCL init failed ({err}); retrying once with "
+                                 f"{dict(missing)}\n")
+                for k, v in missing:
+                    os.environ[k] = v
+                    self.env_set.append(k + " (after a failed first attempt)")
+                if not os.environ.get("XRS_RDZV_FILE"):
+                    os.environ.pop("XRS_RDZV_FILE", None)
+                try:
+                    self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
+                    self.halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
+                    err = ""
+                except Exception as exc:              # noqa: BLE001
+                    err = repr(exc)[:300]
+        self.connect_s = time.perf_counter() - t0
         if self.comm is None:
             sys.stderr.write(f"[bench rank {self.rank}] RCCL communicator unavailable: {err}\n")
             if not self.args.allow_host_halo:
@@ -488,6 +525,8 @@ def run_headline(ctx):
             "rows_per_gpu": rows, "cols": cols, "global_rows": total_rows,
             "sharding": "rows" if world > 1 else "none",
             "halo_exchange": halo_via,
+            "rccl_env": ctx.rccl_env() if world > 1 else None,
+            "rccl": ctx.comm.info() if ctx.comm is not None else None,
             "halo_check": halo_check,
             "halo_exchange_ms_last_step": None if exchange_ms is None else round(exchange_ms, 4),
             "kernel_ms": kernel_ms,
@@ -780,6 +819,49 @@ def cpu_baseline(cols, kernel):
     }
 
 
+def run_dry_rccl(ctx):
+    """--dry-rccl: rendezvous, ONE halo exchange, ONE all-reduce, the halo check -- and what RCCL says about the
+    communicator.  Half a minute on an N-GPU node; tells an initialisation problem (ranks missing, wrong device, IPC
+    refused) from a performance problem before any benchmark is run.  Exit code 3 (from Ctx) if RCCL cannot connect."""
+    L, xs, stream = ctx.L, ctx.xs, ctx.stream
+    rank, world = ctx.rank, ctx.world
+    rows, cols = 64, 4096
+    info = ctx.comm.info() if ctx.comm is not None else None
+    # every owned row of rank r holds r + 1; halo rows start as -1
+    host = np.full((rows + 2 * HALO, cols), -1.0, np.float32)
+    host[HALO:HALO + rows] = rank + 1
+    buf = xs.DeviceArray.from_numpy(host)
+    dem_ptr = buf.ptr + HALO * cols * 4
+    t0 = time.perf_counter()
+    ctx.halo_exchange(dem_ptr, rows, cols, HALO)
+    L("xrs_stream_sync", stream)
+    exchange_s = time.perf_counter() - t0
+    got = buf.get(stream)
+    want_top = float(rank) if rank > 0 else -1.0                    # the neighbour above holds `rank`, below `rank + 2`
+    want_bot = float(rank + 2) if rank < world - 1 else -1.0
+    bad = int(np.count_nonzero(got[:HALO] != want_top)) + int(np.count_nonzero(got[HALO + rows:] != want_bot)) \
+        + int(np.count_nonzero(got[HALO:HALO + rows] != rank + 1))
+    t0 = time.perf_counter()
+    total = ctx.allsum(float(rank + 1))
+    allreduce_s = time.perf_counter() - t0
+    bad_total = ctx.allsum(float(bad))
+    counts = None
+    if ctx.comm is not None:
+        u = ctx.comm.allreduce(np.array([rank + 1, 1], np.uint64), 'sum', stream)        # the typed paths, rank to rank
+        b = ctx.comm.allreduce(np.array([rank % 2, 1], np.uint8), 'max', stream)
+        counts = {"u64_sum": [int(v) for v in u], "u8_max": [int(v) for v in b]}
+    if rank != 0:
+        return None
+    expect = world * (world + 1) / 2
+    ok = bad_total == 0 and total == expect and (counts is None or (counts["u64_sum"] == [int(expect), world] and counts["u8_max"][1] == 1))
+    return {"dry_rccl": True, "ok": bool(ok), "n_gpus": world, "transport": ctx.halo_via, "rccl": info,
+            "rendezvous_and_comm_init_s": None if ctx.connect_s is None else round(ctx.connect_s, 3),
+            "halo_exchange": {"rows_per_neighbour": HALO, "cols": cols, "cells_wrong_all_ranks": int(bad_total),
+                              "first_call_s": round(exchange_s, 4)},
+            "allreduce": {"sum_of_rank_plus_1": total, "expected": expect, "first_call_s": round(allreduce_s, 4), "typed": counts},
+            "rccl_env": ctx.rccl_env(), "build_id": ctx._lib.build_id()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -804,9 +886,14 @@ def main():
     ap.add_argument("--per-step-events", action="store_true",
                     help="fused mode: bracket every launch with its own pair of HIP events (default: ONE pair around the "
                          "K timed launches; --unfused always uses per-kernel events)")
+    ap.add_argument("--dry-rccl", action="store_true",
+                    help="N > 1: only rendezvous, one halo exchange, one all-reduce and their checks; prints what RCCL "
+                         "reports about the communicator (a 30-second run that tells init problems from perf problems)")
     args = ap.parse_args()
     ctx = Ctx(args)
-    if args.workload == "headline":
+    if args.dry_rccl:
+        result = run_dry_rccl(ctx)
+    elif args.workload == "headline":
         result = run_headline(ctx)
     else:
         body = run_s64(ctx) if args.workload == "s64" else run_zonal32k(ctx)
@@ -818,7 +905,8 @@ def main():
                 "value": body.get("mcells_s"), "unit": "Mcells/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": body.get("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
-                "config": {"workload": args.workload, "halo_exchange": ctx.halo_via, "build_id": ctx._lib.build_id(), **body},
+                "config": {"workload": args.workload, "halo_exchange": ctx.halo_via, "build_id": ctx._lib.build_id(),
+                           "rccl_env": ctx.rccl_env() if ctx.world > 1 else None, **body},
                 "roofline": {"bound": "hbm", "kernel": SYM_S64 if args.workload == "s64" else SYM_ZONAL,
                              "achieved": body.get("algorithmic_gbs_per_gpu"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": None if body.get("algorithmic_gbs_per_gpu") is None else round(body["algorithmic_gbs_per_gpu"] / HBM_PEAK_GBS, 4),

@@ -336,6 +336,9 @@ int xrs_true_color_u8(const float *red_dev, const float *green_dev, const float 
 int xrs_comm_unique_id(void *id128);
 int xrs_comm_init_rank(void **comm, const void *id128, int nranks, int rank);
 int xrs_comm_destroy(void *comm);
+/* {RCCL version code, ranks in the communicator, this rank, HIP device} as RCCL reports them (diagnostics:
+ * `bench.py --dry-rccl`; the reference has no counterpart -- dask's scheduler dashboard plays that role) */
+int xrs_comm_info(void *comm, int *info4);
 int xrs_halo_exchange_f32(void *comm, float *shard_dev, int64_t rows, int64_t cols, int64_t ld,
                           int halo, void *stream);
 /* single-GPU loop-back check of the RCCL send/recv plumbing (test support, not on the data path) */

@@ -1,5 +1,5 @@
 """Debug probe (round 3): where does the float32 moments walker hand tiles to the exact walker?  Runs the 25x25 circle
-mean / var / std on an asv DEM with the no-fallback build (XRS_LIB=.../libxrs_hip_nofb.so) and reports, per wave tile
+mean / var / std on an asv DEM with the no-fallback build (a library built with EXTRA=-DXRS_MOM_NO_FALLBACK, loaded through XRS_LIB) and reports, per wave tile
 (128 columns x 131 rows), whether the fast path wrote it completely and how far it is from a float64 reference."""
 import os
 import sys

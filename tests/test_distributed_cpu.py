@@ -226,6 +226,75 @@ def test_bench_workloads_world2(workload, extra):
         assert res["scaling"] == "weak" and cfg["halo_check"]["ok"], cfg
 
 
+def test_bench_dry_rccl_world2():
+    """`bench.py --dry-rccl` (rendezvous, one halo exchange, one all-reduce, their checks) with two ranks over the host
+    transport: rank r's halo rows must hold its neighbours' values, the sum of (rank + 1) must be 3, and the line must
+    carry the effective RCCL environment without bench.py having set anything."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", XRS_RDZV_TIMEOUT="5", XRS_BENCH_SET_RCCL_ENV="0")
+        env.pop("NCCL_SOCKET_IFNAME", None)
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "2", "--dry-rccl", "--allow-host-halo"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()[-3000:]
+        outs.append(out.decode())
+    import json
+    res = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])
+    assert res["dry_rccl"] and res["ok"] and res["n_gpus"] == 2, res
+    assert res["halo_exchange"]["cells_wrong_all_ranks"] == 0 and res["allreduce"]["sum_of_rank_plus_1"] == 3.0
+    assert "NCCL_SOCKET_IFNAME" not in res["rccl_env"] and res["rccl_env"]["set_by_bench"] == []
+    assert "host-staged" in res["transport"]
+
+
+def test_comm_from_env_needs_a_job_identity(monkeypatch, tmp_path):
+    """More than one rank and nothing that names the job (no XRS_RDZV_FILE, MASTER_PORT, TORCHELASTIC_RUN_ID): two jobs on
+    a node would share a rendezvous file, so Comm.from_env raises before touching any file; the default directory is
+    private to the user."""
+    from xrspatial_amd import distributed
+    for k in ("XRS_RDZV_FILE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError, match="XRS_RDZV_FILE"):
+        distributed.Comm.from_env(timeout=1)
+    monkeypatch.setattr(distributed.tempfile, "gettempdir", lambda: str(tmp_path))
+    d = distributed.rendezvous_dir()
+    assert os.path.isdir(d) and (os.stat(d).st_mode & 0o777) == 0o700
+    os.chmod(d, 0o755)
+    with pytest.raises(RuntimeError, match="private"):
+        distributed.rendezvous_dir()
+
+
+def test_combine_partials_with_different_shifts():
+    """Per-rank zonal partials taken about different shifts (what ranks that pick their own shift produce) are
+    re-centred before they are added: the combined moments equal those of the whole about the common shift."""
+    rng = np.random.default_rng(4)
+    x = rng.normal(1e6, 0.5, 4000)
+    zone = rng.integers(0, 7, x.size)
+    def part(sel, shift):
+        cnt = np.bincount(zone[sel], minlength=7).astype(np.uint64)
+        d = x[sel] - shift
+        s1 = np.bincount(zone[sel], weights=d, minlength=7)
+        s2 = np.bincount(zone[sel], weights=d * d, minlength=7)
+        mn = np.array([x[sel][zone[sel] == z].min() for z in range(7)])
+        mx = np.array([x[sel][zone[sel] == z].max() for z in range(7)])
+        return cnt, s1, s2, mn, mx, shift
+    a, b = part(slice(0, 1500), 999999.0), part(slice(1500, None), 1000002.0)
+    c, s1, s2, mn, mx, sh = combine_zonal_partials([a, b])
+    whole = part(slice(None), sh)
+    assert sh == 999999.0 and (c == whole[0]).all()
+    np.testing.assert_allclose(s1, whole[1], rtol=1e-12, atol=1e-6)
+    np.testing.assert_allclose(s2, whole[2], rtol=1e-12)
+    assert (mn == whole[3]).all() and (mx == whole[4]).all()
+    var = s2 / c - (s1 / c) ** 2
+    np.testing.assert_allclose(var, [x[zone == z].var() for z in range(7)], rtol=1e-7)
+
+
 def test_bench_refuses_multi_gpu_without_rccl():
     """Without --allow-host-halo a rank whose RCCL communicator cannot be created exits with code 3 instead of silently
     benchmarking a host-staged exchange."""

@@ -1442,6 +1442,14 @@ def test_rccl_plumbing_single_gpu():
     for op in ('sum', 'min', 'max'):
         np.testing.assert_array_equal(comm.allreduce(vals, op), vals)
     comm.halo_exchange(xs.DeviceArray.from_numpy(np.ones((8 + 4, 16), np.float64)), 2)
+    # what RCCL reports about the communicator (bench.py --dry-rccl prints it), and the typed reduces through the
+    # communicator's scratch buffer (small arrays) and through a fresh device array (large ones)
+    info = comm.info()
+    assert info["ranks"] == 1 and info["rank"] == 0 and info["device"] >= 0 and info["rccl_version"][0].isdigit()
+    np.testing.assert_array_equal(comm.allreduce(np.array([7, 9], np.uint64), 'sum'), [7, 9])
+    np.testing.assert_array_equal(comm.allreduce(np.array([0, 1, 1], np.uint8), 'max'), [0, 1, 1])
+    big = np.arange(5000, dtype=np.float64)
+    np.testing.assert_array_equal(comm.allreduce(big, 'min'), big)
     sharded = xs.ShardedArray.from_numpy(np.ones((8, 16), np.float32), comm, halo_cap=2)
     assert sharded.halos(2) == (0, 0)
     comm.destroy()

@@ -122,6 +122,7 @@ _PROTOTYPES = {
     "xrs_comm_unique_id": [c_void_p],
     "xrs_comm_init_rank": [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int],
     "xrs_comm_destroy": [c_void_p],
+    "xrs_comm_info": [c_void_p, c_void_p],
     "xrs_comm_selftest_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrs_halo_exchange_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
     "xrs_zonal_allreduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],

@@ -53,6 +53,21 @@ int xrs_comm_init_rank(void **comm, const void *id128, int nranks, int rank) {
     return 0;
 }
 
+int xrs_comm_info(void *comm, int *info4) {
+    // what RCCL itself reports for this communicator: {ncclGetVersion code, ncclCommCount, ncclCommUserRank,
+    // ncclCommCuDevice} -- bench.py --dry-rccl prints them so that a 30-second run tells an initialisation problem
+    // (wrong rank count, wrong device) from a performance problem
+    if (!comm || !info4) return fail("xrs_comm_info: null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    int version = 0, count = 0, rank = -1, dev = -1;
+    XRS_NCCL(ncclGetVersion(&version));
+    XRS_NCCL(ncclCommCount(c->nccl, &count));
+    XRS_NCCL(ncclCommUserRank(c->nccl, &rank));
+    XRS_NCCL(ncclCommCuDevice(c->nccl, &dev));
+    info4[0] = version; info4[1] = count; info4[2] = rank; info4[3] = dev;
+    return 0;
+}
+
 int xrs_comm_destroy(void *comm) {
     if (!comm) return 0;
     Comm *c = static_cast<Comm *>(comm);

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 _pool = {}                               # nbytes -> [(device pointer, event recorded when the block was freed)]
-_pool_lock = threading.Lock()
+_pool_lock = threading.RLock()          # re-entrant: DeviceArray.__del__ can run (GC) while a thread holds it
 _POOL_MAX_BYTES = 64 << 30
 _pool_bytes = 0
 _spare_events = []
@@ -80,8 +80,9 @@ def _raw_free(ptr: int, nbytes: int):
             _lib.call("xrs_event_record", ev, _active_stream())
         except Exception:                  # (no device / interpreter shutdown: pool the block without a fence)
             ev = None
+        entry = (ptr, ev)                  # (built outside the lock: an allocation can start a GC pass)
         with _pool_lock:
-            _pool.setdefault(nbytes, []).append((ptr, ev))
+            _pool.setdefault(nbytes, []).append(entry)
             _pool_bytes += nbytes
         return
     _lib.load().xrs_free(ptr)
@@ -100,11 +101,14 @@ def empty_cache():
         _pinned_pool.clear()
         _pinned_pool_bytes = 0
     with _pool_lock:
-        for lst in _pool.values():
-            for p, _ev in lst:
-                _lib.load().xrs_free(p)
+        blocks = [entry for lst in _pool.values() for entry in lst]
         _pool.clear()
         _pool_bytes = 0
+    for p, ev in blocks:
+        _lib.load().xrs_free(p)
+        if ev is not None:                 # the fence of the block: recycled for the next pooled block
+            with _pool_lock:
+                _spare_events.append(ev)
 
 
 # ------------------------------------------------------------------ recycled host blocks for results

@@ -29,7 +29,12 @@ from .device import DeviceArray
 
 def _atomic_write(path: str, data: bytes):
     tmp = f"{path}.tmp{os.getpid()}"
-    with open(tmp, "wb") as fh:
+    try:
+        os.unlink(tmp)                   # (a leftover of a crashed run with the same pid)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)      # never through a file or link somebody else made
+    with os.fdopen(fd, "wb") as fh:
         fh.write(data)
     os.replace(tmp, path)
 
@@ -40,6 +45,21 @@ def _read_bytes(path: str):
             return fh.read()
     except OSError:
         return None
+
+
+def rendezvous_dir() -> str:
+    """A directory only this user can read or write (mode 0700, owner checked) under the temp directory: rendezvous
+    files with predictable names in a world-writable directory could be pre-created or symlinked by someone else."""
+    d = os.path.join(tempfile.gettempdir(), "xrs_rdzv_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"{d} exists but is not a private directory of this user: set XRS_RDZV_FILE")
+    return d
 
 
 def _read_text(path: str):
@@ -122,6 +142,15 @@ class Comm:
         buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
         _lib.call("xrs_comm_init_rank", ctypes.byref(h), buf, self.world, self.rank)
         self.handle = h
+        self._scratch = None             # one small device buffer reused by allreduce() (control-plane values)
+
+    def info(self):
+        """What RCCL reports for this communicator: version, rank count, this rank, HIP device."""
+        raw = (ctypes.c_int * 4)()
+        _lib.call("xrs_comm_info", self.handle, raw)
+        v = int(raw[0])
+        version = "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v >= 10000 else str(v)
+        return {"rccl_version": version, "ranks": int(raw[1]), "rank": int(raw[2]), "device": int(raw[3])}
 
     @staticmethod
     def new_id() -> bytes:
@@ -150,11 +179,18 @@ class Comm:
     @classmethod
     def from_env(cls, timeout: float = 120.0):
         """One process per GPU on one node, launched by anything that sets RANK and WORLD_SIZE (torch.distributed.run,
-        mpirun wrappers, a shell loop).  The rendezvous file is $XRS_RDZV_FILE, or a name in the temp directory derived
-        from MASTER_PORT (distinct concurrent jobs on a node have distinct ports)."""
+        mpirun wrappers, a shell loop).  The rendezvous file is $XRS_RDZV_FILE, or -- when the launcher identifies the job
+        (MASTER_PORT or TORCHELASTIC_RUN_ID: distinct concurrent jobs on a node have distinct ones) -- a name derived from
+        that in a directory of this user only (`rendezvous_dir`).  With more than one rank and neither, two jobs on one
+        node would share a file name, so this raises instead of guessing."""
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-        path = os.environ.get("XRS_RDZV_FILE") or os.path.join(
-            tempfile.gettempdir(), "xrs_rdzv_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "job")))
+        path = os.environ.get("XRS_RDZV_FILE")
+        if not path:
+            port, run = os.environ.get("MASTER_PORT"), os.environ.get("TORCHELASTIC_RUN_ID")
+            if world > 1 and not port and not run:
+                raise RuntimeError("Comm.from_env: WORLD_SIZE > 1 needs XRS_RDZV_FILE, MASTER_PORT or TORCHELASTIC_RUN_ID "
+                                   "to name this job's rendezvous file")
+            path = os.path.join(rendezvous_dir(), "rdzv_%s_%s" % (port or "0", run or "job"))
         return cls.from_file(path, world, rank, timeout)
 
     def halo_exchange(self, shard: DeviceArray, halo: int, stream=None):
@@ -181,6 +217,17 @@ class Comm:
         flat = np.ascontiguousarray(a).reshape(-1)
         if flat.size == 0:
             return flat.reshape(a.shape).copy()
+        if flat.nbytes <= 4096:
+            # scalars and short vectors (barriers, max-over-ranks of a time, zone-id ranges): one scratch per communicator
+            # instead of a device allocation per call
+            if self._scratch is None:
+                self._scratch = DeviceArray((4096,), np.uint8)
+            _lib.call("xrs_memcpy_h2d", self._scratch.ptr, flat.ctypes.data, flat.nbytes, stream)
+            _lib.call(kind, self.handle, self._scratch.ptr, flat.size, self._OPS[op], stream)
+            out = np.empty_like(flat)
+            _lib.call("xrs_memcpy_d2h", out.ctypes.data, self._scratch.ptr, flat.nbytes, stream)
+            _lib.call("xrs_stream_sync", stream)
+            return out.reshape(a.shape)
         dev = DeviceArray.from_numpy(flat, stream=stream)
         _lib.call(kind, self.handle, dev.ptr, flat.size, self._OPS[op], stream)
         return dev.get(stream).reshape(a.shape)
@@ -277,13 +324,27 @@ class OverlappedHalo:
         _lib.call("xrs_event_destroy", self.ev_x0)
 
 
-def combine_zonal_partials(parts):
-    """Host-side combine of per-rank (count, sum, sumsq, min, max) partials -- the algebra of the
-    reference's dask path (zonal.py:92-99): sums add, min/max reduce.  For callers that gather partials
-    themselves instead of calling xrs_zonal_allreduce."""
+def combine_zonal_partials(parts, shift=None):
+    """Host-side combine of per-rank partials -- the algebra of the reference's dask path (zonal.py:92-99): sums add,
+    min/max reduce.  For callers that gather partials themselves instead of calling xrs_zonal_allreduce.
+
+    Each part is what `zonal.zonal_partials` returns: (count, sum, sumsq, min, max[, shift_i]) with sum / sumsq taken about
+    shift_i.  Parts that carry different shifts are re-centred onto `shift` (default: the first part's) before they are
+    added -- s1 += n (sh_i - sh), s2 += 2 (sh_i - sh) s1_i + n (sh_i - sh)^2 -- and the result is
+    (count, sum, sumsq, min, max, shift).  Parts without a shift (5-tuples) are taken to be unshifted sums."""
+    shifts = [float(p[5]) if len(p) > 5 else 0.0 for p in parts]
+    sh = shifts[0] if shift is None else float(shift)
     count = np.sum([p[0] for p in parts], axis=0, dtype=np.uint64)
-    s1 = np.sum([p[1] for p in parts], axis=0)
-    s2 = np.sum([p[2] for p in parts], axis=0)
+    s1 = np.zeros_like(np.asarray(parts[0][1], dtype=np.float64))
+    s2 = np.zeros_like(s1)
+    for p, shi in zip(parts, shifts):
+        n = np.asarray(p[0], dtype=np.float64)
+        d = shi - sh
+        p1, p2 = np.asarray(p[1], dtype=np.float64), np.asarray(p[2], dtype=np.float64)
+        s1 += p1 + n * d
+        s2 += p2 + 2.0 * d * p1 + n * d * d
     mn = np.min([p[3] for p in parts], axis=0)
     mx = np.max([p[4] for p in parts], axis=0)
-    return count, s1, s2, mn, mx
+    if all(len(p) <= 5 for p in parts) and shift is None:
+        return count, s1, s2, mn, mx
+    return count, s1, s2, mn, mx, sh

@@ -99,10 +99,12 @@ def _zone_table_device(zones_dev: DeviceArray):
     return uniq, zmin, rng, DeviceArray.from_numpy(lut)
 
 
-def _dense_zone_index_device(zones_dev: DeviceArray):
+def _dense_zone_index_device(zones_dev: DeviceArray, max_range=None):
     """Device-side counterpart of `_dense_zone_index` for zone rasters already in HBM: returns
     (unique ids as a host array of the zones dtype, int32 DeviceArray of dense indices), or None when
-    the ids are not integral / span too wide a range (the caller then takes the host path)."""
+    the ids are not integral / span too wide a range (the caller then takes the host path).
+    `max_range`: give up right after the (min, max) scan -- before the presence and index passes over the raster -- when
+    the ids span more than that many values."""
     code = _ZONE_DTYPE_CODE.get(zones_dev.dtype)
     if code is None:
         return None
@@ -119,6 +121,8 @@ def _dense_zone_index_device(zones_dev: DeviceArray):
     if not all_integral or zmax - zmin >= _DENSE_RANGE_LIMIT:
         return None
     rng = int(zmax - zmin) + 1
+    if max_range is not None and rng > max_range:
+        return None
     present = DeviceArray((rng,), np.uint8)
     _lib.call("xrs_zonal_presence", zones_dev.ptr, code, n, float(zmin), rng, present.ptr, stream)
     mask = present.get(stream).astype(bool)
@@ -142,33 +146,43 @@ def _stage(zone_idx, values):
     return zdev, vdev
 
 
-def _pick_shift(vdev, comm, stream):
+def _pick_shift(vdev, comm, stream, nodata_values=None):
     """A value near the data for the shifted moments (xrs_zonal_partials_*: sums of x - shift and (x - shift)^2): the
-    mean of a few hundred finite cells sampled from three places of the plane; every rank of a sharded run must use the
-    same one, so they take the smallest candidate.  0 when nothing finite was sampled (any value is correct)."""
+    mean of a few hundred valid cells (finite, not nodata) sampled from three places of the plane, ROUNDED TO AN INTEGER
+    -- x - shift and the sums then stay exact for integral rasters (class maps, integer DEMs), as they were before the
+    shift existed.  Every rank of a sharded run must use the same one, so they take the smallest candidate; a rank
+    without cells still takes part in that collective (with +inf).  0 when nothing valid was sampled anywhere (any
+    value is correct)."""
     n = int(vdev.size)
-    take = min(256, n)
-    itemsize = vdev.dtype.itemsize
-    sample = np.empty(3 * take, vdev.dtype)
-    for k, start in enumerate((0, max(0, n // 2 - take // 2), max(0, (3 * n) // 4 - take // 2))):
-        start = min(start, n - take)
-        _lib.call("xrs_memcpy_d2h", sample[k * take:(k + 1) * take].ctypes.data, vdev.ptr + start * itemsize, take * itemsize, stream)
-    _lib.call("xrs_stream_sync", stream)
-    good = sample[np.isfinite(sample)]
-    cand = float(np.mean(good, dtype=np.float64)) if good.size else np.inf
+    cand = np.inf
+    if n:
+        take = min(256, n)
+        itemsize = vdev.dtype.itemsize
+        sample = np.empty(3 * take, vdev.dtype)
+        for k, start in enumerate((0, max(0, n // 2 - take // 2), max(0, (3 * n) // 4 - take // 2))):
+            start = min(start, n - take)
+            _lib.call("xrs_memcpy_d2h", sample[k * take:(k + 1) * take].ctypes.data, vdev.ptr + start * itemsize, take * itemsize, stream)
+        _lib.call("xrs_stream_sync", stream)
+        good = sample[np.isfinite(sample)]
+        if nodata_values is not None:
+            good = good[good != nodata_values]
+        if good.size:
+            cand = float(np.rint(np.mean(good, dtype=np.float64)))
     if comm is not None:
         cand = float(np.asarray(comm.allreduce(np.array([cand]), 'min')).reshape(-1)[0])
     return cand if np.isfinite(cand) else 0.0
 
 
-def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, table=None):
+def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, table=None, shift=None):
     """Per-zone (count, sum, sumsq, min, max, shift) for dense `zone_idx` (device or host arrays): NumPy arrays, with
     sum / sumsq the sums of (x - shift) and (x - shift)^2 (finalize_stats adds the shift back).
 
     `comm`: optional multi-GPU communicator (xrspatial_amd.distributed.Comm); the partials are
     all-reduced over it so every rank returns the global result.
     `table`: (zmin, range, lut DeviceArray) -- `zone_idx` then holds RAW int32 zone ids that the kernel maps through
-    the table itself (no dense index raster is materialised)."""
+    the table itself (no dense index raster is materialised).
+    `shift`: the value the moments are taken about; callers that gather per-rank partials themselves (comm=None on every
+    rank) must pass the SAME one everywhere or hand the shifts to distributed.combine_zonal_partials."""
     _lib.require_device()
     stream = get_stream()
     zdev, vdev = _stage(zone_idx, values)
@@ -183,7 +197,9 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     _lib.call("xrs_zonal_init" + sfx, cnt.ptr, s1.ptr, s2.ptr, mn.ptr, mx.ptr, n_zones, stream)
     has_nodata = nodata_values is not None
     nodata = float(nodata_values) if has_nodata else 0.0
-    shift = _pick_shift(vdev, comm, stream) if vdev.size else 0.0
+    if shift is None:
+        shift = _pick_shift(vdev, comm, stream, nodata_values)       # (a collective when comm is given: every rank, also an empty one)
+    shift = float(shift)
     if table is not None:
         zmin, rng, lut_dev = table
         _lib.call("xrs_zonal_partials_lut_f64" if f64 else "xrs_zonal_partials_lut_f32", zdev.ptr, int(zmin), int(rng),
@@ -197,7 +213,11 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
     return cnt.get(stream), s1.get(stream), s2.get(stream), mn.get(stream), mx.get(stream), shift
 
 
-_MAJORITY_TABLE_LIMIT = 1 << 22      # (zones x distinct values) counters of the counting path
+# (zones x distinct values) counters of the counting path: the regime in which xrs_crosstab_counts keeps the whole table
+# in per-workgroup LDS counters (zonal_index.hip).  Above it the kernel issues one 64-bit device atomic per cell -- its
+# own comments measured that 40x slower, and it has never been timed against the two radix sorts -- so larger tables
+# (an integer DEM with thousands of distinct values) keep the sorting path.
+_MAJORITY_TABLE_LIMIT = 36864
 
 
 def _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream):
@@ -206,7 +226,10 @@ def _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream):
     counted by the crosstab kernel, and the arg-max of each zone's row (first maximum = smallest value, as
     _stats_majority's np.unique + argmax, zonal.py:56-68) is the answer: four streaming passes instead of two radix
     sorts of the whole raster.  None when the values are not categorical (the caller sorts)."""
-    cat = _dense_zone_index_device(vdev)
+    if n_zones == 0:
+        return np.full(0, np.nan)
+    # (rejected on the value RANGE right after the scan, before the presence and index passes over the raster)
+    cat = _dense_zone_index_device(vdev, max_range=_MAJORITY_TABLE_LIMIT // n_zones)
     if cat is None:
         return None
     cats, cidx = cat

@@ -145,12 +145,12 @@ def call(name, *a):
             _arr(o, n, np.int8)[...] = (np.where(z > 0, 1, np.where(z < 0, -1, 0)) * conf).astype(np.int8)
     elif name == "xrs_zonal_scan":
         z, code, n, res, _ = a
-        assert code == 0
-        ids = _arr(z, n, np.int32)
+        ids = _arr(z, n, (np.int32, np.int64, np.float32, np.float64)[code])
+        fin = ids[np.isfinite(ids)] if code >= 2 else ids
         out = _arr(res, 4, np.float64)
-        out[0], out[1] = (ids.min(), ids.max()) if n else (np.inf, -np.inf)
-        out[2:3].view(np.uint64)[0] = n
-        out[3:4].view(np.int32)[0] = 1
+        out[0], out[1] = (fin.min(), fin.max()) if fin.size else (np.inf, -np.inf)
+        out[2:3].view(np.uint64)[0] = fin.size
+        out[3:4].view(np.int32)[0] = int(bool((fin == np.floor(fin)).all()))
     elif name == "xrs_zonal_presence":
         z, code, n, zmin, rng, present, _ = a
         ids = _arr(z, n, np.int32).astype(np.int64) - int(zmin)
@@ -181,6 +181,14 @@ def call(name, *a):
         _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
         np.minimum.at(_arr(mn, nz, vt), idx[ok], v[ok])
         np.maximum.at(_arr(mx, nz, vt), idx[ok], v[ok])
+    elif name == "xrs_memset":
+        ptr, value, nbytes, _ = a
+        _arr(ptr, nbytes, np.uint8)[...] = value
+    elif name == "xrs_crosstab_counts":
+        z, c, n, nz, nc, counts, _ = a
+        zi, ci = _arr(z, n, np.int32).astype(np.int64), _arr(c, n, np.int32).astype(np.int64)
+        ok = (zi >= 0) & (zi < nz) & (ci >= 0) & (ci < nc)
+        _arr(counts, nz * nc, np.uint64)[...] += np.bincount(zi[ok] * nc + ci[ok], minlength=nz * nc).astype(np.uint64)
     elif name == "xrs_zonal_index":
         z, code, n, zmin, rng, lut, idx, _ = a
         assert code == 0

@@ -65,9 +65,16 @@ def main(outdir):
     table = zonal.stats(shard(zones_full), dem, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
     for col in table.columns:
         out['zonal_' + col] = np.asarray(table[col])
+    # crosstab: every rank counts its rows, the (zones x categories) tables are added, every rank holds the whole frame
+    cats_full = ((np.arange(H)[:, None] * 7 + np.arange(W)[None, :] * 3) % 5 + 10).astype(np.int32)
+    ct = zonal.crosstab(shard(zones_full), shard(cats_full), nodata_values=12)
+    out['crosstab_cols'] = np.asarray([int(c) if c != 'zone' else -1 for c in ct.columns])
+    out['crosstab'] = ct.to_numpy(dtype=np.float64)
+    out['crosstab_pct'] = zonal.crosstab(shard(zones_full), shard(cats_full), zone_ids=[1, 4, 7], cat_ids=[10, 14],
+                                         agg='percentage').to_numpy(dtype=np.float64)
     # what a sharded raster cannot do fails loudly
     for bad in (lambda: zonal.stats(shard(zones_full), dem), lambda: focal.apply(shard(full, halo_cap=2), k7),
-                lambda: zonal.crosstab(shard(zones_full), shard(zones_full)),
+                lambda: zonal.crosstab(shard(zones_full), dem),
                 lambda: xs.slope(xs.DataArray(dem.data, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, y1 - y0),
                                                                                    'lon': np.linspace(1, 2, W)}), method='geodesic')):
         try:

@@ -111,6 +111,23 @@ def test_sharded_api_host_logic(tmp_path, world):
         np.testing.assert_array_equal(p['zonal_zone'], table['zone'])
         for col in names:
             np.testing.assert_allclose(p['zonal_' + col], table[col], rtol=1e-9, err_msg=col)
+    # sharded crosstab == the monolithic table (reference semantics: zonal.py:699-800; nodata category dropped)
+    ct, pct = _crosstab_reference(zones, H, W)
+    for p in parts:
+        np.testing.assert_array_equal(p['crosstab_cols'], [-1, 10, 11, 13, 14])
+        np.testing.assert_array_equal(p['crosstab'], ct)
+        np.testing.assert_allclose(p['crosstab_pct'], pct, rtol=1e-6)
+
+
+def _crosstab_reference(zones, H, W):
+    cats = ((np.arange(H)[:, None] * 7 + np.arange(W)[None, :] * 3) % 5 + 10).astype(np.int32)
+    zs, cs = np.unique(zones), [10, 11, 13, 14]                          # (category 12 is the nodata value)
+    ct = np.array([[z] + [int(np.count_nonzero((zones == z) & (cats == c))) for c in cs] for z in zs], dtype=np.float64)
+    pct = []
+    for z in (1, 4, 7):
+        total = np.float32(np.count_nonzero(zones == z))                   # all categories that exist in the raster count
+        pct.append([z] + [np.count_nonzero((zones == z) & (cats == c)) / total * 100 for c in (10, 14)])
+    return ct, np.array(pct, dtype=np.float64)
 
 
 def test_combine_partials():

@@ -1940,6 +1940,16 @@ def test_sharded_api_equals_single_gpu(tmp_path, world):
         for col in table.columns:
             np.testing.assert_allclose(p['zonal_' + col].astype(np.float64), np.asarray(table[col], dtype=np.float64),
                                        rtol=1e-12, err_msg=col)
+    # sharded crosstab (per-rank counts + xrs_allreduce_u64) == the single-GPU table
+    from xrspatial_amd import zonal
+    H, W = zones_full.shape
+    cats_full = ((np.arange(H)[:, None] * 7 + np.arange(W)[None, :] * 3) % 5 + 10).astype(np.int32)
+    dev = lambda a: xs.DataArray(xs.DeviceArray.from_numpy(a), dims=['y', 'x'])   # noqa: E731
+    ct = zonal.crosstab(dev(zones_full), dev(cats_full), nodata_values=12).to_numpy(dtype=np.float64)
+    pct = zonal.crosstab(dev(zones_full), dev(cats_full), zone_ids=[1, 4, 7], cat_ids=[10, 14], agg='percentage').to_numpy(dtype=np.float64)
+    for p in parts:
+        np.testing.assert_array_equal(p['crosstab'], ct)
+        np.testing.assert_array_equal(p['crosstab_pct'], pct)
 
 
 # ---------------------------------------------------------------- zonal.trim / zonal.crop, multispectral.true_color

@@ -563,6 +563,13 @@ def _crosstab_2d(zones_data, values_data, zone_ids, cat_ids, nodata_values, agg)
         _lib.call("xrs_memset", cdev.ptr, 0, cdev.nbytes, stream)
         _lib.call("xrs_crosstab_counts", zidx.ptr, cidx.ptr, zidx.size, nz, nc, cdev.ptr, stream)
         counts = cdev.get(stream).reshape(nz, nc)
+    return _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_values, agg)
+
+
+def _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_values, agg):
+    """(zones x categories) cell counts -> the reference's DataFrame (zonal.py:699-800): nodata category dropped, zone /
+    category selections, counts or percentages of the zone's valid cells."""
+    nc = len(all_cats)
     valid_cat = np.ones(nc, dtype=bool) if nodata_values is None else (all_cats != nodata_values)
     unique_cats = all_cats[valid_cat]
     counts = counts[:, valid_cat].astype(np.int64)
@@ -585,6 +592,66 @@ def _crosstab_2d(zones_data, values_data, zone_ids, cat_ids, nodata_values, agg)
         for c in sel_cats:
             frame[c] = frame[c] / total * 100
     return pd.DataFrame(frame)[['zone'] + list(sel_cats)]
+
+
+def _sharded_dense_index(arr, what):
+    """Dense indices of an integral row-sharded raster that every rank agrees on: (global unique values in the raster's
+    dtype, int32 DeviceArray of this rank's dense indices; -1 for non-finite cells).  The ranks all-reduce the value range
+    and then the union of their presence maps -- the protocol of `_stats_sharded`."""
+    comm, stream, loc = arr.comm, get_stream(), arr.local
+    code = _ZONE_DTYPE_CODE.get(loc.dtype)
+    if code is None:
+        raise TypeError(f"sharded {what} rasters must be int32 / int64 / float32 / float64")
+    res = DeviceArray((4,), np.float64)
+    _lib.call("xrs_zonal_scan", loc.ptr, code, loc.size, res.ptr, stream)
+    raw = res.get(stream)
+    n_local = int(raw[2:3].view(np.uint64)[0])
+    integral = float(int(raw[3:4].view(np.int32)[0]) if n_local else 1)
+    lo, hi = (raw[0], raw[1]) if n_local else (np.inf, -np.inf)
+    if comm is not None and arr.world > 1:
+        lo, neg_hi, integral = (float(v) for v in comm.allreduce(np.array([lo, -hi, integral]), 'min'))
+        hi = -neg_hi
+    if not integral:
+        raise NotImplementedError(f"sharded {what} rasters must hold integral values (categories)")
+    if not np.isfinite(lo):
+        return np.empty(0, loc.dtype), DeviceArray.from_numpy(np.full(loc.shape, -1, np.int32))
+    rng = int(hi - lo) + 1
+    if rng > _SHARDED_RANGE_LIMIT:
+        raise NotImplementedError(f"{what} values span {rng}; sharded rasters handle up to {_SHARDED_RANGE_LIMIT}")
+    present = DeviceArray((rng,), np.uint8)
+    _lib.call("xrs_zonal_presence", loc.ptr, code, loc.size, float(lo), rng, present.ptr, stream)
+    seen = present.get(stream)
+    if comm is not None and arr.world > 1:
+        seen = comm.allreduce(seen, 'max')
+    mask = np.asarray(seen) > 0
+    lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
+    uniq = (np.flatnonzero(mask).astype(np.float64) + lo).astype(loc.dtype)
+    idx = DeviceArray(loc.shape, np.int32)
+    _lib.call("xrs_zonal_index", loc.ptr, code, loc.size, float(lo), rng, DeviceArray.from_numpy(lut).ptr, idx.ptr, stream)
+    _lib.call("xrs_stream_sync", stream)
+    return uniq, idx
+
+
+def _crosstab_2d_sharded(zones, values, zone_ids, cat_ids, nodata_values, agg):
+    """2-D crosstab of row-sharded rasters (the dask slot of the reference: zonal.py:868-916 -- per-block tables combined
+    by summing): every rank counts its rows with the same kernel into the same (zones x categories) layout, one
+    xrs_allreduce_u64 adds the tables, and every rank returns the whole DataFrame."""
+    same_layout(zones, values)
+    _lib.require_device()
+    stream = get_stream()
+    unique_zones, zidx = _sharded_dense_index(zones, "zone")
+    all_cats, cidx = _sharded_dense_index(values, "category")
+    nz, nc = len(unique_zones), len(all_cats)
+    counts = np.zeros((nz, nc), dtype=np.uint64)
+    if nz and nc:
+        cdev = DeviceArray((nz * nc,), np.uint64)
+        _lib.call("xrs_memset", cdev.ptr, 0, cdev.nbytes, stream)
+        _lib.call("xrs_crosstab_counts", zidx.ptr, cidx.ptr, zidx.size, nz, nc, cdev.ptr, stream)
+        counts = cdev.get(stream)
+        if zones.comm is not None and zones.world > 1:
+            counts = zones.comm.allreduce(counts, 'sum')
+        counts = np.asarray(counts).reshape(nz, nc)
+    return _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_values, agg)
 
 
 def _crosstab_3d(zones_data, values_data, cat_labels, zone_ids, cat_ids, nodata_values, agg):
@@ -620,8 +687,9 @@ def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count"
         raise TypeError("zones must be instance of DataArray")
     if not isinstance(values, DataArray):
         raise TypeError("values must be instance of DataArray")
-    if isinstance(zones.data, ShardedArray) or isinstance(values.data, ShardedArray):
-        raise NotImplementedError("zonal.crosstab is not implemented for row-sharded (multi-GPU) arrays")
+    sharded = isinstance(zones.data, ShardedArray) or isinstance(values.data, ShardedArray)
+    if sharded and not (isinstance(zones.data, ShardedArray) and isinstance(values.data, ShardedArray) and values.ndim == 2):
+        raise NotImplementedError("zonal.crosstab of row-sharded (multi-GPU) arrays: both rasters sharded, 2-D values")
     if zones.ndim != 2:
         raise ValueError("zones must be 2D")
     if not (issubclass(zones.data.dtype.type, np.integer) or issubclass(zones.data.dtype.type, np.floating)):
@@ -634,6 +702,8 @@ def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count"
         validate_arrays(zones, values)
         if agg not in ("percentage", "count"):
             raise ValueError("`agg` method for 2D data array must be one of following ['percentage', 'count']")
+        if sharded:
+            return _crosstab_2d_sharded(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
         return _crosstab_2d(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
     if agg not in _DEFAULT_STATS:
         raise ValueError(f"`agg` method for 3D numpy backed data array must be one of following {list(_DEFAULT_STATS)}")

@@ -1250,6 +1250,13 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
             return launch_focal<0, 0, 2>(a, vec, lds, s);
         }
     }
+    if (stat_mask == (1u << XRS_STAT_MEAN) && !prefer_lds() && !getenv("XRS_FOCAL_MEAN_DIRECT") &&
+        pass_has_compile_time_mask(kernel, krows, kcols)) {
+        // circle_kernel(1, 1, 2) / np.ones((3, 3)): the strip kernel of pass.hip without terrain products -- compile-time
+        // mask, shared row sums (XRS_FOCAL_MEAN_DIRECT=1: this file's run-time-mask kernel, A/B runs)
+        return xrs_raster_pass_f32(in_dev, nullptr, nullptr, nullptr, nullptr, a.out[XRS_STAT_MEAN], kernel, krows, kcols, work_dev,
+                                   rows, cols, ld_in, ld_out, 1.0, 1.0, 0.0, 0.0, halo_top, halo_bot, stream);
+    }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
     if (krows <= 7 && krows == kcols && (krows >= 5 || getenv("XRS_FOCAL_WALK3")) && !prefer_strip()) {
         // small circles / boxes (5x5, 7x7): all requested statistics from one column-walker kernel

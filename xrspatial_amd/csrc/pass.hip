@@ -158,6 +158,9 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
 #pragma unroll
         for (int ir = 0; ir < NR; ++ir) {
+            // (the focal mean alone: without the terrain block in front, the scheduler hoists the conversions of ALL rows to
+            //  the top -- 128 registers of float64 images -- and spills 100 of them; one row at a time)
+            if (OPS == 0) __builtin_amdgcn_sched_barrier(0);
             double d[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
@@ -344,6 +347,7 @@ template <int K>
 int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
     if (ops & OP_ASPECT) return launch_pass<FUSABLE, K>(a, s);
     switch (ops) {
+        case 0: return launch_pass<0, K>(a, s);                              // the focal mean alone (compile-time masks only)
         case OP_HILL: return launch_pass<OP_HILL, K>(a, s);
         case OP_SLOPE: return launch_pass<OP_SLOPE | OP_HILL, K>(a, s);     // (absent hillshade skipped by a wave-uniform test;
                                                                              //  measured faster than a slope-only instantiation)
@@ -357,6 +361,24 @@ int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace xrs {
+// circle_kernel(1, 1, 2) or np.ones((3, 3)): the masks raster_pass_kernel is specialised for
+bool pass_has_compile_time_mask(const double *kernel, int krows, int kcols) {
+    if (!kernel || krows != kcols) return false;
+    if (krows == 3) {
+        for (int i = 0; i < 9; ++i)
+            if (kernel[i] != 1.0) return false;
+        return true;
+    }
+    if (krows != 5) return false;
+    static const int rows5[5] = {4, 14, 31, 14, 4};
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx)
+            if ((kernel[ky * 5 + kx] == 1.0) != ((rows5[ky] >> kx & 1) != 0)) return false;
+    return true;
+}
+}  // namespace xrs
 
 extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
                                    float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
@@ -374,8 +396,12 @@ extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float 
     if (rows <= 0 || cols <= 0 || (!ops && !focal_mean_dev)) return 0;
 
     const int fused_ops = ops & FUSABLE;
+    // The focal mean ALONE also runs here when its mask is one of the compile-time ones (round 3: the stand-alone 5x5
+    // kernel of kxk.hip spills when it is given the compile-time mask and the shared row sums this kernel has; this
+    // instantiation is that kernel -- kxk.hip's xrs_focal_stats_f32 routes such requests here).
+    const bool focal_only = !fused_ops && focal_mean_dev && pass_has_compile_time_mask(kernel, krows, kcols);
     // (any width / pitch / base address: the strip layout's 16-byte accesses only need dword alignment)
-    bool fast = fused_ops && focal_mean_dev && krows == kcols && (krows == 3 || krows == 5) && ld_in >= cols &&
+    bool fast = (fused_ops || focal_only) && focal_mean_dev && krows == kcols && (krows == 3 || krows == 5) && ld_in >= cols &&
                 ld_out >= cols && halo_top >= 0 && halo_bot >= 0;
     float *outs[4] = {slope_dev, aspect_dev, curvature_dev, hillshade_dev};
     bool nt = ld_out % 4 == 0 && aligned16(focal_mean_dev);

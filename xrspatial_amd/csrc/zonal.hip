@@ -123,8 +123,9 @@ struct Acc {
 
 // NT threads per workgroup: 256, or 1024 when the zone table leaves room for only ONE workgroup per CU (more than 64 KiB of
 // LDS: 2 300+ zones) -- 16 waves then share the table instead of 4 (5 000 zones: 1.51 -> 1.36 ms; the rest is the flush of every workgroup's table with device atomics)
+// (1024-thread workgroups: 8 waves per SIMD = 64 registers, so that TWO workgroups fit a CU when their tables do)
 template <typename VT, bool LDS, bool VEC, int NT = 256>
-__global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
+__global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zonal_kernel(const ZonalArgs<VT> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Acc<VT, LDS> acc;
     if (LDS) {
@@ -150,11 +151,12 @@ __global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
     // of a real zone raster touches few zones, so the LDS flush at the end is short.
     const long n_chunks = gridDim.x;                                           // a multiple of 8
     const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
-    constexpr long TRIP = (long)NT * 4;                                        // 16-byte slots of one workgroup trip (U = 4)
+    constexpr int U = NT == 1024 ? 2 : 4;   // 16-byte slots per lane per trip, 64 slots apart (1024-thread workgroups: 2, so
+                                            // that both the one-zone path and the row path fit the 64 registers of 8 waves per SIMD)
+    constexpr long TRIP = (long)NT * U;                                        // 16-byte slots of one workgroup trip
     const long per_chunk = (((n4 + n_chunks - 1) / n_chunks + TRIP - 1) / TRIP) * TRIP;
     const long c_begin = my_chunk * per_chunk;
     const long c_end = (my_chunk < n_chunks && c_begin < n4) ? (c_begin + per_chunk < n4 ? c_begin + per_chunk : n4) : c_begin;
-    constexpr int U = 4;                    // 16-byte slots per lane per trip, 64 slots apart: a wave covers 1024
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // consecutive cells per load instruction
     for (long i0 = c_begin; i0 < c_end; i0 += NT * U) {
         // (whole waves stay converged for the reductions: the loop bound is wave-uniform)
@@ -186,29 +188,23 @@ __global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
                 }
             }
         }
-        // fold the lane's 16 cells while they stay in one zone; spill the partial when the zone changes
+        // ---- the whole trip in ONE zone (the common case of spatially coherent zones): every lane folds its 4 U cells, one
+        // set of wave64 reductions, one lane touches the accumulators
         Part<VT> p; p.z = -1; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
         bool lane_single = true;       // all valid cells of this lane fell into p.z
 #pragma unroll
         for (int k = 0; k < 4 * U; ++k) {
             if (!cell_ok(a, z[k], v[k])) continue;
-            if (p.z >= 0 && p.z != z[k]) {
-                acc.add(p);
-                lane_single = false;
-                p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
-            }
+            lane_single = lane_single && (p.z < 0 || p.z == z[k]);
             p.z = z[k];
             const double d = (double)v[k] - a.shift;
             p.c += 1; p.s += d; p.q += d * d;
             p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
         }
-        // wave-level: if every lane's surviving partial is for the same zone, shuffle-reduce it
         const unsigned long long have = __ballot(p.z >= 0);
         if (!have) continue;
-        const int first = __ffsll((long long)have) - 1;
-        const int z0 = __shfl(p.z, first);
-        const bool uniform = __all((p.z < 0 || p.z == z0) && lane_single);
-        if (uniform) {
+        const int z0 = __shfl(p.z, __ffsll((long long)have) - 1);
+        if (__all(lane_single && (p.z < 0 || p.z == z0))) {
             // wave64 reductions with DPP cross-lane moves (VALU only: the LDS pipe stays free for the atomics)
             rocprim::warp_reduce<unsigned, 64>::storage_type su;
             rocprim::warp_reduce<double, 64>::storage_type sd;
@@ -219,8 +215,63 @@ __global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
             rocprim::warp_reduce<VT, 64>().reduce(p.mn, p.mn, sv, rocprim::minimum<VT>());
             rocprim::warp_reduce<VT, 64>().reduce(p.mx, p.mx, sv, rocprim::maximum<VT>());
             if ((threadIdx.x & 63) == 0) { p.z = z0; acc.add(p); }
-        } else if (p.z >= 0) {
-            acc.add(p);
+            continue;
+        }
+        // ---- several zones under the wave.  Slot by slot (a slot = 64 consecutive 16-byte groups = 256 cells in lane
+        // order): the lane's 4 cells folded into one partial (a zone boundary that cuts through them -- rare -- sends those
+        // cells to the accumulators one by one), then the lanes are reduced in ROWS OF 16 (64 cells) wherever a row lies
+        // in one zone -- DPP row operations, four steps -- and only the row's first lane adds; rows that straddle zones
+        // (finely scattered zone rasters) go lane by lane.  Letting every lane add its own partial serialised 32 lanes on
+        // one LDS address for blocky rasters whose zones are narrower than a wave's trip (128-cell blocks: 1.35 ms for a
+        // 16384^2 raster against 0.36 for 1024-cell blocks; profiles/r03).
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p.z = -1; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int zk = z[4 * u + k];
+                const VT vk = v[4 * u + k];
+                if (!cell_ok(a, zk, vk)) continue;
+                const double d = (double)vk - a.shift;
+                if (p.z >= 0 && p.z != zk) {
+                    Part<VT> one; one.z = zk; one.c = 1; one.s = d; one.q = d * d; one.mn = vk; one.mx = vk;
+                    acc.add(one);
+                    continue;
+                }
+                p.z = zk;
+                p.c += 1; p.s += d; p.q += d * d;
+                p.mn = vk < p.mn ? vk : p.mn; p.mx = vk > p.mx ? vk : p.mx;
+            }
+            // (finely scattered zones -- more runs of equal zones than rows under the slot -- skip the row test)
+            const int z_prev = __shfl_up(p.z, 1);
+            if (__popcll(__ballot((threadIdx.x & 63) == 0 || z_prev != p.z)) > 8) {
+                if (p.z >= 0) acc.add(p);
+                continue;
+            }
+            rocprim::warp_reduce<int, 16>::storage_type si;
+            int zlo, zhi;
+            rocprim::warp_reduce<int, 16>().reduce(p.z, zlo, si, rocprim::minimum<int>());
+            rocprim::warp_reduce<int, 16>().reduce(p.z, zhi, si, rocprim::maximum<int>());
+            // (the reduced value is valid in the row's first lane: broadcast it to the row)
+            zlo = __shfl(zlo, (int)(threadIdx.x & 48), 64);
+            zhi = __shfl(zhi, (int)(threadIdx.x & 48), 64);
+            const bool row_one_zone = zlo == zhi && zlo >= 0;
+            if (__any(row_one_zone)) {
+                Part<VT> r = p;
+                rocprim::warp_reduce<unsigned, 16>::storage_type su;
+                rocprim::warp_reduce<double, 16>::storage_type sd;
+                typename rocprim::warp_reduce<VT, 16>::storage_type sv;
+                rocprim::warp_reduce<unsigned, 16>().reduce(p.c, r.c, su);
+                rocprim::warp_reduce<double, 16>().reduce(p.s, r.s, sd);
+                rocprim::warp_reduce<double, 16>().reduce(p.q, r.q, sd);
+                rocprim::warp_reduce<VT, 16>().reduce(p.mn, r.mn, sv, rocprim::minimum<VT>());
+                rocprim::warp_reduce<VT, 16>().reduce(p.mx, r.mx, sv, rocprim::maximum<VT>());
+                if (row_one_zone) {
+                    if ((threadIdx.x & 15) == 0) acc.add(r);
+                    p.z = -1;
+                }
+            }
+            if (p.z >= 0) acc.add(p);
         }
     }
 
@@ -237,7 +288,11 @@ __global__ void __launch_bounds__(NT) zonal_kernel(const ZonalArgs<VT> a) {
 
     if (LDS) {
         __syncthreads();
-        for (int z = threadIdx.x; z < a.nz; z += NT) {
+        // every workgroup starts its flush somewhere else in the table: workgroups finish together, and all of them walking
+        // the zones in the same order would queue their device atomics on the same few addresses at any moment
+        const int z_start = (int)(((long)blockIdx.x * 977) % (a.nz > 0 ? a.nz : 1));
+        for (int zi = threadIdx.x; zi < a.nz; zi += NT) {
+            const int z = zi + z_start < a.nz ? zi + z_start : zi + z_start - a.nz;
             const unsigned c = acc.c32[z];
             if (c) {
                 atomicAdd(&a.count[z], (unsigned long long)c);
@@ -299,19 +354,34 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
         a.count = reinterpret_cast<unsigned long long *>(count_dev) + base;
         a.sum = sum_dev + base; a.sumsq = sumsq_dev + base; a.mn = min_dev + base; a.mx = max_dev + base;
         const size_t smem = (size_t)nzw * per_zone;
-        const bool big = smem > 64 * 1024;                        // one workgroup per CU: make it 1024 threads
-        const int nt = big ? 1024 : 256;
+        // 1024-thread workgroups: 16 waves share one table.  Up to 64 KiB of table two of them fit a CU (32 waves, the
+        // CU's limit) and 512 chunks cover the chip; larger tables: one per CU, 256 chunks.  Measured on 16384^2, 1000 zones
+        // (profiles/r03): 256-thread workgroups x 2048 chunks 0.417 ms blocky / 0.469 scattered; 1024 x 512: 0.339 / 0.398 --
+        // a quarter of the tables to initialise and flush, and the flushes (rotated start) queue on fewer addresses.
+        // XRS_ZONAL_NT=256 / XRS_ZONAL_CHUNKS=n: the round-2 geometry, for A/B runs.
+        const bool big = smem > 64 * 1024;                        // one workgroup per CU
+        bool wide = true;
+        if (const char *e = getenv("XRS_ZONAL_NT")) wide = atoi(e) != 256;
+        const int nt = (big || wide) ? 1024 : 256;
         long grid = ((vec ? (n + 3) / 4 : n) + nt - 1) / nt;
-        const long cap = big ? 256L : 256L * 8;                   // chunks: 8 per CU, or one (a second one would only flush a second table)
+        long cap = big ? 256L : wide ? 512L : 256L * 8;
+        if (const char *e = getenv("XRS_ZONAL_CHUNKS")) cap = atol(e) > 0 ? atol(e) : cap;
         if (grid > cap) grid = cap;
         if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
         grid = xcd_grid(grid, 1);                                 // multiple of 8: chunk <-> XCD mapping is a bijection
-        if (big) {
-            // (idempotent per instantiation; a race only repeats the call)
-            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true, 1024>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, false, 1024>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        if (nt == 1024) {
+            // once per process and device (idempotent; a race only repeats the call).  Round 3: issued on EVERY call it cost
+            // ~1 ms of the 1.37 ms a 5000-zone reduction of a 16384^2 raster took -- the call synchronises.
+            static thread_local unsigned long long attr_done = 0;          // bit d: device d
+            int dev = 0;
+            XRS_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !(attr_done >> dev & 1)) {
+                XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true, 1024>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+                XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, false, 1024>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+                if (dev >= 0 && dev < 64) attr_done |= 1ull << dev;
+            }
             if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
             else hipLaunchKernelGGL((zonal_kernel<VT, true, false, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
         } else {

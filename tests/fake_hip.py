@@ -153,7 +153,9 @@ def call(name, *a):
         out[3:4].view(np.int32)[0] = int(bool((fin == np.floor(fin)).all()))
     elif name == "xrs_zonal_presence":
         z, code, n, zmin, rng, present, _ = a
-        ids = _arr(z, n, np.int32).astype(np.int64) - int(zmin)
+        raw = _arr(z, n, (np.int32, np.int64, np.float32, np.float64)[code])
+        raw = raw[np.isfinite(raw)] if code >= 2 else raw
+        ids = raw.astype(np.int64) - int(zmin)
         flags = _arr(present, rng, np.uint8)
         flags[...] = 0
         flags[ids[(ids >= 0) & (ids < rng)]] = 1
@@ -191,9 +193,10 @@ def call(name, *a):
         _arr(counts, nz * nc, np.uint64)[...] += np.bincount(zi[ok] * nc + ci[ok], minlength=nz * nc).astype(np.uint64)
     elif name == "xrs_zonal_index":
         z, code, n, zmin, rng, lut, idx, _ = a
-        assert code == 0
-        off = _arr(z, n, np.int32).astype(np.int64) - int(zmin)
-        inside = (off >= 0) & (off < rng)
+        raw = _arr(z, n, (np.int32, np.int64, np.float32, np.float64)[code])
+        fin = np.isfinite(raw) if code >= 2 else np.ones(n, bool)
+        off = np.where(fin, raw, 0).astype(np.int64) - int(zmin)
+        inside = fin & (off >= 0) & (off < rng)
         _arr(idx, n, np.int32)[...] = np.where(inside, _arr(lut, rng, np.int32)[np.clip(off, 0, rng - 1)], -1)
     elif name in ("xrs_zonal_partials_f64",):
         z, vals, n, nz, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, _ = a

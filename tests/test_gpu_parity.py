@@ -473,6 +473,45 @@ def test_third_generation_walkers_interior_and_rim_tiles():
         np.testing.assert_allclose(o_std.get(), want['std'][first:first + n], rtol=2.5e-6)
 
 
+def test_windows_beyond_the_tiled_kernels():
+    """Windows the tiled kernels could not take until round 3: 51x51 .. 63x63 (LDS tiles beyond 64 KiB, one workgroup per
+    CU) and anything larger in either direction (csrc/kxk_big.hip: one thread per cell, mask / weights from a device copy of
+    the kernel) -- 75x75 and 101x101 circles, a ragged 67x5 mask, a 3x71 box -- all seven statistics and convolve_2d
+    against the oracle, with NaN cells, on rasters smaller and larger than the window."""
+    rng = np.random.default_rng(21)
+    ragged = (rng.random((67, 5)) < 0.5).astype(float)
+    ragged[33, 2] = 1.0
+    masks = {'circle55': circle_kernel(1, 1, 27), 'ragged57': (rng.random((57, 57)) < 0.3).astype(float),
+             'circle63': circle_kernel(1, 1, 31), 'circle75': circle_kernel(1, 1, 37), 'circle101': circle_kernel(1, 1, 50),
+             'ragged67x5': ragged, 'box3x71': np.ones((3, 71))}
+    masks['ragged57'][28, 28] = 1.0
+    for name, k in masks.items():
+        for shape in ((90, 300), (40, 60)):
+            z = synth.smooth_dem(shape, seed=len(name), nan_frac=0.01)
+            with np.errstate(all='ignore'):
+                want = {st: corc.focal_apply(z, k, st, nthreads=8) for st in ('mean', 'max', 'min', 'range', 'std', 'var', 'sum')}
+            got = focal_stats(raster(z), k).data
+            for i, st in enumerate(('mean', 'max', 'min', 'range', 'std', 'var', 'sum')):
+                msg = f"{name} {shape} {st}"
+                if st in ('max', 'min', 'range'):
+                    np.testing.assert_array_equal(got[i], want[st], err_msg=msg)
+                elif st == 'sum':
+                    check_window_sum(got[i], z, k, msg)
+                else:
+                    np.testing.assert_allclose(got[i], want[st], rtol=2e-6, atol=0, equal_nan=True, err_msg=msg)
+            if k.shape[0] == k.shape[1]:
+                w = k / k.sum()
+                z2 = synth.smooth_dem(shape, seed=3)
+                np.testing.assert_allclose(convolve_2d(z2, w), corc.convolve_2d(z2, w, nthreads=8), rtol=2e-6, atol=0,
+                                           equal_nan=True, err_msg=f"{name} {shape} convolve_2d")
+    # device-resident input and a row shard with halos through the any-size kernel
+    k = circle_kernel(1, 1, 37)
+    z = synth.asv_dem(200, 256)
+    want = corc.focal_apply(z, k, 'mean', nthreads=8)
+    got = apply(xs.DataArray(xs.DeviceArray.from_numpy(z), dims=['y', 'x'], attrs={'res': (1, 1)}), k).data.get()
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+
+
 def test_large_window_statistic_subsets():
     """Subsets of the seven statistics on 9x9 .. 25x25 masks run the one-pass walker with only the pass they need
     (walk2_impl.h: extrema only, moments only, both): every subset against the oracle, on clean tiles (fast path), tiles

@@ -436,8 +436,15 @@ def test_sharded_array_bookkeeping(monkeypatch):
     assert ArrayTypeFunctionMapping(numpy_func=1, hip_func=2, sharded_func=3)(agg) == 3
     with pytest.raises(NotImplementedError):
         ArrayTypeFunctionMapping(numpy_func=1, hip_func=2)(agg)
+    # sharded crosstab: both rasters sharded and categorical (round 3); non-integral values or a host-side raster are refused
     with pytest.raises(NotImplementedError):
-        zonal.crosstab(DataArray(ShardedArray.from_numpy(z.astype(np.int32)), dims=['y', 'x']), agg)
+        zonal.crosstab(DataArray(ShardedArray.from_numpy(z.astype(np.int32)), dims=['y', 'x']),
+                       DataArray(ShardedArray.from_numpy(z + np.float32(0.5)), dims=['y', 'x']))
+    with pytest.raises(NotImplementedError):
+        zonal.crosstab(DataArray(ShardedArray.from_numpy(z.astype(np.int32)), dims=['y', 'x']), DataArray(z, dims=['y', 'x']))
+    ct = zonal.crosstab(DataArray(ShardedArray.from_numpy((z.astype(np.int32) // 100)), dims=['y', 'x']),
+                        DataArray(ShardedArray.from_numpy(np.floor(z / 7) % 3), dims=['y', 'x']))
+    assert list(ct['zone']) == [0, 1, 2, 3, 4] and int(ct.drop(columns='zone').to_numpy().sum()) == z.size
     with pytest.raises(TypeError):
         xa.slope(DataArray(solo, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, 40), 'lon': np.linspace(1, 2, 12)}),
                  method='geodesic')

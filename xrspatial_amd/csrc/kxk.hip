@@ -883,13 +883,15 @@ int plan_tile(KxkArgs &a, size_t *lds_bytes) {
     a.pitch = TW + ((2 * rx + 3) & ~3);
     for (int th = 16; th >= 4; th >>= 1) {
         const size_t bytes = ((size_t)(th + a.krows - 1) * a.pitch + 32) * sizeof(float);   // + read slack (<= 5 slots past the last row)
-        if (bytes <= 64 * 1024) {
+        // (CDNA4: 160 KiB of LDS per CU.  Up to 64 KiB several workgroups share a CU; the tiles of 51x51 .. 63x63 windows
+        //  take up to 84 KiB = one workgroup per CU, raised per kernel with hipFuncSetAttribute: allow_big_lds)
+        if (bytes <= 156 * 1024) {
             a.th = th;
             *lds_bytes = bytes;
             return 0;
         }
     }
-    return fail("kernel %dx%d needs more than 64 KiB of LDS per tile (limit ~49x49 this release)", a.krows, a.kcols);
+    return fail("kernel %dx%d needs more than 156 KiB of LDS per tile", a.krows, a.kcols);
 }
 
 int check_common(const char *who, const float *in, long rows, long cols, long ld_in, long ld_out,
@@ -898,7 +900,7 @@ int check_common(const char *who, const float *in, long rows, long cols, long ld
     if (rows < 0 || cols < 0 || ld_in < cols || ld_out < cols) return fail("%s: bad shape", who);
     if (!kernel || krows <= 0 || kcols <= 0 || !(krows & 1) || !(kcols & 1))
         return fail("%s: kernel must be odd x odd, got %dx%d", who, krows, kcols);
-    if (krows > MAX_K || kcols > MAX_K) return fail("%s: kernel larger than %d", who, MAX_K);
+    // (windows beyond MAX_K in either direction: kxk_big.hip -- the callers test for that right after this check)
     if (ht < 0 || hb < 0) return fail("%s: negative halo", who);
     return 0;
 }
@@ -910,9 +912,23 @@ bool vec_ok(const KxkArgs &a, unsigned out_mask) {
     return v;
 }
 
+// dynamic LDS beyond 64 KiB has to be allowed per kernel (once per thread and kernel: the call synchronises)
+template <typename K>
+int allow_big_lds(K kernel_fn, size_t lds) {
+    if (lds <= 64 * 1024) return 0;
+    static thread_local bool done = false;                    // (one instance per kernel type K... and per function pointer value:
+    static thread_local const void *done_for = nullptr;       //  instantiations of one template share K, so remember the pointer)
+    const void *fn = reinterpret_cast<const void *>(kernel_fn);
+    if (done && done_for == fn) return 0;
+    XRS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    done = true; done_for = fn;
+    return 0;
+}
+
 template <int KH, int KW, int MODE>
 int launch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
     const unsigned grid = (unsigned)xcd_grid(a.n_tiles, XCD_UNIT(XRS_XCD_LDS, a.tiles_x));
+    if (int rc = vec ? allow_big_lds(&focal_stats_kernel<KH, KW, MODE, true>, lds) : allow_big_lds(&focal_stats_kernel<KH, KW, MODE, false>, lds)) return rc;
     if (vec)
         hipLaunchKernelGGL((focal_stats_kernel<KH, KW, MODE, true>), dim3(grid), dim3(256), lds, s, a);
     else
@@ -1043,6 +1059,11 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
                               halo_top, halo_bot)) return rc;
     if (!out_dev || !work_dev) return fail("xrs_convolve2d_f32: null output/workspace");
     if (rows == 0 || cols == 0) return 0;
+    if (krows > MAX_K || kcols > MAX_K) {
+        float *outs1[1] = {out_dev};
+        return launch_window_any_size(true, in_dev, outs1, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev, halo_top,
+                                      halo_bot, as_stream(stream));
+    }
     KxkArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in_dev; a.out[0] = out_dev;
@@ -1075,6 +1096,7 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     const bool vec = vec_ok(a, 1u);
 #define XRS_CONV(KH, KW)                                                                              \
     do {                                                                                              \
+        if (int rc_ = vec ? allow_big_lds(&convolve_kernel<KH, KW, true>, lds) : allow_big_lds(&convolve_kernel<KH, KW, false>, lds)) return rc_; \
         if (vec) hipLaunchKernelGGL((convolve_kernel<KH, KW, true>), dim3(grid), dim3(256), lds, s, a);  \
         else hipLaunchKernelGGL((convolve_kernel<KH, KW, false>), dim3(grid), dim3(256), lds, s, a);     \
     } while (0)
@@ -1107,6 +1129,9 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     }
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = as_stream(stream);
+    if (krows > MAX_K || kcols > MAX_K)
+        return launch_window_any_size(false, in_dev, a.out, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev, halo_top,
+                                      halo_bot, s);
     // Large circles / boxes (the walkers of wide_impl.h / walk2_impl.h).  XRS_FOCAL_GEN=1 keeps the first-generation
     // column walkers (A/B runs); XRS_FOCAL_SUM=sequential keeps `sum` on the kernel that adds the taps in the
     // reference's order in float32 (bit-exact with numba's nansum) instead of rounding the exact sum once.

@@ -275,6 +275,11 @@ int try_launch_focal_box2_mom(const float *in, float *out_sum, float *out_max, f
                           float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
                           const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 
+// kxk_big.hip: focal statistics / convolve_2d for windows beyond the tiled kernels' 63 x 63 (one thread per cell, window from
+// global memory, mask / weights from a device copy of the kernel in `work_dev`)
+int launch_window_any_size(bool conv, const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,
+                           const double *kernel, int krows, int kcols, void *work_dev, int halo_top, int halo_bot,
+                           hipStream_t s);
 // pass.hip: is this mask one of the compile-time masks of raster_pass_kernel (circle_kernel(1, 1, 2), np.ones((3, 3)))?
 bool pass_has_compile_time_mask(const double *kernel, int krows, int kcols);
 // kxk_ext_circle.hip / kxk_ext_box.hip (ext_impl.h): max / min / range, radius 4..12 cells, two input rows per step.

@@ -64,8 +64,11 @@ def _focal_stats_hip(data, kernel, stats, stacked=None):
         ptrs[_STAT_INDEX[s]] = arr.ptr
         mask |= 1 << _STAT_INDEX[s]
     stream = get_stream()
+    work = _window_workspace(k)
     _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, ld, ld, k.ctypes.data,
-              k.shape[0], k.shape[1], None, 0, 0, stream)
+              k.shape[0], k.shape[1], work.ptr if work is not None else None, 0, 0, stream)
+    if work is not None:
+        _lib.call("xrs_stream_sync", stream)          # (the workspace must outlive the launch)
     if like_numpy:
         return {s: arr.get(stream) for s, arr in outs.items()}
     return outs
@@ -86,9 +89,18 @@ def _focal_stats_banded(host, kernel, stats):
         for s, ptr in zip(stats, out_ptrs):
             ptrs[_STAT_INDEX[s]] = ptr
         _lib.call("xrs_focal_stats_f32", in_ptr, ptrs, mask, n_rows, cols, cols, cols, k.ctypes.data, k.shape[0],
-                  k.shape[1], None, ht, hb, stream)
+                  k.shape[1], work.ptr if work is not None else None, ht, hb, stream)
 
+    work = _window_workspace(k)      # (alive until pipelined_rows has drained its streams)
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
+
+
+def _window_workspace(k):
+    """Device workspace for windows beyond the tiled kernels' 63 x 63 (csrc/kxk_big.hip reads the mask from a device copy
+    of the kernel); None for everything smaller.  The caller keeps it alive until the launch has been synchronised."""
+    if max(k.shape) <= 63:
+        return None
+    return DeviceArray((int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])),), np.uint8)
 
 
 def _apply_sharded(data, kernel, stat):
@@ -102,8 +114,11 @@ def _apply_sharded(data, kernel, stat):
     out = src.like(np.float32)
     ptrs = (ctypes.c_void_p * 7)()
     ptrs[_STAT_INDEX[stat]] = out.ptr
+    work = _window_workspace(k)
     _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k.ctypes.data,
-              k.shape[0], k.shape[1], None, ht, hb, stream)
+              k.shape[0], k.shape[1], work.ptr if work is not None else None, ht, hb, stream)
+    if work is not None:
+        _lib.call("xrs_stream_sync", stream)
     return out
 
 
@@ -121,8 +136,11 @@ def _focal_stats_sharded(data, kernel, stats):
     for s, arr in outs.items():
         ptrs[_STAT_INDEX[s]] = arr.ptr
         mask |= 1 << _STAT_INDEX[s]
+    work = _window_workspace(k)
     _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, cols, cols, k.ctypes.data, k.shape[0], k.shape[1],
-              None, ht, hb, stream)
+              work.ptr if work is not None else None, ht, hb, stream)
+    if work is not None:
+        _lib.call("xrs_stream_sync", stream)
     return outs
 
 

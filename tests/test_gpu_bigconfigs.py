@@ -196,7 +196,9 @@ def test_s32_zonal_stats_1000_zones(vals32k, kind):
     df = xs.zonal_stats(xs.DataArray(zones, dims=['y', 'x']), xs.DataArray(vals32k.dev, dims=['y', 'x']), stats_funcs=names)
     ids, cnt, sm, sq, mn, mx = _host_zonal(kind, vals32k.partials, n, n)
     assert len(ids) == 1000 and df['zone'].tolist() == ids.tolist()
-    cfg = f"C5 zonal.stats 32768^2, 1000 int32 zones ({kind})"
+    # (the comparison is against an EXACT float64 host reduction of the same raster, not against the oracle's float32
+    #  pairwise NumPy semantics -- zonal.py:144-163 -- which sit ~1e-6 from it by construction)
+    cfg = f"C5 zonal.stats 32768^2, 1000 int32 zones ({kind}), vs an exact float64 host reduction"
     np.testing.assert_array_equal(df['count'].to_numpy().astype(np.int64), cnt)          # bit-exact integer counts
     assert int(cnt.sum()) == int(np.isfinite(vals32k.base).sum()) * (n // PERIOD)
     np.testing.assert_array_equal(df['min'].to_numpy().astype(np.float32), mn)

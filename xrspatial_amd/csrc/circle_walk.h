@@ -102,15 +102,45 @@ __device__ __forceinline__ void ring_rotate(float (&a)[K][N]) {                /
 // whole launch waits for it (measured on the 25x25 moments kernel: 1.85 ms -> see DESIGN.md), and the top row delays
 // another.  Dealt out first, round-robin over the XCDs, they are spread evenly and their tails hide behind interior work.
 // (gy, gx) of workgroup `block` in a gw x gh grid of workgroup tiles; false for the surplus blocks of the padded grid.
-// Output rows per tile of the third-generation walkers.  Every tile pays 2R rows of run-in before its first output row:
-// 128-row tiles walk 1.19 input rows per output row at radius 12, 256-row tiles 1.09 -- but a raster must be tall enough
-// to still give every CU several tiles.  XRS_WALK_TILE_ROWS overrides (A/B runs).
-inline int walk3_tile_base(long rows, int radius) {
+// Output rows per tile of the third-generation walkers.  Every tile pays 2R rows of run-in before its first output row
+// (128-row tiles walk 1.19 input rows per output row at radius 12, 256-row tiles 1.09), but the launch also has to come
+// out in whole ROUNDS of resident workgroups: 4096 workgroups on 768 slots are 5.3 rounds and cost 6.  Chosen per launch:
+// the tile height whose (rounds x input rows per tile) is smallest, for `groups_x` workgroups per tile row, `wg_per_cu`
+// resident workgroups per CU and rounds of `u` rows.  Measured on 16384^2, radius 12 (profiles/r03): moments 1.65 ms with
+// 128-row tiles, 1.36 with 256, 2.2 with 384.  XRS_WALK_TILE_ROWS overrides (A/B runs).
+// resident 256-thread workgroups per CU of a kernel, as the runtime computes it from the kernel's registers and LDS
+template <typename K>
+inline int walk3_wg_per_cu(K kernel_fn, int fallback) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel_fn, 256, 0) != hipSuccess || n < 1) return fallback;
+    return n;
+}
+
+inline int walk3_tile_base(long rows, long groups_x, int radius, int u, int wg_per_cu) {
     const char *e = getenv("XRS_WALK_TILE_ROWS");
     if (e && atoi(e) >= 16) return atoi(e);
-    // measured on 16384^2 (profiles/r03): radius 12 moments 1.65 ms with 128-row tiles, 1.36 with 256, 2.2 with 384 (too
-    // few workgroups per CU); radius 6 is faster with 128 (its lighter kernels run 3 workgroups per CU)
-    return rows >= 8192 && radius >= 10 ? 256 : 128;
+    static thread_local int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    // (radius < 10, or a raster too short to fill the chip several times: 128 -- the lighter kernels of small windows are
+    //  bound by HBM, not by rounds, and measured 10-15 % slower on 256-row tiles: box 11x11 seven statistics 2.39 vs 2.75 ms)
+    if (radius < 10 || rows < 8192) return 128;
+    const long slots = (long)n_cu * wg_per_cu;
+    int best = 256;
+    double best_cost = 1e300;
+    for (int base = 192; base <= 320; base += 32) {
+        const long nin = ((base + 2 * radius + u - 1) / u) * u, wth = nin - 2 * radius;
+        const long tiles_y = (rows + wth - 1) / wth;
+        const long rounds = (groups_x * tiles_y + slots - 1) / slots;
+        // (a partly filled last round still costs a round: its workgroups run alone on their CUs, not faster)
+        const double cost = (double)rounds * (double)nin;
+        if (cost < best_cost) { best_cost = cost; best = base; }
+    }
+    return best;
 }
 
 struct RimFirst {

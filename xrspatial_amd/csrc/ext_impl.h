@@ -256,7 +256,9 @@ int launch_ext(ExtArgs &a, const double *kernel, hipStream_t s) {
     if (!is_shape<R, Shape>(kernel)) return -1;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + 255) / 256;
-    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
+    if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_ext_kernel<R, Shape, 3>, XRS_EXT_WAVES);
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, g.tiles_x, R, C::U, wg_per_cu)) - 2 * R;
     g.n_tiles = g.tiles_x * ((g.rows + a.tile_rows - 1) / a.tile_rows);
     a.rim_first = RimFirst::mode_from_env();
     const long grid = RimFirst(g.tiles_x, g.n_tiles / g.tiles_x, a.rim_first).grid();

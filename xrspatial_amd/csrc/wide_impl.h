@@ -427,7 +427,9 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     using C = WideCfg<R, Shape>;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
-    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
+    if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_wide_kernel<R, Shape, WIDE_MEAN>, XRS_WIDE_WAVES);
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::U, wg_per_cu)) - 2 * R;
     const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
@@ -454,7 +456,9 @@ int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double
     if (!is_uniform_shape<R, Shape>(kernel, &a.wgt)) return -1;
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
-    a.tile_rows = C::nin(walk3_tile_base(g.rows, R)) - 2 * R;
+    static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
+    if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_wide_kernel<R, Shape, WIDE_MEAN>, XRS_WIDE_WAVES);
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::U, wg_per_cu)) - 2 * R;
     const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;

@@ -439,7 +439,13 @@ def test_third_generation_walkers_interior_and_rim_tiles():
         holes[260, 200] = np.inf
         holes[170, 650] = -np.inf
         holes[220:220 + 3 * K, 30:30 + 3 * K] = 1234.5
-        cases = {'steep': steep, 'asv': synth.asv_dem(*shape), 'holes': holes,
+        # a nodata region with a ragged boundary (windows with 1, 2, 3, ... valid cells along it) plus scattered NaN cells:
+        # the NaN-aware float32 walker (MomWalkN), and behind it the exact walker's wave-wide window recomputation
+        nodata = synth.asv_dem(*shape).copy()
+        edge = shape[1] // 3 + (np.arange(shape[0]) // 7) % 5
+        nodata[np.arange(shape[1])[None, :] < edge[:, None]] = np.nan
+        nodata[rng.random(shape) < 0.002] = np.nan
+        cases = {'steep': steep, 'asv': synth.asv_dem(*shape), 'holes': holes, 'nodata': nodata,
                  'zero-mean': rng.normal(0, 3, shape).astype(np.float32)}
         for name, z in cases.items():
             with np.errstate(all='ignore'):

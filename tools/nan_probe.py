@@ -29,6 +29,8 @@ for label, frac, block in (("clean", 0.0, False), ("scattered 0.1%", 0.001, Fals
 
     cases = {"hillshade": lambda: xs.hillshade(A), "focal5_mean": lambda: focal.apply(A, k5), "fused hill+focal5": fused,
              "focal5_stats7": lambda: focal.focal_stats(A, k5), "focal25_mean": lambda: focal.apply(A, k25),
+             "focal25_stats7": lambda: focal.focal_stats(A, k25), "focal25_mean_var_std": lambda: focal.focal_stats(A, k25, stats_funcs=['mean', 'var', 'std']),
+             "focal25_max_min_range": lambda: focal.focal_stats(A, k25, stats_funcs=['max', 'min', 'range']),
              "convolve5": lambda: xs.convolution.convolve_2d(dev, k5 / k5.sum()), "focal.mean": lambda: focal.mean(A)}
     for name, fn in cases.items():
         med, mn = t.time(lambda: (fn(), None)[1], 5, warmup=2)

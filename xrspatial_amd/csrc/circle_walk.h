@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <rocprim/warp/warp_reduce.hpp>
 #include <type_traits>
 
 namespace xrs {
@@ -321,6 +322,46 @@ __device__ __forceinline__ double walk_rcp(int n) {
     return n ? r : nan("");
 }
 
+// One window by the reference's two passes (focal.py _calc_mean / _calc_var: the mean, then the squared deviations from
+// it; NaN cells skipped), computed by the WHOLE wave: lane l takes taps l, l + 64, ... of the (2R+1)^2 square, float64
+// partial sums meet in a wave reduction.  (A lane looping over its own window alone is 2 * ntaps dependent loads -- about
+// 0.2 ms per output for 25x25, which one nodata boundary turned into a 30 ms kernel.)  Flat windows stay exact: every
+// partial sum of m <= 2^10 equal float32 values is exact in float64, so the mean is the value and every deviation 0.
+template <int R, typename Shape>
+__device__ __forceinline__ void walk_exact_window(const WalkGeom &g, long yo, long xs, int lane, double &mean, double &var) {
+    constexpr int K = 2 * R + 1, NT = K * K, IT = (NT + 63) / 64;
+    const long y_lo = -(long)g.halo_top, y_hi = g.rows + g.halo_bot;
+    auto tap = [&](int i) -> float {                       // NaN: not under the mask / outside the raster
+        const int idx = lane + 64 * i;
+        const int ky = idx / K, kx = idx - ky * K;
+        const int dy = ky < R ? R - ky : ky - R, dx = kx < R ? R - kx : kx - R;
+        const long yr = yo - R + ky, xr = xs - R + kx;
+        const bool ok = idx < NT && dx <= Shape::hw(R, dy) && yr >= y_lo && yr < y_hi && xr >= 0 && xr < g.cols;
+        return ok ? g.in[yr * g.ld_in + xr] : nan_f32();
+    };
+    rocprim::warp_reduce<double, 64>::storage_type st;
+    double s = 0.0, m = 0.0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const float v = tap(i);
+        if (!isnan(v)) { s += (double)v; m += 1.0; }
+    }
+    rocprim::warp_reduce<double, 64>().reduce(s, s, st);
+    rocprim::warp_reduce<double, 64>().reduce(m, m, st);
+    s = __shfl(s, 0);
+    m = __shfl(m, 0);
+    mean = m > 0.0 ? s / m : nan("");                      // true division: a flat window must give its value exactly
+    double dev = 0.0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const float v = tap(i);
+        if (!isnan(v)) { const double d = (double)v - mean; dev = fma(d, d, dev); }
+    }
+    rocprim::warp_reduce<double, 64>().reduce(dev, dev, st);
+    dev = __shfl(dev, 0);
+    var = m > 0.0 ? dev / m : nan("");
+}
+
 template <int R, typename Shape, bool WANT_VAR = true>       // WANT_VAR = false: mean only (no squares, no guard)
 struct WalkF64 {
     static constexpr int K = 2 * R + 1;
@@ -336,10 +377,12 @@ struct WalkF64 {
         amax = 0.0f;
         cf = 0.0f;
         const long yc = (y0 + CTH / 2 < g.rows ? y0 + CTH / 2 : g.rows - 1);
-        if (x < g.cols) {
-            const float c0 = g.in[yc * g.ld_in + x];
-            if (isfinite(c0)) cf = c0;
-        }
+        float c0 = nan_f32();
+        if (x < g.cols) c0 = g.in[yc * g.ld_in + x];
+        // (a lane on nodata borrows a neighbour's value: a shift of 0 would make `amax` -- the guard's scale -- the data's level)
+        const unsigned long long have = __ballot(isfinite(c0));
+        const float c_any = __shfl(c0, have ? __ffsll((long long)have) - 1 : 0);
+        cf = isfinite(c0) ? c0 : have ? c_any : 0.0f;
     }
 
     __device__ __forceinline__ void row(const float (&v)[K]) {
@@ -372,10 +415,10 @@ struct WalkF64 {
         }
     }
 
-    // completed output row yo (slot 2R), column x
-    __device__ __forceinline__ void emit(const WalkGeom &g, long yo, long x, float *out_mean, float *out_var,
+    // completed output row yo (slot 2R), column x.  Returns true WITHOUT storing when the window is ill-conditioned or
+    // exactly flat (or holds +-inf): the caller recomputes it with `walk_exact_window`.
+    __device__ __forceinline__ bool emit(const WalkGeom &g, long yo, long x, float *out_mean, float *out_var,
                                          float *out_std) const {
-        const long y_lo = -(long)g.halo_top, y_hi = g.rows + g.halo_bot;
         const double shift = (double)cf;
         const int n = cn[2 * R];
         const double inv = walk_rcp(n);
@@ -383,47 +426,20 @@ struct WalkF64 {
         if (!WANT_VAR) {
             // mean only: c + S/n needs no guard (a +-inf under the window gives +-inf / NaN like the reference's sum)
             if (out_mean) out_mean[yo * g.ld_out + x] = (float)(shift + ms);
-            return;
+            return false;
         }
         const double ssd = sq[WANT_VAR ? 2 * R : 0] - sd[2 * R] * ms;
-        double mean = shift + ms;
+        const double mean = shift + ms;
         double var = (ssd > 0.0 ? ssd : 0.0) * inv;
         // rounding noise of Q and S^2/n is ~ ntaps * eps * max(d^2); 1e6 of headroom as in kxk_runs.hip
         const double guard = 1e-9 * (double)shape_taps<Shape>(R) * ((double)amax * (double)amax);
-        if (n != 0 && !(ssd >= guard)) {
-            // ill-conditioned / exactly flat window, or +-inf under it: the reference's two-pass loops
-            double s = 0.0;
-            int m = 0;
-            for (int ky = 0; ky < K; ++ky) {
-                const long yr = yo - R + ky;
-                if (yr < y_lo || yr >= y_hi) continue;
-                const int h = Shape::hw(R, ky < R ? R - ky : ky - R);
-                for (int kx = R - h; kx <= R + h; ++kx) {
-                    const long xr = x - R + kx;
-                    if (xr < 0 || xr >= g.cols) continue;
-                    const float val = g.in[yr * g.ld_in + xr];
-                    if (!isnan(val)) { s += (double)val; ++m; }
-                }
-            }
-            mean = m ? s / (double)m : nan("");          // true division: a flat window must give its value exactly
-            double dev = 0.0;
-            for (int ky = 0; ky < K; ++ky) {
-                const long yr = yo - R + ky;
-                if (yr < y_lo || yr >= y_hi) continue;
-                const int h = Shape::hw(R, ky < R ? R - ky : ky - R);
-                for (int kx = R - h; kx <= R + h; ++kx) {
-                    const long xr = x - R + kx;
-                    if (xr < 0 || xr >= g.cols) continue;
-                    const float val = g.in[yr * g.ld_in + xr];
-                    if (!isnan(val)) { const double d = (double)val - mean; dev += d * d; }
-                }
-            }
-            var = m ? dev / (double)m : nan("");
-        }
+        if (n == 1 && ssd == ssd) var = 0.0;                             // one valid (finite) cell: its value, variance 0
+        else if (n != 0 && !(ssd >= guard)) return true;
         const long off = yo * g.ld_out + x;
         if (out_mean) out_mean[off] = (float)mean;
         if (out_var) out_var[off] = (float)var;
         if (out_std) out_std[off] = (float)sqrt(var);
+        return false;
     }
 
     __device__ __forceinline__ void shift() {
@@ -589,9 +605,25 @@ __device__ __forceinline__ void walk_columns(const WalkGeom &g, const WalkOuts &
             if (F32) a32.row(v);
             if (F64) a64.row(v);
             const long yo = yy - R;                     // the output row that is now complete
+            bool redo = false;
             if (yo >= y0 && (!EDGE || x < g.cols)) {
                 if (F32) a32.emit(yo * g.ld_out + x, o.sum, o.max, o.min, o.range);
-                if (F64) a64.emit(g, yo, x, o.mean, o.var, o.std);
+                if (F64) redo = a64.emit(g, yo, x, o.mean, o.var, o.std);
+            }
+            if (F64 && WANT_VAR) {
+                unsigned long long todo = __ballot(redo);               // (every lane of the wave is here)
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    double mean, var;
+                    walk_exact_window<R, Shape>(g, yo, xw + src, lane, mean, var);
+                    if (lane == src) {
+                        const long off = yo * g.ld_out + x;
+                        if (o.mean) o.mean[off] = (float)mean;
+                        if (o.var) o.var[off] = (float)var;
+                        if (o.std) o.std[off] = (float)sqrt(var);
+                    }
+                }
             }
             if (F32) a32.shift();
             if (F64) a64.shift();

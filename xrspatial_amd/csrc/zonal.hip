@@ -124,8 +124,8 @@ struct Acc {
 // NT threads per workgroup: 256, or 1024 when the zone table leaves room for only ONE workgroup per CU (more than 64 KiB of
 // LDS: 2 300+ zones) -- 16 waves then share the table instead of 4 (5 000 zones: 1.51 -> 1.36 ms; the rest is the flush of every workgroup's table with device atomics)
 // (1024-thread workgroups: 8 waves per SIMD = 64 registers, so that TWO workgroups fit a CU when their tables do)
-template <typename VT, bool LDS, bool VEC, int NT = 256>
-__global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zonal_kernel(const ZonalArgs<VT> a) {
+template <typename VT, bool LDS, bool VEC, int NT = 256, int SLOTS = (NT == 1024 ? 2 : 4)>
+__global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 2 ? 8 : 1) zonal_kernel(const ZonalArgs<VT> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Acc<VT, LDS> acc;
     if (LDS) {
@@ -151,8 +151,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zon
     // of a real zone raster touches few zones, so the LDS flush at the end is short.
     const long n_chunks = gridDim.x;                                           // a multiple of 8
     const long my_chunk = ((long)blockIdx.x & 7) * (n_chunks >> 3) + ((long)blockIdx.x >> 3);
-    constexpr int U = NT == 1024 ? 2 : 4;   // 16-byte slots per lane per trip, 64 slots apart (1024-thread workgroups: 2, so
-                                            // that both the one-zone path and the row path fit the 64 registers of 8 waves per SIMD)
+    constexpr int U = SLOTS;                // 16-byte slots per lane per trip, 64 slots apart (1024-thread workgroups: 2, so
+                                            // that both the one-zone path and the row path fit the 64 registers of 8 waves per
+                                            // SIMD; 4 when the table leaves room for one workgroup per CU anyway: 128 registers)
     constexpr long TRIP = (long)NT * U;                                        // 16-byte slots of one workgroup trip
     const long per_chunk = (((n4 + n_chunks - 1) / n_chunks + TRIP - 1) / TRIP) * TRIP;
     const long c_begin = my_chunk * per_chunk;
@@ -189,22 +190,22 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zon
             }
         }
         // ---- the whole trip in ONE zone (the common case of spatially coherent zones): every lane folds its 4 U cells, one
-        // set of wave64 reductions, one lane touches the accumulators
-        Part<VT> p; p.z = -1; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
-        bool lane_single = true;       // all valid cells of this lane fell into p.z
+        // set of wave64 reductions, one lane touches the accumulators.  (Tested on the zone indices before any arithmetic:
+        // rasters whose zones are narrower than a trip pay ~10 instructions for the test, not the fold.)
+        bool lane_same = true;
 #pragma unroll
-        for (int k = 0; k < 4 * U; ++k) {
-            if (!cell_ok(a, z[k], v[k])) continue;
-            lane_single = lane_single && (p.z < 0 || p.z == z[k]);
-            p.z = z[k];
-            const double d = (double)v[k] - a.shift;
-            p.c += 1; p.s += d; p.q += d * d;
-            p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
-        }
-        const unsigned long long have = __ballot(p.z >= 0);
-        if (!have) continue;
-        const int z0 = __shfl(p.z, __ffsll((long long)have) - 1);
-        if (__all(lane_single && (p.z < 0 || p.z == z0))) {
+        for (int k = 1; k < 4 * U; ++k) lane_same = lane_same && z[k] == z[0];
+        const int z0 = __builtin_amdgcn_readfirstlane(z[0]);
+        if (__all(lane_same && z[0] == z0)) {
+            if (z0 < 0 || z0 >= a.nz) continue;                                  // (wave-uniform: no zone under the trip)
+            Part<VT> p; p.z = z0; p.c = 0; p.s = 0.0; p.q = 0.0; p.mn = INFINITY; p.mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4 * U; ++k) {
+                if (!cell_ok(a, z[k], v[k])) continue;
+                const double d = (double)v[k] - a.shift;
+                p.c += 1; p.s += d; p.q += d * d;
+                p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
+            }
             // wave64 reductions with DPP cross-lane moves (VALU only: the LDS pipe stays free for the atomics)
             rocprim::warp_reduce<unsigned, 64>::storage_type su;
             rocprim::warp_reduce<double, 64>::storage_type sd;
@@ -214,9 +215,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zon
             rocprim::warp_reduce<double, 64>().reduce(p.q, p.q, sd);
             rocprim::warp_reduce<VT, 64>().reduce(p.mn, p.mn, sv, rocprim::minimum<VT>());
             rocprim::warp_reduce<VT, 64>().reduce(p.mx, p.mx, sv, rocprim::maximum<VT>());
-            if ((threadIdx.x & 63) == 0) { p.z = z0; acc.add(p); }
+            if ((threadIdx.x & 63) == 0 && p.c) acc.add(p);
             continue;
         }
+        Part<VT> p;
         // ---- several zones under the wave.  Slot by slot (a slot = 64 consecutive 16-byte groups = 256 cells in lane
         // order): the lane's 4 cells folded into one partial (a zone boundary that cuts through them -- rare -- sends those
         // cells to the accumulators one by one), then the lanes are reduced in ROWS OF 16 (64 cells) wherever a row lies
@@ -244,18 +246,16 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 ? 8 : 1) zon
             }
             // (finely scattered zones -- more runs of equal zones than rows under the slot -- skip the row test)
             const int z_prev = __shfl_up(p.z, 1);
-            if (__popcll(__ballot((threadIdx.x & 63) == 0 || z_prev != p.z)) > 8) {
+            const unsigned long long starts = __ballot((threadIdx.x & 63) == 0 || z_prev != p.z);
+            if (__popcll(starts) > 8) {
                 if (p.z >= 0) acc.add(p);
                 continue;
             }
-            rocprim::warp_reduce<int, 16>::storage_type si;
-            int zlo, zhi;
-            rocprim::warp_reduce<int, 16>().reduce(p.z, zlo, si, rocprim::minimum<int>());
-            rocprim::warp_reduce<int, 16>().reduce(p.z, zhi, si, rocprim::maximum<int>());
-            // (the reduced value is valid in the row's first lane: broadcast it to the row)
-            zlo = __shfl(zlo, (int)(threadIdx.x & 48), 64);
-            zhi = __shfl(zhi, (int)(threadIdx.x & 48), 64);
-            const bool row_one_zone = zlo == zhi && zlo >= 0;
+            // a row of 16 lanes lies in one zone: no run starts inside it (scalar masks, no cross-lane traffic) and its
+            // first lane holds a valid partial
+            const unsigned long long empty = __ballot(p.z < 0);
+            const unsigned row_bits = (unsigned)(starts >> (threadIdx.x & 48)), row_empty = (unsigned)(empty >> (threadIdx.x & 48));
+            const bool row_one_zone = (row_bits & 0xfffeu) == 0 && !(row_empty & 1u);
             if (__any(row_one_zone)) {
                 Part<VT> r = p;
                 rocprim::warp_reduce<unsigned, 16>::storage_type su;
@@ -372,7 +372,7 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
         if (nt == 1024) {
             // once per process and device (idempotent; a race only repeats the call).  Round 3: issued on EVERY call it cost
             // ~1 ms of the 1.37 ms a 5000-zone reduction of a 16384^2 raster took -- the call synchronises.
-            static thread_local unsigned long long attr_done = 0;          // bit d: device d
+            static thread_local unsigned long long attr_done = 0, attr_big = 0;          // bit d: device d
             int dev = 0;
             XRS_HIP(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !(attr_done >> dev & 1)) {
@@ -382,7 +382,15 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
                 if (dev >= 0 && dev < 64) attr_done |= 1ull << dev;
             }
-            if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
+            static const int big_slots = getenv("XRS_ZONAL_BIG_SLOTS") ? atoi(getenv("XRS_ZONAL_BIG_SLOTS")) : 4;
+            if (big && vec && big_slots == 4) {
+                if (dev < 0 || dev >= 64 || !(attr_big >> dev & 1)) {
+                    XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true, 1024, 4>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+                    if (dev >= 0 && dev < 64) attr_big |= 1ull << dev;
+                }
+                hipLaunchKernelGGL((zonal_kernel<VT, true, true, 1024, 4>), dim3((unsigned)grid), dim3(1024), smem, s, a);
+            } else if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
             else hipLaunchKernelGGL((zonal_kernel<VT, true, false, 1024>), dim3((unsigned)grid), dim3(1024), smem, s, a);
         } else {
             if (vec) hipLaunchKernelGGL((zonal_kernel<VT, true, true>), dim3((unsigned)grid), dim3(256), smem, s, a);

@@ -580,6 +580,45 @@ inline bool is_uniform_shape(const double *kernel, double *weight) {
     return true;
 }
 
+// Nodata regions: is EVERY cell a wave's tile can see NaN (raster columns [x_lo, x_hi), rows [y_lo, y_hi), clipped to the
+// raster and the shard's halo rows -- cells outside count as NaN, as every walker treats them)?  Stops at the first row
+// with a valid cell, so a tile with data costs one row; a tile inside a nodata region costs one pass over cells the
+// fast walker just brought into L2, and then needs no walk at all (the exact walkers are 5-10x slower than the fast ones,
+// and a raster with an ocean has many such tiles).
+__device__ __forceinline__ bool walk_tile_all_nan(const WalkGeom &g, long x_lo, long x_hi, long y_lo, long y_hi, int lane) {
+    x_lo = x_lo < 0 ? 0 : x_lo;
+    x_hi = x_hi > g.cols ? g.cols : x_hi;
+    y_lo = y_lo < -(long)g.halo_top ? -(long)g.halo_top : y_lo;
+    y_hi = y_hi > g.rows + g.halo_bot ? g.rows + g.halo_bot : y_hi;
+    // (the first row alone, then 8 rows per verdict: one row per verdict is one memory latency per row, ~0.15 ms a tile)
+    for (long y = y_lo, step = 1; y < y_hi; y += step, step = 8) {
+        bool valid = false;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r >= step || y + r >= y_hi) break;
+            const float *p = g.in + (y + r) * g.ld_in;
+            for (long x = x_lo + lane; x < x_hi; x += 64) { const float v = p[x]; valid = valid || v == v; }
+        }
+        if (__any(valid)) return false;
+    }
+    return true;
+}
+
+// ... and its results: no valid cell under any window (focal.py:268-302: nanmean / nanvar / nanstd / nanmax / nanmin of an
+// all-NaN window are NaN, nansum is 0).  `fill_sum`: the value for the sum plane (convolve_2d: NaN).
+__device__ __forceinline__ void walk_fill_no_data(const WalkGeom &g, float *const *planes, int n_planes, float *sum_plane,
+                                                  float fill_sum, long x_lo, long x_hi, long y0, long y_end, int lane) {
+    x_hi = x_hi > g.cols ? g.cols : x_hi;
+    const float qnan = nan_f32();
+    for (long y = y0; y < y_end; ++y) {
+        for (long x = x_lo + lane; x < x_hi; x += 64) {
+            const long off = y * g.ld_out + x;
+            for (int i = 0; i < n_planes; ++i) if (planes[i]) planes[i][off] = qnan;
+            if (sum_plane) sum_plane[off] = fill_sum;
+        }
+    }
+}
+
 struct WalkOuts {
     float *sum, *max, *min, *range, *mean, *var, *std;      // any may be NULL
 };

@@ -403,6 +403,9 @@ struct MomWalk {
         };
         (one(std::integral_constant<int, J>{}), ...);
         c = c_next;
+#ifndef XRS_MOM_T_NONANSTOP
+        badm |= __builtin_amdgcn_ballot_w64(c != c);             // a NaN under the round's runs: stop now, not 2R rows later
+#endif
         dq_old = fmaxf(dq_last * C::HIST_FIRST, dq_old * C::HIST_DECAY);
         dq_last = d * d;
         dqn = (float)C::NTAPS * fmaxf(dq_last, dq_old);
@@ -699,8 +702,20 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
 #ifdef XRS_MOM_NO_FALLBACK
     return;
 #endif
-    // rim tiles, and tiles whose fast walk met a non-finite sum or failed its guard: the NaN-aware float32 walker, 64 columns
-    // at a time; what fails THAT guard (+-inf, ill-conditioned windows) goes to the exact float64 walker
+    // the fast walk met a non-finite sum or failed its guard.  Inside a nodata region: nothing to walk
+#ifndef XRS_MOM_T_NOALLNAN
+    if (walk_tile_all_nan(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
+        float *const planes[3] = {a.out_mean, a.out_var, a.out_std};
+        walk_fill_no_data(g, planes, 3, a.out_sum, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
+        return;
+    }
+#endif
+    // otherwise the NaN-aware float32 walker, 64 columns at a time; what fails THAT guard (+-inf, windows with a few valid
+    // cells at the edge of a nodata region, ill-conditioned sums) goes to the exact float64 walker.
+    // (Tried: the four waves of the workgroup sharing those exact walks behind a barrier -- a nodata boundary leaves one
+    // slow tile per tile row, ~0.8 ms of kernel tail.  It shortened that raster's time by 7 % and cost EVERY raster 5 %:
+    // the changed control flow pushed scalar registers of the interior loop into VGPR lanes, 48-56 v_readlane per round
+    // instead of 8.  A kernel argument read only by the NaN-aware walker did the same.  tools/readlanes.sh counts them.)
     for (int q = 0; q < C::NC; ++q) {
         if (x_tile + 64 * q >= g.cols) break;
 #ifndef XRS_MOM_NO_NANWALK

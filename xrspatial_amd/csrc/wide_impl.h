@@ -407,6 +407,12 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
     }
     if (ok || XRS_WIDE_NO_FALLBACK) return;
     constexpr bool SUM = MODE == WIDE_SUM;
+    // inside a nodata region (every cell the tile sees is NaN): mean NaN, sum 0, convolution NaN -- nothing to walk
+    if (walk_tile_all_nan(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
+        float *const planes[1] = {SUM ? nullptr : a.out};
+        walk_fill_no_data(g, planes, 1, SUM ? a.out : nullptr, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
+        return;
+    }
     if (MODE == WIDE_CONV) {
         // a non-finite cell in reach, or sums too ill-conditioned for float32: the float64 conv walker (tap by tap, in the
         // reference's order, where a window holds a non-finite cell)

@@ -1283,7 +1283,10 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
             if big and stat in ('mean', 'std', 'var', 'sum'):
                 # the walkers sum values shifted by a cell at the centre of the wave's TILE (float64 in walk2_impl.h,
                 # float32 in wide_impl.h): cutting the raster into bands moves the tiles, and the last bit may move with them
-                np.testing.assert_allclose(got.data[i], want[i], rtol=3e-7, atol=0, equal_nan=True, err_msg=f"focal_stats {stat} {k.shape}")
+                # (std / var of the float32 moments kernels: each within ~2e-7 of the float64 result, the raster here has
+                # NaN cells, and the NaN-aware walker's shift follows the tile too)
+                tol = 1e-6 if stat in ('std', 'var') else 2e-6 if stat == 'sum' else 3e-7        # (sum: n c + S in float32)
+                np.testing.assert_allclose(got.data[i], want[i], rtol=tol, atol=0, equal_nan=True, err_msg=f"focal_stats {stat} {k.shape}")
             else:
                 np.testing.assert_array_equal(got.data[i], want[i], err_msg=f"focal_stats {stat} {k.shape}")
         if big:

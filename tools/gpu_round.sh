@@ -38,6 +38,8 @@ for s in $STEPS; do
       echo "rc=$?" >> $OUT/pytest_quick.log; tail -15 $OUT/pytest_quick.log ;;
     kb_small)
       timeout 600 python tools/kbench.py --reps 10 --only copy_kernel,stream_1r2w,stream_1r3w,stream_1r7w,hillshade,slope,aspect,curvature,terrain_fused4,pass_aspect_focal5,pass_all4_focal5,pass_hill_focal5,pass_hill_slope_focal5,pass_curv_hill_focal5,pass_hill_focal3,focal5_mean,focal3_mean,focal25_mean,focal25_stats7,focal13_mean,focal13_stats7,box11_mean,box11_stats7 --fast-inputs > $OUT/kb_small.log 2>&1; tail -20 $OUT/kb_small.log ;;
+    nan)
+      timeout 600 python tools/nan_probe.py > $OUT/nan_probe.log 2>&1; echo "nan rc=$?"; grep -E "focal25|fused|hillshade" $OUT/nan_probe.log | tail -30 ;;
     s64bench)
       timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
     *) echo "unknown step $s" ;;

@@ -585,21 +585,30 @@ inline bool is_uniform_shape(const double *kernel, double *weight) {
 // with a valid cell, so a tile with data costs one row; a tile inside a nodata region costs one pass over cells the
 // fast walker just brought into L2, and then needs no walk at all (the exact walkers are 5-10x slower than the fast ones,
 // and a raster with an ocean has many such tiles).
+template <int NL>                  // NL >= (x_hi - x_lo + 63) / 64: loads per lane and row
 __device__ __forceinline__ bool walk_tile_all_nan(const WalkGeom &g, long x_lo, long x_hi, long y_lo, long y_hi, int lane) {
     x_lo = x_lo < 0 ? 0 : x_lo;
     x_hi = x_hi > g.cols ? g.cols : x_hi;
     y_lo = y_lo < -(long)g.halo_top ? -(long)g.halo_top : y_lo;
     y_hi = y_hi > g.rows + g.halo_bot ? g.rows + g.halo_bot : y_hi;
-    // (the first row alone, then 8 rows per verdict: one row per verdict is one memory latency per row, ~0.15 ms a tile)
-    for (long y = y_lo, step = 1; y < y_hi; y += step, step = 8) {
-        bool valid = false;
+    if (x_lo >= x_hi) return true;
+    // the first row alone, then 16 rows per verdict, every load of a batch independent of the others (columns clamped into
+    // the range instead of tested: a short-circuit `valid || v == v` in a loop with a per-lane trip count made every load
+    // wait for the one before -- 48 memory latencies per batch, and an all-NaN tile as expensive as a walked one)
+    for (long y = y_lo, step = 1; y < y_hi; y += step, step = 16) {
+        unsigned valid = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 16; ++r) {
             if (r >= step || y + r >= y_hi) break;
             const float *p = g.in + (y + r) * g.ld_in;
-            for (long x = x_lo + lane; x < x_hi; x += 64) { const float v = p[x]; valid = valid || v == v; }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const long x = x_lo + lane + 64 * i;
+                const float v = p[x < x_hi ? x : x_hi - 1];
+                valid |= v == v ? 1u : 0u;
+            }
         }
-        if (__any(valid)) return false;
+        if (__any(valid != 0)) return false;
     }
     return true;
 }

@@ -48,6 +48,12 @@ __device__ __forceinline__ void st_row_nt(float *sbase, unsigned voff, lds_dma_v
     asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
+// rows [y0, y_end) x 128 columns from x0 of a plane set to one value: one 8-byte streaming store per lane and row
+__device__ __forceinline__ void fill_tile128_nt(float *plane, long ld, long x0, long y0, long y_end, int lane, float value) {
+    lds_dma_v2f q; q[0] = value; q[1] = value;
+    for (long y = y0; y < y_end; ++y) st_row_nt(uniform_ptr(plane + y * ld + x0), 8u * (unsigned)lane, q);
+}
+
 // LDS float at byte address `addr` + 4 k, with `addr` hidden from the compiler: it then addresses every read of a row as
 // (one base register) + (immediate offset) instead of materialising one address per group of reads
 typedef __attribute__((address_space(3))) const float lds_cfloat;

@@ -704,9 +704,14 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
 #endif
     // the fast walk met a non-finite sum or failed its guard.  Inside a nodata region: nothing to walk
 #ifndef XRS_MOM_T_NOALLNAN
-    if (walk_tile_all_nan(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
+    if (walk_tile_all_nan<(C::TW + 2 * R + 63) / 64>(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
         float *const planes[3] = {a.out_mean, a.out_var, a.out_std};
-        walk_fill_no_data(g, planes, 3, a.out_sum, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
+        if (C::TW == 128 && x_tile + 128 <= g.cols) {
+            for (int i = 0; i < 3; ++i) if (planes[i]) fill_tile128_nt(planes[i], g.ld_out, x_tile, y0, y_end, lane, nan_f32());
+            if (a.out_sum) fill_tile128_nt(a.out_sum, g.ld_out, x_tile, y0, y_end, lane, 0.0f);
+        } else {
+            walk_fill_no_data(g, planes, 3, a.out_sum, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
+        }
         return;
     }
 #endif
@@ -722,7 +727,9 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
         MomWalkN<R, Shape, OM> w(a, lds_rows[wv], x_tile + 64 * q, y0, y_end, lane);
         if (w.run()) continue;
 #endif
+#ifndef XRS_MOM_NO_EXACT           // (debug builds: keep what the NaN-aware walker wrote -- tests/mom_boundary_probe.py)
         mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end, q, 1);
+#endif
     }
 }
 

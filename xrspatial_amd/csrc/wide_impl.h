@@ -408,9 +408,10 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
     if (ok || XRS_WIDE_NO_FALLBACK) return;
     constexpr bool SUM = MODE == WIDE_SUM;
     // inside a nodata region (every cell the tile sees is NaN): mean NaN, sum 0, convolution NaN -- nothing to walk
-    if (walk_tile_all_nan(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
+    if (walk_tile_all_nan<(C::TW + 2 * R + 63) / 64>(g, x_tile - R, x_tile + C::TW + R, y0 - R, y_end + R, lane)) {
         float *const planes[1] = {SUM ? nullptr : a.out};
-        walk_fill_no_data(g, planes, 1, SUM ? a.out : nullptr, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
+        if (C::TW == 128 && x_tile + 128 <= g.cols) fill_tile128_nt(a.out, g.ld_out, x_tile, y0, y_end, lane, SUM ? 0.0f : nan_f32());
+        else walk_fill_no_data(g, planes, 1, SUM ? a.out : nullptr, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
         return;
     }
     if (MODE == WIDE_CONV) {

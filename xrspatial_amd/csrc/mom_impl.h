@@ -30,69 +30,9 @@
 //     A window over equal cells passes with S = Q = 0 exactly (its shift has converged onto the value) or is redone;
 //   * sum = n c + S (one fma), mean = c + S / n, var = (Q - S^2 / n) / n, std = sqrt(var) in float32.
 // Included by kxk_mom_circle.hip / kxk_mom_box.hip, which define XRS_MOM_SHAPE / XRS_MOM_ENTRY.
-#include "circle_walk.h"
-#include "lds_dma.h"
-
-#include <rocprim/warp/warp_reduce.hpp>
-
-#include <utility>
-
-using namespace xrs;
+#include "mom_nan_walk.h"
 
 namespace {
-
-struct MomArgs {
-    WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
-    float *out_sum, *out_mean, *out_var, *out_std;
-    long n_groups, groups_x;      // workgroups = groups of 4 horizontally adjacent wave tiles
-    int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
-    int rim_first;                // work order (circle_walk.h RimFirst)
-};
-
-template <int R, typename Shape>
-struct MomCfg {
-    static constexpr int K = 2 * R + 1;
-#ifndef XRS_MOM_NC
-#define XRS_MOM_NC 2
-#endif
-    static constexpr int NC = XRS_MOM_NC;                  // columns per lane
-    static constexpr int TW = 64 * NC;                     // columns per wave tile
-    static constexpr int HL = NC * ((R + NC - 1) / NC);    // halo columns each side, whole lane groups
-    static constexpr int NV = NC + 2 * HL;                 // cells a lane reads back per row
-    static constexpr int NQ = NV / NC;
-    static constexpr int CELLS = TW + 2 * HL;
-    static_assert(CELLS <= 256, "one 16-byte DMA per row");
-    static constexpr int NTAPS = shape_taps<Shape>(R);
-#ifndef XRS_MOM_U
-#define XRS_MOM_U 5
-#endif
-    static constexpr int U = XRS_MOM_U;                    // rows per unrolled round = rows between two re-centrings
-#ifndef XRS_MOM_D
-#define XRS_MOM_D 8
-#endif
-    static constexpr int D = XRS_MOM_D;                    // rows in flight by LDS-DMA; D + 1 row buffers per wave
-    static constexpr int RBF = 256;                        // floats per row buffer (the 16-byte DMA writes a whole KiB)
-    // input rows a full tile walks: whole rounds covering `base` output rows + the 2R rows of run-in
-    static constexpr int nin(int base) { return ((base + 2 * R + U - 1) / U) * U; }
-    // How much of a re-centring by d is still inside the partial sums of the rows about to be emitted: a row emitted k
-    // rounds later was at most K - (k - 1) U - 1 input rows old when it happened, i.e. held that fraction of its cells
-    // (radius 12, U = 5: 1, 0.84, 0.6, 0.33, 0.09, 0).  Kept as two numbers: d^2 of the last re-centring and a decaying
-    // maximum of the older ones (x 0.85, then x 0.7 per round: 0.85, 0.6, 0.42, 0.29 ... -- never below the table).
-    static constexpr float HIST_FIRST = 0.85f, HIST_DECAY = 0.7f;
-    static constexpr bool level_used(int h) {
-        for (int dy = 0; dy <= R; ++dy)
-            if (Shape::hw(R, dy) == h) return true;
-        return false;
-    }
-    // cells a ring slot has accumulated at a round boundary: the slot that the next row will hit at offset dy_next
-    // has seen the rows at offsets -R .. dy_next - 1
-    static constexpr int seen(int idx) {
-        const int dy_next = idx <= R ? -idx : K - idx;
-        int n = 0;
-        for (int dy = -R; dy < dy_next; ++dy) n += 2 * Shape::hw(R, dy < 0 ? -dy : dy) + 1;
-        return n;
-    }
-};
 
 // number of in-raster cells under the window centred on (yo, x): rows [y_lo, y_hi), columns [0, cols)
 template <int R, typename Shape>
@@ -108,11 +48,6 @@ __device__ __forceinline__ int mom_clipped_count(long yo, long x, long y_lo, lon
     return n;
 }
 
-// OM: the outputs the launch writes (bit 0 sum, 1 mean, 2 var, 3 std) as a compile-time set, or 0 = whatever pointers are
-// non-null at run time.  The common sets are compiled in because the run-time form keeps its "is this plane wanted" flags
-// in vector registers this kernel does not have (one spilled flag = one scratch reload + s_waitcnt vmcnt(0) per round,
-// which drains the DMA ring); it also sets the vmcnt bookkeeping of the ring (assuming fewer stores than the truth is safe).
-enum : int { MOM_SUM = 1, MOM_MEAN = 2, MOM_VAR = 4, MOM_STD = 8 };
 // EDGE = false: a full tile whose whole input window lies inside the raster (LDS-DMA ring, no predicates, trailing shift);
 // EDGE = true: tiles at the raster / shard edge and partial tiles: predicated loads staged through LDS with NaN for the
 // cells outside (a reader turns them into w = 0), divisors = the geometric count of in-raster cells under each window,
@@ -434,225 +369,6 @@ struct MomWalk {
     }
 };
 
-
-// ---- The NaN-aware walker: raster edges, nodata regions, scattered NaN cells -- still float32, still about a shift that
-// trails the walk.  One column per lane (64-column half tiles); every staged cell travels as z = (valid ? v : 0) and
-// f = (valid ? 1 : 0), valid = inside the raster and not NaN (the loading lane decides, once per cell); a reader forms
-// w = z - c f, and THREE lane-local prefix sums -- of f, w and w^2 -- give every centred run's count, sum and sum of squares
-// with one subtraction each; three register rings (N, S, Q) carry the 2R+1 output rows in flight.  With the counts in the
-// ring the re-centring needs no compile-time cell counts (S' = S - N d with the slot's own N), so it works at the raster
-// edge and next to nodata exactly as in the interior: mean = c + S / N, var = (Q - S^2 / N) / N, sum = N c + S, NaN (sum: 0)
-// for a window without a valid cell (numba nanmean / nanvar / nansum of an empty window).  Same guard as the fast walk;
-// +-inf or a failed guard hand the half tile to the exact float64 walker.
-// Round 2 and the first form of this file sent every tile with a NaN cell to that exact walker: a raster with 0.1 %
-// scattered NaN took 5.0 ms instead of 1.3 for mean + var + std, one with a nodata third 33 ms (tools/nan_probe.py).
-template <int R, typename Shape, int OM>
-struct MomWalkN {
-    __device__ __forceinline__ bool want(int bit, const float *p) const { return OM ? (OM & bit) != 0 : p != nullptr; }
-    using C = MomCfg<R, Shape>;
-    static constexpr int K = C::K, U = C::U;
-    static constexpr int STG = 64 + 2 * R;                 // staged cells per row: raster columns xw - R .. xw + 63 + R
-
-    float accN[K], accS[K], accQ[K];
-    float pf_own[U], pf_halo[U];                           // the rows of the current round, loaded up front
-    float c, snapS, snapN;                                 // the shift; sum / count of the round's widest runs about it
-    float dq_last, dq_old, dqm;                            // d^2 of the last re-centring, decaying maximum of the older ones, max
-    unsigned long long badm;
-    float gmf;
-    int t, n_in;
-
-    const MomArgs &a;
-    const WalkGeom &g;
-    float *lds;                                            // Z[STG] then F[STG]
-    unsigned lds_z;                                        // LDS byte address of Z[lane]
-    long xw, x, y0, y_end, y_first;
-    int lane;
-
-    __device__ __forceinline__ MomWalkN(const MomArgs &a_, float *lds_, long xw_, long y0_, long ye, int lane_)
-        : a(a_), g(a_.g), lds(lds_), xw(xw_), x(xw_ + lane_), y0(y0_), y_end(ye), lane(lane_) {}
-
-    __device__ __forceinline__ void load_row(int il, float &own, float &halo) const {
-        const long yy = y_first + il;
-        own = halo = nan_f32();                                 // outside the raster == not valid
-        const bool row_ok = il < n_in && yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;     // wave-uniform
-        if (!row_ok) return;
-        const float *p = g.in + yy * g.ld_in;
-        const long xa = xw - R + lane, xb = xa + 64;
-        if (xa >= 0 && xa < g.cols) own = p[xa];
-        if (lane < 2 * R && xb >= 0 && xb < g.cols) halo = p[xb];
-    }
-
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int j = 0; j < K; ++j) { accN[j] = 0.0f; accS[j] = 0.0f; accQ[j] = 0.0f; }
-        snapS = snapN = 0.0f;
-        dq_last = dq_old = dqm = 0.0f;
-        badm = 0;
-        gmf = (want(MOM_MEAN, a.out_mean) || want(MOM_SUM, a.out_sum)) ? 0.04f : 0.0f;
-        t = 0;
-        y_first = y0 - R;
-        n_in = (int)(y_end - y0) + 2 * R;
-        lds_z = lds_addr(lds) + 4u * (unsigned)lane;
-        c = 0.0f;
-    }
-
-    // first shift, from the rows of the first round: the mean of the lane's valid cells (staged cell `lane` = raster column
-    // x - R: close enough for a first value), else any lane's, else 0 -- the first re-centring replaces it
-    __device__ __forceinline__ void first_shift() {
-        float s = 0.0f, n = 0.0f;
-#pragma unroll
-        for (int r = 0; r < U; ++r) {
-            const bool ok = isfinite(pf_own[r]);
-            s += ok ? pf_own[r] : 0.0f;
-            n += ok ? 1.0f : 0.0f;
-        }
-        const float m = n > 0.0f ? s / n : 0.0f;
-        const unsigned long long have = __ballot(n > 0.0f);
-        const float m_any = __shfl(m, have ? __ffsll((long long)have) - 1 : 0);      // (every lane executes the shuffle)
-        c = n > 0.0f ? m : have ? m_any : 0.0f;
-    }
-
-    // WHAT: 0 = counts, 1 = w, 2 = w^2
-    template <int PHASE, int WHAT>
-    __device__ __forceinline__ void pass() {
-        float p[K];
-        lds_cfloat *z = (lds_cfloat *)(size_t)lds_z;
-        lds_cfloat *f = (lds_cfloat *)(size_t)(lds_z + 4u * STG);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (WHAT == 0) { p[k] = f[k]; continue; }
-            const float w = fmaf(-c, f[k], z[k]);
-            p[k] = WHAT == 1 ? w : w * w;
-        }
-        const float p0 = p[R];
-#pragma unroll
-        for (int k = 1; k < K; ++k) p[k] += p[k - 1];
-#pragma unroll
-        for (int h = 0; h <= R; ++h) {
-            if (!C::level_used(h)) continue;
-            const float S = h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
-            if (h == R) {                                      // (hw(0) == R for every shape)
-                if (WHAT == 0) snapN += S;
-                if (WHAT == 1) snapS += S;
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int dy = j - R;
-                if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
-                const int idx = ((PHASE - dy) % K + K) % K;
-                if (WHAT == 0) accN[idx] += S;
-                else if (WHAT == 1) accS[idx] += S;
-                else accQ[idx] += S;
-            }
-        }
-    }
-
-    template <int PHASE>
-    __device__ __forceinline__ void step() {
-        const int i = t + PHASE;
-        if (i >= n_in) return;
-        {   // ---- stage the row: the loading lane decides validity once per cell
-            const float o = pf_own[PHASE], hq = pf_halo[PHASE];
-            const bool vo = o == o, vh = hq == hq;
-            lds[lane] = vo ? o : 0.0f;
-            lds[STG + lane] = vo ? 1.0f : 0.0f;
-            if (lane < 2 * R) {
-                lds[64 + lane] = vh ? hq : 0.0f;
-                lds[STG + 64 + lane] = vh ? 1.0f : 0.0f;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                         // (LDS serves one wave's instructions in order)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        pass<PHASE, 0>();
-        pass<PHASE, 1>();
-        pass<PHASE, 2>();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- the output row R rows up is complete
-        constexpr int DONE = ((PHASE - R) % K + K) % K;
-        const long yo = y0 + (i - 2 * R);
-        bool bad = false;
-        if (i >= 2 * R && yo < y_end && x < g.cols) {
-            const float n = accN[DONE], S = accS[DONE], Q = accQ[DONE];
-            float mean = nan_f32(), var = nan_f32(), sd = nan_f32(), sum = 0.0f;
-            if (n > 0.0f) {
-                const float ms = S / n;
-                mean = c + ms;
-                const float e = n == 1.0f ? 0.0f : Q - S * ms;      // (one valid cell: variance exactly 0, whatever the shift)
-                const float B = Q + n * dqm;
-                bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
-                var = e / n;
-                sd = sqrtf(var);
-                sum = fmaf(n, c, S);
-            }
-            const long off = yo * g.ld_out + x;
-            if (want(MOM_MEAN, a.out_mean)) a.out_mean[off] = mean;
-            if (want(MOM_VAR, a.out_var)) a.out_var[off] = var;
-            if (want(MOM_STD, a.out_std)) a.out_std[off] = sd;
-            if (want(MOM_SUM, a.out_sum)) a.out_sum[off] = sum;
-        }
-        // (outside the lane-divergent block: the verdict must be the same in EVERY lane, columns beyond the raster
-        // included -- the exact walker's wave-wide reductions need the whole wave to arrive together)
-        badm |= __builtin_amdgcn_ballot_w64(bad);
-        accN[DONE] = 0.0f; accS[DONE] = 0.0f; accQ[DONE] = 0.0f;
-    }
-
-    __device__ __forceinline__ void recentre() {
-        // the lane's own estimate of the level of its columns: the mean of the round's widest runs.  Next to nodata a run
-        // holds few valid cells and its mean jitters (a jittering shift trips the guard), inside nodata it holds none: such
-        // lanes follow the wave's estimate instead (mean of the lanes that have one)
-        const bool own = snapN >= 16.0f;
-        float est = c + (snapN > 0.0f ? snapS / snapN : 0.0f);
-        {
-            rocprim::warp_reduce<float, 64>::storage_type st;
-            float se = own ? est : 0.0f, sn = own ? 1.0f : 0.0f;
-            rocprim::warp_reduce<float, 64>().reduce(se, se, st);
-            rocprim::warp_reduce<float, 64>().reduce(sn, sn, st);
-            se = __shfl(se, 0);
-            sn = __shfl(sn, 0);
-            if (!own) est = sn > 0.0f ? se / sn : est;
-        }
-        float d = est - c;
-        snapS = snapN = 0.0f;
-        const float c_new = c + d;
-        d = c_new - c;                                         // exact: the step the walk really takes
-        c = c_new;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float S = accS[j];
-            const float S2 = fmaf(-accN[j], d, S);
-            accQ[j] -= d * (S + S2);
-            accS[j] = S2;
-        }
-        dq_old = fmaxf(dq_last * C::HIST_FIRST, dq_old * C::HIST_DECAY);
-        dq_last = d * d;
-        dqm = fmaxf(dq_last, dq_old);
-    }
-
-    template <int... P>
-    __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
-        (load_row(t + P, pf_own[P], pf_halo[P]), ...);
-        if (t == 0) first_shift();
-        (step<P>(), ...);
-        ring_rotate<K, U>(accN);
-        ring_rotate<K, U>(accS);
-        ring_rotate<K, U>(accQ);
-        t += U;
-        recentre();
-    }
-
-    // true: every result of the half tile is good; false: the caller redoes it with the exact float64 walker
-    __device__ __forceinline__ bool run() {
-        init();
-        while (t < n_in) {
-            round(std::make_integer_sequence<int, U>{});
-            if (badm) return false;
-        }
-        return true;
-    }
-};
 
 // raster edges, non-finite cells under a window, sums too ill-conditioned for float32: the exact float64 column walker
 // (NaN-skipping, counting, the reference's two-pass variance where it matters), 64 columns at a time.  

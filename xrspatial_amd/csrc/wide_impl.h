@@ -38,6 +38,7 @@
 // 0.3 loads + ~50.  HBM-bound by construction (8 B per cell); measured numbers in DESIGN.md.
 #include "circle_walk.h"
 #include "lds_dma.h"
+#include "mom_nan_walk.h"
 
 #include <utility>
 
@@ -420,10 +421,23 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
         for (int q = 0; q < C::NC; ++q) walk_conv_columns<R, Shape>(g, a.out, a.wgt, a.weights, x_tile + 64 * q, lane, y0, y_end);
         return;
     }
-    // non-finite cells under a window, or sums too ill-conditioned for float32: the float64 column walker (NaN-skipping,
-    // counting; mean from float64 sums, the sum with the reference's sequential float32 adds), 64 columns at a time
+    // NaN cells under a window (nodata, the raster's edge): the NaN-aware float32 walker of mom_nan_walk.h without its
+    // squares -- validity and counts carried with the sums, the shift trails the walk, the rounding of S bounded at the end
+    // of the tile like this kernel's own -- 64 columns at a time.  What fails that (+-inf, values straddling zero), and
+    // sums too ill-conditioned for float32 in the first place: the float64 column walker (NaN-skipping, counting; mean from
+    // float64 sums, the sum with the reference's sequential float32 adds).
     const WalkOuts o = {SUM ? a.out : nullptr, nullptr, nullptr, nullptr, SUM ? nullptr : a.out, nullptr, nullptr};
+    MomArgs ma;
+    ma.g = g;
+    ma.out_sum = SUM ? a.out : nullptr; ma.out_mean = SUM ? nullptr : a.out; ma.out_var = nullptr; ma.out_std = nullptr;
     for (int q = 0; q < C::NC; ++q) {
+        if (x_tile + 64 * q >= g.cols) break;
+#ifndef XRS_WIDE_NO_NANWALK
+        {
+            MomWalkN<R, Shape, SUM ? MOM_SUM : MOM_MEAN> w(ma, lds_rows[wv], x_tile + 64 * q, y0, y_end, lane);
+            if (w.run()) continue;
+        }
+#endif
         if (!SUM) walk_columns<R, Shape, false, false, false, true, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
         else walk_columns<R, Shape, true, true, false, false, false>(g, o, x_tile + 64 * q, lane, y0, y_end);
     }

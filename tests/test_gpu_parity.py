@@ -354,7 +354,12 @@ def test_circular_masks_column_walker(radius, shape_kind):
     k2 = k.copy()
     k2[0, 0] = 1.0
     z = synth.smooth_dem((60, 200), nan_frac=0.02)
-    np.testing.assert_array_equal(apply(raster(z), k2, _calc_sum).data, corc.focal_apply(z, k2, 'sum', nthreads=8))
+    if (k2 != k).any():
+        np.testing.assert_array_equal(apply(raster(z), k2, _calc_sum).data, corc.focal_apply(z, k2, 'sum', nthreads=8))
+    else:
+        # (a box already has that corner: still the walker, whose sum is n c + S -- also in the tiles that hold a NaN, which
+        # used to reach the sequential float32 adds of the exact walker and were bit-exact by that accident)
+        check_window_sum(apply(raster(z), k2, _calc_sum).data, z, k2, "box with its corner set")
 
 
 @pytest.mark.parametrize("radius", [3, 6, 12])

@@ -25,9 +25,12 @@
 //     emulation and the GPU runs put the error at <= 2e-6 there; a bound of 10 let 1.5e-5 through on windows that straddle
 //     a cliff, where several large re-centrings follow each other) and mean / sum
 //     if mean^2 >= 0.04 B / n; otherwise -- flat windows next to relief, values
-//     straddling zero, NaN / inf anywhere under a window (the comparisons fail on non-finite sums) -- the whole tile
-//     is redone by the exact float64 NaN-skipping walker of circle_walk.h, like the tiles at the raster edge.
-//     A window over equal cells passes with S = Q = 0 exactly (its shift has converged onto the value) or is redone;
+//     straddling zero, NaN / inf anywhere under a window (the comparisons fail on non-finite sums) -- the tile is
+//     redone: an all-NaN tile is filled without a walk, a tile with NaN cells goes through the NaN-aware float32 walker of
+//     mom_nan_walk.h (counts carried with the sums), and only what fails THAT guard -- +-inf, windows with a few close
+//     valid cells at the rim of a nodata region, ill-conditioned sums -- reaches the exact float64 NaN-skipping walker of
+//     circle_walk.h.  A window over equal cells passes with S = Q = 0 exactly (its shift has converged onto the value) or
+//     is redone;
 //   * sum = n c + S (one fma), mean = c + S / n, var = (Q - S^2 / n) / n, std = sqrt(var) in float32.
 // Included by kxk_mom_circle.hip / kxk_mom_box.hip, which define XRS_MOM_SHAPE / XRS_MOM_ENTRY.
 #include "mom_nan_walk.h"

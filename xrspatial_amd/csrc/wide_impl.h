@@ -18,9 +18,11 @@
 //     kernel runs at instruction-fetch speed (measured: 1.20 ms against 0.6 ms; profiles/r02).
 //   * mean = c + S / n.  Everything is float32: the error of S is bounded by u * A * (a few 10^4) with A the largest
 //     |v - c| of the tile, i.e. <= 7e-6 * A on the mean; the wave checks A <= 1.4 * min |mean| at the end of its tile
-//     (which guarantees 1e-5 relative) and that every result is finite, and otherwise hands the whole tile to the
-//     float64 column walker of circle_walk.h (NaN-skipping, counting, exact) -- nodata regions, +-inf, rasters whose
-//     values straddle zero take that path.  Typical errors are ~1e-8 relative (tests: 1e-6 on both DEMs).
+//     (which guarantees 1e-5 relative) and that every result is finite, and otherwise hands the whole tile on: filled
+//     without a walk if every cell it sees is NaN, else to the NaN-aware float32 walker of mom_nan_walk.h in its mean / sum
+//     mode (nodata regions, scattered NaN cells), and from there -- +-inf, rasters whose values straddle zero -- to the
+//     float64 column walker of circle_walk.h (NaN-skipping, counting, exact).  Typical errors are ~1e-8 relative
+//     (tests: 1e-6 on both DEMs).
 //   * raster edges (clipped windows): out-of-raster cells enter as d = 0 and the divisor is the geometric count of
 //     in-raster cells, so edge tiles stay on the fast path (a second, predicated instantiation of the same walk).
 //   * memory latency: the interior walk prefetches its rows D = 8 ahead by LDS-DMA (global_load_lds_dwordx4: global ->

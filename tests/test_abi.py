@@ -84,3 +84,24 @@ def test_oracle_is_used_only_by_tests_smoke_and_the_cpu_baseline():
     assert hits and all(h > leg for h in hits)              # every import sits inside the cpu_baseline function
     entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert all(h > entry.index("def smoke") for h in [m.start() for m in imp.finditer(entry)])
+
+
+def test_build_id_covers_every_source_and_header():
+    """xrs_build_id() is a hash of the files the Makefile lists (SRCS + HDRS): bench.py, the PMC table and every log key
+    their numbers by it, so a kernel source or header that is not listed would change the library without changing the id."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xrspatial_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read().replace("\\\n", " ")
+    listed = set()
+    for var in ("SRCS", "HDRS"):
+        m = re.search(r"^%s\s*=\s*(.*)$" % var, mk, re.M)
+        assert m, var
+        listed |= {os.path.basename(w) for w in m.group(1).split()}
+    on_disk = {os.path.basename(p) for ext in ("*.hip", "*.h") for p in glob.glob(os.path.join(csrc, ext))}
+    assert on_disk <= listed, f"not in the Makefile's SRCS / HDRS (so not in the build id): {sorted(on_disk - listed)}"
+    # ... and every quoted include resolves to a listed file
+    for name in on_disk:
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(os.path.join(csrc, name)).read(), re.M):
+            base = os.path.basename(inc)
+            assert base in listed or base == "build_id.h", f"{name} includes {inc}, which the Makefile does not list"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Scalar-register pressure check for the large-window moments kernel (mom_impl.h): compiles the radius-12 circle
 # instantiation alone and counts the v_readlane_b32 (SGPRs parked in VGPR lanes) and VALU instructions of the interior
-# walker's round loop.  8 / 610 at the time of writing; control-flow changes AFTER the loop have pushed it to 48-56 and
+# walker's round loop (5 rows x 2 columns per lane).  At the time of writing: see DESIGN.md; control-flow changes AFTER the loop have pushed it to 48-56 and
 # cost 5 % of the kernel.   usage: tools/readlanes.sh ["extra compiler flags"]
 set -e
 cd "$(dirname "$0")/../xrspatial_amd/csrc"
@@ -12,8 +12,32 @@ S=$T/kxk_mom_circle-hip-amdgcn-amd-amdhsa-gfx950.s
 K=_ZN12_GLOBAL__N_116focal_mom_kernelILi12EN3xrs11CircleShapeELi14EEEvNS_7MomArgsE
 awk -v k="^$K:" '$0 ~ k {f=1} f{print} /^\.Lfunc_end/{if(f) exit}' $S > $T/kernel.s
 grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):" $S | paste - - - - - | grep "$K" | sed -E 's/\s+/ /g'
-start=$(grep -n "Inner Loop Header: Depth=1" $T/kernel.s | head -1 | cut -d: -f1)
-end=$((start + 1080))
-echo "round loop (lines $start..$end): v_readlane $(sed -n ${start},${end}p $T/kernel.s | grep -c v_readlane)," \
-     "VALU $(sed -n ${start},${end}p $T/kernel.s | grep -cE '^\s*v_'), scratch $(sed -n ${start},${end}p $T/kernel.s | grep -c scratch_)"
+# the interior walker's round loop: the first depth-1 loop that holds LDS-DMA instructions; from its header label to the
+# last branch back to that label
+python3 - $T/kernel.s <<'PY'
+import re, sys
+lines = open(sys.argv[1]).read().split("\n")
+labels = {}
+for i, l in enumerate(lines):
+    m = re.match(r"^(\.LBB\d+_\d+):", l)
+    if m:
+        labels[m.group(1)] = i
+best = None
+for lab, i in labels.items():
+    ends = [j for j, l in enumerate(lines) if j > i and re.search(r"s_cbranch\w+\s+" + re.escape(lab) + r"\s*$", l)]
+    if not ends:
+        continue
+    body = lines[i:ends[-1] + 1]
+    # (the SMALLEST loop with the DMA and a round's worth of arithmetic: the tile loop around it holds the edge walker too)
+    if any("global_load_lds" in l for l in body) and sum(1 for l in body if re.match(r"^\s+v_", l)) > 400 \
+            and (best is None or len(body) < best[2]):
+        best = (i, ends[-1], len(body), body)
+if best is None:
+    print("round loop not found")
+else:
+    i, j, n, body = best
+    c = lambda pat: sum(1 for l in body if re.search(pat, l))
+    counts = (c("v_readlane"), c("v_writelane"), c("^\\s+v_"), c("^\\s+s_"), c("^\\s+ds_"), c("scratch_"))
+    print("round loop (lines %d..%d): v_readlane %d, v_writelane %d, VALU %d, SALU %d, LDS %d, scratch %d" % ((i + 1, j + 1) + counts))
+PY
 rm -rf $T

@@ -189,6 +189,18 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
                         int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                         const double *kernel, int krows, int kcols, void *work_dev,
                         int halo_top, int halo_bot, void *stream);
+/* The same with accuracy options (xrs_focal_stats_f32 == flags 0).  Windows of 9x9 cells and more take float32 walkers
+ * whose mean / var / std / sum agree with the reference's float64 accumulators to <= 2e-6 relative (a guard per output
+ * sends ill-conditioned tiles to the exact kernels); the flags keep whole launches on the exact kernels instead:
+ *   XRS_FOCAL_EXACT_MOMENTS   mean / var / std from float64 running sums (NaN-skipping, counted): ~1 ulp of the reference;
+ *   XRS_FOCAL_SEQUENTIAL_SUM  `sum` added tap by tap in the reference's row-major order in float32 (numba's nansum keeps
+ *                             the array dtype): bit-identical to the CPU path.
+ * The host layer sets them from xrspatial_amd.focal.options / the XRS_FOCAL_SUM and XRS_FOCAL_MOMENTS variables. */
+enum { XRS_FOCAL_EXACT_MOMENTS = 1, XRS_FOCAL_SEQUENTIAL_SUM = 2 };
+int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned stat_mask,
+                           int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                           const double *kernel, int krows, int kcols, void *work_dev,
+                           int halo_top, int halo_bot, unsigned flags, void *stream);
 
 /* focal.apply with a user callable (func other than the built-in reducers): the kernel-shaped float32 arrays that
  * _apply_numpy, xrspatial/focal.py:305-326, builds per cell (NaN, then data[ky, kx] where kernel == 1 and inside the

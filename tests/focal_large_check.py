@@ -1,5 +1,5 @@
 """Large-window focal kernels on the GPU box: parity against the C oracle and same-box A/B timing of the
-first-generation column walkers (XRS_FOCAL_GEN=1) against the wide row walker / second-generation walker.
+first-generation column walkers (flag XRS_FOCAL_EXACT_MOMENTS) against the wide row walker / second-generation walker.
 
     python tests/focal_large_check.py [--out gpurun_out/focal_large.json] [--size 16384] [--skip-parity]
 
@@ -108,14 +108,14 @@ def timing(report, n):
     L("xrs_event_create", ctypes.byref(e0))
     L("xrs_event_create", ctypes.byref(e1))
 
-    def run(k, mask, reps=4):
+    def run(k, mask, reps=4, flags=0):
         kk = np.ascontiguousarray(k, dtype=np.float64)
         ptrs = (ctypes.c_void_p * 7)()
         for i in range(7):
             if mask >> i & 1:
                 ptrs[i] = outs_dev[i].ptr
-        fn = lambda: L("xrs_focal_stats_f32", dem.ptr, ptrs, mask, n, n, n, n, kk.ctypes.data, k.shape[0], k.shape[1],  # noqa: E731
-                       None, 0, 0, None)
+        fn = lambda: L("xrs_focal_stats_f32_ex", dem.ptr, ptrs, mask, n, n, n, n, kk.ctypes.data, k.shape[0], k.shape[1],  # noqa: E731
+                       None, 0, 0, flags, None)
         fn()
         L("xrs_stream_sync", None)
         L("xrs_event_record", e0, None)
@@ -146,19 +146,14 @@ def timing(report, n):
             k = circle_kernel(1, 1, radius) if kind == "circle" else np.ones((K, K))
             for what, mask, nbytes in (("mean", 1, 8), ("all7", 127, 32), ("mean+var+std", 1 | 16 | 32, 16), ("sum", 64, 8)):
                 row = {"mask": f"{kind} r={radius}", "stats": what}
-                for gen, env in (("gen1", "1"), ("gen2", "")):
-                    if env:
-                        os.environ["XRS_FOCAL_GEN"] = env
-                    else:
-                        os.environ.pop("XRS_FOCAL_GEN", None)
+                for gen, flags in (("gen1", 1), ("gen2", 0)):       # (gen1: XRS_FOCAL_EXACT_MOMENTS, the float64 column walkers)
                     try:
-                        t = run(k, mask)
+                        t = run(k, mask, flags=flags)
                         row[gen + "_ms"] = round(t, 4)
                         row[gen + "_gbs"] = round(nbytes * n * n / (t * 1e-3) / 1e9, 1)
                         row[gen + "_frac_of_copy"] = round(nbytes * n * n / (t * 1e-3) / 1e9 / copy_gbs, 3)
                     except Exception as exc:      # noqa: BLE001
                         row[gen + "_error"] = repr(exc)[:300]
-                os.environ.pop("XRS_FOCAL_GEN", None)
                 report["timing"].append(row)
                 print(json.dumps(row), flush=True)
 

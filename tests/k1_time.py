@@ -1,4 +1,4 @@
-"""Time one focal_stats configuration on a 16384^2 DEM and compare it with the first-generation walkers (XRS_FOCAL_GEN=1),
+"""Time one focal_stats configuration on a 16384^2 DEM and compare it with the first-generation walkers (flag XRS_FOCAL_EXACT_MOMENTS),
 for A/B runs of library builds (XRS_LIB=...):   python tests/k1_time.py [radius] [mask: 1=mean, 127=all7] [circle|box]"""
 import ctypes
 import os
@@ -32,12 +32,12 @@ L("xrs_event_create", ctypes.byref(e0))
 L("xrs_event_create", ctypes.byref(e1))
 
 
-def run(dst, reps):
+def run(dst, reps, flags=0):
     ptrs = (ctypes.c_void_p * 7)()
     for i in range(7):
         if dst[i] is not None:
             ptrs[i] = dst[i].ptr
-    fn = lambda: L("xrs_focal_stats_f32", dem.ptr, ptrs, mask, n, n, n, n, k.ctypes.data, K, K, None, 0, 0, None)  # noqa: E731
+    fn = lambda: L("xrs_focal_stats_f32_ex", dem.ptr, ptrs, mask, n, n, n, n, k.ctypes.data, K, K, None, 0, 0, flags, None)  # noqa: E731
     fn()
     L("xrs_stream_sync", None)
     L("xrs_event_record", e0, None)
@@ -53,8 +53,7 @@ def run(dst, reps):
 for _ in range(20):
     L("xrs_copy_f32", dem.ptr, outs[0].ptr if outs[0] is not None else [o for o in outs if o is not None][0].ptr, n * n, None)
 t = run(outs, 6)
-os.environ["XRS_FOCAL_GEN"] = "1"
-t1 = run(ref, 2)
+t1 = run(ref, 2, flags=1)          # XRS_FOCAL_EXACT_MOMENTS: the first-generation float64 walkers
 worst = 0.0
 for i in range(7):
     if outs[i] is None:

@@ -87,14 +87,14 @@ def test_oracle_is_used_only_by_tests_smoke_and_the_cpu_baseline():
 
 
 def test_build_id_covers_every_source_and_header():
-    """xrs_build_id() is a hash of the files the Makefile lists (SRCS + HDRS): bench.py, the PMC table and every log key
+    """xrs_build_id() is a hash of the files the Makefile lists (SRCS + SRCS_AB + HDRS): bench.py, the PMC table and every log key
     their numbers by it, so a kernel source or header that is not listed would change the library without changing the id."""
     import glob
     import re
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xrspatial_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read().replace("\\\n", " ")
     listed = set()
-    for var in ("SRCS", "HDRS"):
+    for var in ("SRCS", "SRCS_AB", "HDRS"):
         m = re.search(r"^%s\s*=\s*(.*)$" % var, mk, re.M)
         assert m, var
         listed |= {os.path.basename(w) for w in m.group(1).split()}

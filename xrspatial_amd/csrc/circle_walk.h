@@ -118,7 +118,7 @@ inline int walk3_wg_per_cu(K kernel_fn, int fallback) {
 }
 
 inline int walk3_tile_base(long rows, long groups_x, int radius, int u, int wg_per_cu) {
-    const char *e = getenv("XRS_WALK_TILE_ROWS");
+    const char *e = ab_env("XRS_WALK_TILE_ROWS");
     if (e && atoi(e) >= 16) return atoi(e);
     static thread_local int n_cu = 0;
     if (!n_cu) {
@@ -152,7 +152,7 @@ struct RimFirst {
         n_rim = mode == 0 ? -1 : (gw <= 2 || gh <= 2) ? n_all : 2 * gw + 2 * (gh - 2);
     }
     static int mode_from_env() {
-        const char *e = getenv("XRS_RIM_FIRST");
+        const char *e = ab_env("XRS_RIM_FIRST");
         return e && e[0] == '0' ? 0 : 1;
     }
     __host__ long grid() const { return n_rim < 0 ? xcd_grid(n_all, 0) : n_rim + xcd_grid(n_all - n_rim, 0); }

@@ -912,16 +912,28 @@ bool vec_ok(const KxkArgs &a, unsigned out_mask) {
     return v;
 }
 
-// dynamic LDS beyond 64 KiB has to be allowed per kernel (once per thread and kernel: the call synchronises)
+// dynamic LDS beyond 64 KiB has to be allowed per kernel and device (the call synchronises, so it is issued once per
+// thread, kernel instantiation and device: every instantiation of one kernel template has the same pointer TYPE, so the
+// cache is keyed on the pointer VALUE, with one bit per device as in zonal.hip)
 template <typename K>
 int allow_big_lds(K kernel_fn, size_t lds) {
     if (lds <= 64 * 1024) return 0;
-    static thread_local bool done = false;                    // (one instance per kernel type K... and per function pointer value:
-    static thread_local const void *done_for = nullptr;       //  instantiations of one template share K, so remember the pointer)
+    struct Seen { const void *fn; unsigned long long devices; };
+    static thread_local Seen seen[8];
+    static thread_local int n_seen = 0;
     const void *fn = reinterpret_cast<const void *>(kernel_fn);
-    if (done && done_for == fn) return 0;
+    int dev = 0;
+    XRS_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;          // (device >= 64: never cached)
+    Seen *e = nullptr;
+    for (int i = 0; i < n_seen; ++i) if (seen[i].fn == fn) e = &seen[i];
+    if (e && (e->devices & bit)) return 0;
     XRS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    done = true; done_for = fn;
+    if (!e) {
+        e = &seen[n_seen < 8 ? n_seen++ : 7];                               // (table full: the last entry is recycled)
+        e->fn = fn; e->devices = 0;
+    }
+    e->devices |= bit;
     return 0;
 }
 
@@ -964,7 +976,7 @@ int launch_mean_direct_rb(KxkArgs a, hipStream_t s) {
 
 template <int KH, int KW>
 int launch_mean_direct(const KxkArgs &a, hipStream_t s) {
-    const char *e = getenv("XRS_FOCAL_RB");          // A/B knob: rows per wave (default 4)
+    const char *e = ab_env("XRS_FOCAL_RB");          // A/B knob: rows per wave (default 4)
     if (e && e[0] == '2') return launch_mean_direct_rb<KH, KW, 2>(a, s);
     return launch_mean_direct_rb<KH, KW, 4>(a, s);
 }
@@ -990,7 +1002,7 @@ int launch_convolve_direct(KxkArgs a, hipStream_t s) {
 
 // XRS_FOCAL_VARIANT=lds forces the LDS-tile kernels for small masks (A/B measurements; default: direct)
 bool prefer_lds() {
-    const char *e = getenv("XRS_FOCAL_VARIANT");
+    const char *e = ab_env("XRS_FOCAL_VARIANT");
     return e && strcmp(e, "lds") == 0;
 }
 
@@ -1017,7 +1029,7 @@ int try_walk_f64(const float *in, float *mean, float *var, float *sd, long rows,
 
 // XRS_FOCAL_VARIANT=strip keeps small circular masks on the register-strip all-statistics kernel (A/B; default: walker)
 bool prefer_strip() {
-    const char *e = getenv("XRS_FOCAL_VARIANT");
+    const char *e = ab_env("XRS_FOCAL_VARIANT");
     return e && (strcmp(e, "strip") == 0 || strcmp(e, "lds") == 0);
 }
 
@@ -1074,20 +1086,21 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     hipStream_t s = as_stream(stream);
     XRS_HIP(hipMemcpyAsync(work_dev, kernel, (size_t)krows * kcols * sizeof(double), hipMemcpyHostToDevice, s));
     a.weights = static_cast<const double *>(work_dev);
-    if (krows >= 7 && !getenv("XRS_CONV_TAPS")) {
+    if (krows >= 7 && !ab_env("XRS_CONV_TAPS")) {
         // one weight value on a circle / box (normalised circle_kernel, np.ones / k^2): the wide row walker (wide_impl.h,
-        // float32 on shifted values, guarded); XRS_CONV_GEN=1: round 1's float64 column walker (A/B)
-        const char *gen = getenv("XRS_CONV_GEN");
-        const bool gen1 = gen && gen[0] == '1';
-        int rc = gen1 ? try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
-                                               halo_top, halo_bot, s)
-                      : try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
-                                                    halo_top, halo_bot, s);
+        // float32 on shifted values, guarded).  (`make AB=1` + XRS_CONV_GEN=1: round 1's float64 column walker.)
+        int rc = -1;
+#ifdef XRS_AB
+        const char *gen = ab_env("XRS_CONV_GEN");
+        if (gen && gen[0] == '1') {
+            rc = try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
+            if (rc < 0) rc = try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
+            if (rc >= 0) return rc;
+        }
+#endif
+        rc = try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc < 0)
-            rc = gen1 ? try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
-                                            halo_top, halo_bot, s)
-                      : try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols,
-                                                 halo_top, halo_bot, s);
+            rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     a.tiles_x = (cols + TW - 1) / TW;
@@ -1113,6 +1126,13 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
 int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned stat_mask, int64_t rows,
                         int64_t cols, int64_t ld_in, int64_t ld_out, const double *kernel, int krows,
                         int kcols, void *work_dev, int halo_top, int halo_bot, void *stream) {
+    return xrs_focal_stats_f32_ex(in_dev, outs_dev, stat_mask, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev,
+                                  halo_top, halo_bot, 0u, stream);
+}
+
+int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned stat_mask, int64_t rows,
+                           int64_t cols, int64_t ld_in, int64_t ld_out, const double *kernel, int krows,
+                           int kcols, void *work_dev, int halo_top, int halo_bot, unsigned flags, void *stream) {
     if (int rc = check_common("xrs_focal_stats_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
                               halo_top, halo_bot)) return rc;
     if (!outs_dev) return fail("xrs_focal_stats_f32: null outputs");
@@ -1132,13 +1152,15 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
     if (krows > MAX_K || kcols > MAX_K)
         return launch_window_any_size(false, in_dev, a.out, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev, halo_top,
                                       halo_bot, s);
-    // Large circles / boxes (the walkers of wide_impl.h / walk2_impl.h).  XRS_FOCAL_GEN=1 keeps the first-generation
-    // column walkers (A/B runs); XRS_FOCAL_SUM=sequential keeps `sum` on the kernel that adds the taps in the
-    // reference's order in float32 (bit-exact with numba's nansum) instead of rounding the exact sum once.
-    const char *gen = getenv("XRS_FOCAL_GEN");
-    const bool gen1 = gen && gen[0] == '1';
-    const char *sum_env = getenv("XRS_FOCAL_SUM");
-    const bool seq_sum = sum_env && sum_env[0] == 's';
+    // Large circles / boxes: the float32 walkers of wide_impl.h / ext_impl.h / mom_impl.h.  XRS_FOCAL_EXACT_MOMENTS keeps
+    // the float64 column walkers (mean / var / std within ~1 ulp of the reference's float64 accumulators, ~2x the time);
+    // XRS_FOCAL_SEQUENTIAL_SUM keeps `sum` on the kernel that adds the taps in the reference's order in float32 (bit-exact
+    // with numba's nansum) instead of rounding the exact sum once.  (`make AB=1`: XRS_FOCAL_GEN=1 / 2 select the first /
+    // second generation for A/B runs.)
+    if (flags & ~(unsigned)(XRS_FOCAL_EXACT_MOMENTS | XRS_FOCAL_SEQUENTIAL_SUM)) return fail("xrs_focal_stats_f32_ex: unknown flag bits 0x%x", flags);
+    const char *gen = ab_env("XRS_FOCAL_GEN");
+    const bool gen1 = (flags & XRS_FOCAL_EXACT_MOMENTS) || (gen && gen[0] == '1');
+    const bool seq_sum = (flags & XRS_FOCAL_SEQUENTIAL_SUM) != 0;
     const unsigned m_mean = 1u << XRS_STAT_MEAN, m_sum = 1u << XRS_STAT_SUM;
     if (!gen1 && krows == kcols && krows >= 7 && !(stat_mask & ~(m_mean | m_sum)) && !((stat_mask & m_sum) && seq_sum)) {
         // mean and / or sum only: one 16-byte load per lane and row, float32 prefix sums (wide_impl.h)
@@ -1187,6 +1209,7 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
             // (rc < 0: neither a circle nor a box of radius 4..12 -- the kernels below)
         }
     }
+#ifdef XRS_AB
     if (gen && gen[0] == '2' && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
         float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
         const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
@@ -1217,7 +1240,8 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
             return fail("xrs_focal_stats_f32: no sequential-sum kernel for this mask");
         }
     }
-    if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !getenv("XRS_FOCAL_MEAN_RUNS")) {
+#endif
+    if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !ab_env("XRS_FOCAL_MEAN_RUNS")) {
         // circles and boxes, 7x7 .. 25x25: column walker (running float64 sums over centred runs)
         const int rc = try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,
                                     krows, kcols, halo_top, halo_bot, s);
@@ -1275,7 +1299,7 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
             return launch_focal<0, 0, 2>(a, vec, lds, s);
         }
     }
-    if (stat_mask == (1u << XRS_STAT_MEAN) && !prefer_lds() && !getenv("XRS_FOCAL_MEAN_DIRECT") &&
+    if (stat_mask == (1u << XRS_STAT_MEAN) && !prefer_lds() && !ab_env("XRS_FOCAL_MEAN_DIRECT") &&
         pass_has_compile_time_mask(kernel, krows, kcols)) {
         // circle_kernel(1, 1, 2) / np.ones((3, 3)): the strip kernel of pass.hip without terrain products -- compile-time
         // mask, shared row sums (XRS_FOCAL_MEAN_DIRECT=1: this file's run-time-mask kernel, A/B runs)
@@ -1283,7 +1307,7 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
                                    rows, cols, ld_in, ld_out, 1.0, 1.0, 0.0, 0.0, halo_top, halo_bot, stream);
     }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
-    if (krows <= 7 && krows == kcols && (krows >= 5 || getenv("XRS_FOCAL_WALK3")) && !prefer_strip()) {
+    if (krows <= 7 && krows == kcols && (krows >= 5 || ab_env("XRS_FOCAL_WALK3")) && !prefer_strip()) {
         // small circles / boxes (5x5, 7x7): all requested statistics from one column-walker kernel
         const bool f32_stats = a.out[XRS_STAT_SUM] || a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
         const int rc = f32_stats

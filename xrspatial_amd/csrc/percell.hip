@@ -169,7 +169,7 @@ template <int K>
 int launch(const CellArgs &q, hipStream_t s) {
     if (q.n <= 0) return 0;
     const bool vec = aligned16(q.a) && aligned16(q.b) && aligned16(q.out) && (Bands<K>::n != 3 || aligned16(q.c));
-    const char *variant = getenv("XRS_PERCELL_VARIANT");
+    const char *variant = ab_env("XRS_PERCELL_VARIANT");
     if (vec && !(variant && variant[0] == 'g')) {              // default: one-shot chunks ('g' = grid-stride, for A/B)
         const long n_chunks = ((q.n >> 2) + 1023) / 1024 > 0 ? ((q.n >> 2) + 1023) / 1024 : 1;
         hipLaunchKernelGGL((percell_chunk_kernel<K>), dim3((unsigned)xcd_grid(n_chunks, 1)), dim3(256), 0, s, q, n_chunks);

@@ -220,7 +220,7 @@ int launch_strip_rb(TerrainArgs &a, hipStream_t s);
 
 template <int OPS, typename HillT>
 int launch_strip(TerrainArgs &a, hipStream_t s) {
-    const char *e = getenv("XRS_TERRAIN_RB");        // A/B knob: rows per wave (default 4)
+    const char *e = ab_env("XRS_TERRAIN_RB");        // A/B knob: rows per wave (default 4)
     if (e && e[0] == '2') return launch_strip_rb<OPS, HillT, 2>(a, s);
     if (e && e[0] == '8') return launch_strip_rb<OPS, HillT, 8>(a, s);
     return launch_strip_rb<OPS, HillT, 4>(a, s);
@@ -246,7 +246,7 @@ int terrain_dispatch(TerrainArgs &a, int ops, bool hill_f64, hipStream_t s) {
     if (a.halo_top < 0 || a.halo_bot < 0) return fail("terrain: negative halo");
     // the strip kernels take any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane);
     // XRS_TERRAIN_VARIANT=cell forces the one-cell-per-thread kernel (A/B, and the oracle of the ragged path's tests)
-    const char *variant = getenv("XRS_TERRAIN_VARIANT");
+    const char *variant = ab_env("XRS_TERRAIN_VARIANT");
     const bool fast = !(variant && variant[0] == 'c');
     if (fast) {
         switch (ops) {

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/xrs_hip.h"
@@ -39,6 +40,17 @@ inline int fail(const char *fmt, ...) {
             return ::xrs::fail("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
                                __FILE__, __LINE__);                                    \
     } while (0)
+
+// A/B switches (XRS_FOCAL_GEN, XRS_CONV_GEN, XRS_RIM_FIRST ...) exist only in `make AB=1` builds: the default library
+// reads no environment variable on a launch path -- ab_env() is a constant there and every branch behind it folds away.
+#ifdef XRS_AB
+inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+constexpr const char *ab_env(const char *) { return nullptr; }
+#endif
+
+// Run-time options of the library (xrs_set_option / xrs_get_option, include/xrs_hip.h): process-wide, relaxed atomics.
+int option_value(int key);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -361,11 +361,11 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
         // XRS_ZONAL_NT=256 / XRS_ZONAL_CHUNKS=n: the round-2 geometry, for A/B runs.
         const bool big = smem > 64 * 1024;                        // one workgroup per CU
         bool wide = true;
-        if (const char *e = getenv("XRS_ZONAL_NT")) wide = atoi(e) != 256;
+        if (const char *e = ab_env("XRS_ZONAL_NT")) wide = atoi(e) != 256;
         const int nt = (big || wide) ? 1024 : 256;
         long grid = ((vec ? (n + 3) / 4 : n) + nt - 1) / nt;
         long cap = big ? 256L : wide ? 512L : 256L * 8;
-        if (const char *e = getenv("XRS_ZONAL_CHUNKS")) cap = atol(e) > 0 ? atol(e) : cap;
+        if (const char *e = ab_env("XRS_ZONAL_CHUNKS")) cap = atol(e) > 0 ? atol(e) : cap;
         if (grid > cap) grid = cap;
         if (n / grid >= (1L << 32)) grid = n / ((1L << 32) - 1) + 1;  // a u32 per-workgroup count cannot overflow
         grid = xcd_grid(grid, 1);                                 // multiple of 8: chunk <-> XCD mapping is a bijection
@@ -382,7 +382,7 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
                 if (dev >= 0 && dev < 64) attr_done |= 1ull << dev;
             }
-            static const int big_slots = getenv("XRS_ZONAL_BIG_SLOTS") ? atoi(getenv("XRS_ZONAL_BIG_SLOTS")) : 4;
+            static const int big_slots = ab_env("XRS_ZONAL_BIG_SLOTS") ? atoi(ab_env("XRS_ZONAL_BIG_SLOTS")) : 4;
             if (big && vec && big_slots == 4) {
                 if (dev < 0 || dev >= 64 || !(attr_big >> dev & 1)) {
                     XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&zonal_kernel<VT, true, true, 1024, 4>),

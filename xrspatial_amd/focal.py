@@ -20,6 +20,32 @@ from .utils import ArrayTypeFunctionMapping
 _STAT_INDEX = {'mean': 0, 'max': 1, 'min': 2, 'range': 3, 'std': 4, 'var': 5, 'sum': 6}
 
 
+# Accuracy options of the large-window statistics (include/xrs_hip.h: xrs_focal_stats_f32_ex).  Windows of 9x9 cells and
+# more run float32 walkers whose mean / var / std / sum agree with the reference's float64 accumulators to <= 2e-6 relative
+# (a per-output guard sends ill-conditioned tiles to the exact kernels).  Set
+#   options['moments'] = 'exact'      (or XRS_FOCAL_MOMENTS=exact)      float64 running sums for mean / var / std: ~1 ulp;
+#   options['sum'] = 'sequential'     (or XRS_FOCAL_SUM=sequential)     `sum` bit-identical to numba's float32 nansum
+# to keep whole launches on the exact kernels (about 2x the time).
+options = {'moments': 'fast', 'sum': 'rounded'}
+_FLAG_EXACT_MOMENTS, _FLAG_SEQUENTIAL_SUM = 1, 2
+
+
+def _focal_flags():
+    import os
+    moments = os.environ.get('XRS_FOCAL_MOMENTS', options['moments'])
+    sums = os.environ.get('XRS_FOCAL_SUM', options['sum'])
+    if moments not in ('fast', 'exact'):
+        raise ValueError(f"focal moments option must be 'fast' or 'exact', got {moments!r}")
+    if sums not in ('rounded', 'sequential'):
+        raise ValueError(f"focal sum option must be 'rounded' or 'sequential', got {sums!r}")
+    return (_FLAG_EXACT_MOMENTS if moments == 'exact' else 0) | (_FLAG_SEQUENTIAL_SUM if sums == 'sequential' else 0)
+
+
+def _stats_call(in_ptr, ptrs, mask, rows, cols, ld_in, ld_out, k, work, ht, hb, stream):
+    _lib.call("xrs_focal_stats_f32_ex", in_ptr, ptrs, mask, rows, cols, ld_in, ld_out, k.ctypes.data, k.shape[0], k.shape[1],
+              work.ptr if work is not None else None, ht, hb, _focal_flags(), stream)
+
+
 class _BuiltinReducer:
     """Stands in for the reference's `@ngjit _calc_*` functions (focal.py:268-302).
 
@@ -65,8 +91,7 @@ def _focal_stats_hip(data, kernel, stats, stacked=None):
         mask |= 1 << _STAT_INDEX[s]
     stream = get_stream()
     work = _window_workspace(k)
-    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, ld, ld, k.ctypes.data,
-              k.shape[0], k.shape[1], work.ptr if work is not None else None, 0, 0, stream)
+    _stats_call(src.ptr, ptrs, mask, rows, cols, ld, ld, k, work, 0, 0, stream)
     if work is not None:
         _lib.call("xrs_stream_sync", stream)          # (the workspace must outlive the launch)
     if like_numpy:
@@ -88,8 +113,7 @@ def _focal_stats_banded(host, kernel, stats):
         ptrs = (ctypes.c_void_p * 7)()
         for s, ptr in zip(stats, out_ptrs):
             ptrs[_STAT_INDEX[s]] = ptr
-        _lib.call("xrs_focal_stats_f32", in_ptr, ptrs, mask, n_rows, cols, cols, cols, k.ctypes.data, k.shape[0],
-                  k.shape[1], work.ptr if work is not None else None, ht, hb, stream)
+        _stats_call(in_ptr, ptrs, mask, n_rows, cols, cols, cols, k, work, ht, hb, stream)
 
     work = _window_workspace(k)      # (alive until pipelined_rows has drained its streams)
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
@@ -115,8 +139,7 @@ def _apply_sharded(data, kernel, stat):
     ptrs = (ctypes.c_void_p * 7)()
     ptrs[_STAT_INDEX[stat]] = out.ptr
     work = _window_workspace(k)
-    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k.ctypes.data,
-              k.shape[0], k.shape[1], work.ptr if work is not None else None, ht, hb, stream)
+    _stats_call(src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k, work, ht, hb, stream)
     if work is not None:
         _lib.call("xrs_stream_sync", stream)
     return out
@@ -137,8 +160,7 @@ def _focal_stats_sharded(data, kernel, stats):
         ptrs[_STAT_INDEX[s]] = arr.ptr
         mask |= 1 << _STAT_INDEX[s]
     work = _window_workspace(k)
-    _lib.call("xrs_focal_stats_f32", src.ptr, ptrs, mask, rows, cols, cols, cols, k.ctypes.data, k.shape[0], k.shape[1],
-              work.ptr if work is not None else None, ht, hb, stream)
+    _stats_call(src.ptr, ptrs, mask, rows, cols, cols, cols, k, work, ht, hb, stream)
     if work is not None:
         _lib.call("xrs_stream_sync", stream)
     return outs

@@ -627,8 +627,10 @@ def _sharded_dense_index(arr, what):
     lut = np.where(mask, np.cumsum(mask, dtype=np.int64) - 1, -1).astype(np.int32)
     uniq = (np.flatnonzero(mask).astype(np.float64) + lo).astype(loc.dtype)
     idx = DeviceArray(loc.shape, np.int32)
-    _lib.call("xrs_zonal_index", loc.ptr, code, loc.size, float(lo), rng, DeviceArray.from_numpy(lut).ptr, idx.ptr, stream)
+    lut_dev = DeviceArray.from_numpy(lut)          # named: the kernel reads it until the sync below (a temporary's block
+    _lib.call("xrs_zonal_index", loc.ptr, code, loc.size, float(lo), rng, lut_dev.ptr, idx.ptr, stream)   # would be recycled)
     _lib.call("xrs_stream_sync", stream)
+    del lut_dev
     return uniq, idx
 
 

@@ -164,7 +164,7 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             double d[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
-            if (CMASK != 0u && KH <= 8 && XRS_PASS_SHARED_ROWS && (OPS & (OP_SLOPE | OP_ASPECT)) != (OP_SLOPE | OP_ASPECT)) {
+            if (CMASK != 0u && KH <= 8 && XRS_PASS_SHARED_ROWS && !(OPS & OP_ASPECT)) {
                 // shared row sums (make_row_plan): every distinct row pattern once per input row.  Same-box A/B: hillshade + 5x5
                 // mean 0.577 -> 0.570 ms, + slope 0.808 -> 0.798; NOT for the instantiation with slope AND aspect, which the row sums
                 // push from 168 to 178 VGPRs = from 3 to 2 waves per SIMD (all four products + mean: 1.19 -> 1.37 ms)
@@ -339,14 +339,18 @@ int launch_pass(PassArgs &a, hipStream_t s) {
 // Instantiated product sets.  The focal mean fuses well with every terrain product (measured on 16384^2:
 // hillshade+focal 0.57 ms vs 0.79 ms as two launches, hillshade+slope+focal 0.84 vs 1.19).  Round 1 left aspect to
 // terrain.hip (its library atan2 on top of float64 Horn sums made the fused kernel VALU-bound); with the float32 Horn
-// sums and atan2_fast of terrain_cells.h it rides along: any set with aspect takes the all-four instantiation (absent
-// products skipped by wave-uniform tests).
+// sums and the octant-folded arc tangent of terrain_cells.h it rides along (own instantiations for aspect alone and
+// aspect + hillshade; any other set with aspect takes the all-four instantiation).
 constexpr int FUSABLE = OP_SLOPE | OP_ASPECT | OP_CURV | OP_HILL;
 
 template <int K>
 int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
-    if (ops & OP_ASPECT) return launch_pass<FUSABLE, K>(a, s);
     switch (ops) {
+        // aspect alone / with hillshade: their own instantiations (the all-four kernel's 168 VGPRs are slope + aspect +
+        // curvature together); every other set with aspect takes the all-four kernel, absent products skipped by
+        // wave-uniform tests
+        case OP_ASPECT: return launch_pass<OP_ASPECT, K>(a, s);
+        case OP_ASPECT | OP_HILL: return launch_pass<OP_ASPECT | OP_HILL, K>(a, s);
         case 0: return launch_pass<0, K>(a, s);                              // the focal mean alone (compile-time masks only)
         case OP_HILL: return launch_pass<OP_HILL, K>(a, s);
         case OP_SLOPE: return launch_pass<OP_SLOPE | OP_HILL, K>(a, s);     // (absent hillshade skipped by a wave-uniform test;
@@ -356,7 +360,9 @@ int launch_pass_ops(PassArgs &a, int ops, hipStream_t s) {
         case OP_CURV | OP_HILL: return launch_pass<OP_CURV | OP_HILL, K>(a, s);
         case OP_SLOPE | OP_CURV: return launch_pass<OP_SLOPE | OP_CURV, K>(a, s);
         case OP_SLOPE | OP_CURV | OP_HILL: return launch_pass<OP_SLOPE | OP_CURV | OP_HILL, K>(a, s);
-        default: return fail("raster pass: internal error, product set %d has no fused kernel", ops);
+        default:
+            if (ops & OP_ASPECT) return launch_pass<FUSABLE, K>(a, s);
+            return fail("raster pass: internal error, product set %d has no fused kernel", ops);
     }
 }
 

@@ -147,9 +147,29 @@ __device__ __forceinline__ float slope_cell(const Nb &q, double inv8cx, double i
 __device__ __forceinline__ float aspect_from_horn(const Horn &g) {
 #pragma clang fp contract(off)
     const float fx = (float)g.gx, fy = (float)g.gy;
-    if (fx == 0.0f && fy == 0.0f) return -1.0f;
-    const float deg = atan2_fast(-fx, -fy) * 57.29577951308232f;
-    return deg < 0.0f ? deg + 360.0f : deg;
+    // compass = atan2(y, x) in degrees wrapped to [0, 360) with y = -fx, x = -fy.  The octant folding of atan2_fast with
+    // (a) the radian -> degree factor D folded into the polynomial (D atan z = z (D + t D p(t)), as in slope_from_horn) and
+    // (b) the sign of y applied as 360 - r instead of copysign + "negative: add 360": the same value (360 + (-r) is the same
+    // float32 operation) in three instructions fewer per cell.
+    const float ax = fabsf(fy), ay = fabsf(fx);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float z = mn * __builtin_amdgcn_rcpf(mx);
+    z = (mn == mx) ? 1.0f : z;                               // (45 degrees exactly; inf / inf)
+    const float t = z * z;
+    float p = 2.920402046e-03f * 57.29577951f;
+    p = fmaf(p, t, -1.636684009e-02f * 57.29577951f);
+    p = fmaf(p, t, 4.321022630e-02f * 57.29577951f);
+    p = fmaf(p, t, -7.552088772e-02f * 57.29577951f);
+    p = fmaf(p, t, 1.066595276e-01f * 57.29577951f);
+    p = fmaf(p, t, -1.421104430e-01f * 57.29577951f);
+    p = fmaf(p, t, 1.999377186e-01f * 57.29577951f);
+    p = fmaf(p, t, -3.333315272e-01f * 57.29577951f);
+    float r = z * fmaf(p, t, 57.29577951f);                 // D atan(z), 0 .. 45 degrees
+    r = ay > ax ? 90.0f - r : r;
+    r = fy > 0.0f ? 180.0f - r : r;                          // x = -fy < 0
+    r = fx > 0.0f ? 360.0f - r : r;                          // y = -fx < 0
+    r = __builtin_isunordered(fx, fy) ? nan_f32() : r;       // (fmax / fmin skip a NaN operand)
+    return (fx == 0.0f && fy == 0.0f) ? -1.0f : r;
 }
 
 __device__ __forceinline__ float aspect_cell(const Nb &q) { return aspect_from_horn(horn_cell(q)); }

@@ -54,7 +54,7 @@ SYM_FUSED = "raster_pass_kernel<8, 5, 5, 4, true, 4685252u>"
 SYM_FOCAL5 = "focal_mean_direct_kernel<5, 5, 4, 0u>"
 SYM_HILL = "terrain_strip_kernel<8, float, 4>"
 SYM_S64 = "raster_pass_kernel<9, 5, 5, 4, true, 4685252u>"
-SYM_ZONAL = "zonal_kernel"
+SYM_ZONAL = "zonal_kernel<float, true, true, 1024, 2>"     # (1000 zones: 2 table slots per lane)
 
 
 class Ctx:
@@ -72,12 +72,18 @@ class Ctx:
             args.gpus = self.world
         os.environ.setdefault("XRS_DEVICE", str(self.local_rank))
         # The multi-process environment is the launcher's business: nothing is set here unless asked for.
-        #   XRS_BENCH_SET_RCCL_ENV=1  -> defaults for a single node whose launcher exported nothing:
+        #   XRS_BENCH_SET_RCCL_ENV=1  -> defaults for a single node whose launcher exported nothing (implied when MASTER_ADDR
+        #                                is loopback; =0 switches them off):
         #                                HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) and NCCL_SOCKET_IFNAME=lo (bootstrap
         #                                over loopback); existing values are never overridden.
         # The effective values are printed in config.rccl_env of every N > 1 line and by --dry-rccl.
         self.env_set = []
-        if self.world > 1 and os.environ.get("XRS_BENCH_SET_RCCL_ENV", "") == "1":
+        # A launcher that rendezvouses over loopback (the driver's `--master-addr 127.0.0.1`) is a single node: there the two
+        # single-node defaults are applied up front unless XRS_BENCH_SET_RCCL_ENV=0 -- a wrong bootstrap interface makes
+        # ncclCommInitRank HANG rather than fail, and a hang never reaches the retry below.
+        loopback = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1")
+        want_defaults = os.environ.get("XRS_BENCH_SET_RCCL_ENV", "1" if loopback else "")
+        if self.world > 1 and want_defaults == "1":
             for k, v in (("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ("NCCL_SOCKET_IFNAME", "lo")):
                 if k not in os.environ:
                     os.environ[k] = v
@@ -271,8 +277,11 @@ def traffic_for(ctx, symbol, rows, cols, default_shape):
     """HBM bytes per launch of `symbol` from the PMC table -- only if it was collected on the build that is loaded and on
     this raster shape; otherwise None (with the reason)."""
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    scale = None
     if (rows, cols) != default_shape:
-        return None, "not the profiled raster shape"
+        if default_shape is not None:
+            return None, "not the profiled raster shape"
+        scale = True          # the strong-scaling workloads: the profiled launch's bytes PER CELL x this rank's cells (stated)
     try:
         table = json.load(open(tfile))
     except Exception:                                 # noqa: BLE001
@@ -283,7 +292,25 @@ def traffic_for(ctx, symbol, rows, cols, default_shape):
     ent = table.get("kernels", {}).get(symbol)
     if not ent:
         return None, f"no PMC entry for {symbol}"
+    if scale:
+        n = int(table.get("_size", 16384))
+        per_cell = float(ent["hbm_bytes"]) / (float(n) * n)
+        return int(per_cell * rows * cols), (f"rocprofv3 --pmc on build {have} ({table.get('_source')}): {per_cell:.3f} B/cell measured on "
+                                             f"{n}x{n}, times this rank's {rows}x{cols} cells (halo rows: O(1/rows), not counted)")
     return int(ent["hbm_bytes"]), f"rocprofv3 --pmc on build {have} ({table.get('_source')})"
+
+
+def n1_reference(ctx, workload):
+    """ms per step of the same strong-scaling workload on ONE GPU, from profiles/n1_strong.json (written by
+    `bench.py --workload ... --write-n1` on a 1-GPU box, committed): lets an N > 1 line state its speed-up
+    (north_star: >= 6x at 8 GPUs) by itself."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "n1_strong.json")))
+        ent = table[workload]
+        return float(ent["ms_per_step"]), (f"profiles/n1_strong.json: {ent['ms_per_step']} ms on 1 GPU, build {ent.get('build_id')}"
+                                           + ("" if ent.get("build_id") == ctx._lib.build_id() else " (an EARLIER build than the one loaded)"))
+    except Exception as exc:                          # noqa: BLE001
+        return None, f"profiles/n1_strong.json unusable: {exc!r}"[:200]
 
 
 # =====================================================================================================
@@ -660,6 +687,12 @@ def run_s64(ctx, steps=None, warmup=None, brief=False):
         "algorithmic_gbs_per_gpu": round(alg * rows * cols / (dev_ms * 1e-3) / 1e9, 1),
         "halo_check": halo_check,
     }
+    if args.s64_size == 65536:
+        out["traffic_rank0"], out["traffic_from"] = traffic_for(ctx, SYM_S64, rows, cols, None)
+        if world > 1:
+            n1, src = n1_reference(ctx, "s64")
+            out["speedup_vs_n1"] = None if n1 is None else round(n1 / (elapsed / steps * 1e3), 3)
+            out["speedup_vs_n1_from"] = src
     if world == 1:
         # the north_star bar: >= 70 % of the MEASURED copy bandwidth at 65536^2, fused and as three calls
         copy_gbs = ctx.copy_bandwidth(dem_ptr, o_hill.ptr, rows * cols)
@@ -757,6 +790,12 @@ def run_zonal32k(ctx, steps=None, warmup=None, brief=False):
                       ("host-staged over gloo (--allow-host-halo)" if world > 1 else "none (one GPU)")),
         "counts_bit_exact_vs_host": counts_ok, "total_count": int(got.sum()),
     }
+    if args.zonal_size == 32768:
+        out["traffic_rank0"], out["traffic_from"] = traffic_for(ctx, SYM_ZONAL, rows, cols, None)
+        if world > 1:
+            n1, src = n1_reference(ctx, "zonal32k")
+            out["speedup_vs_n1"] = None if n1 is None else round(n1 / (elapsed / steps * 1e3), 3)
+            out["speedup_vs_n1_from"] = src
     if not counts_ok:
         out["count_mismatches"] = int(np.count_nonzero(got != want))
     del vals, zones
@@ -818,12 +857,14 @@ def cpu_baseline(cols, kernel):
            "whole_raster_estimate_s": round(65536.0 * 65536.0 / (dem.size / (t3 - t0)), 0)}
     zrows = zcols = 4096
     vals = synth.asv_dem(zrows, zcols)
-    zones = synth.block_zones(zrows, zcols, n_zones=1000, block=128)
+    zones = synth.block_zones(zrows, zcols, n_zones=1000, block=1024)      # the GPU line's layout: 1024 x 1024-cell blocks
     t0 = time.perf_counter()
     orc.zonal_stats(zones, vals, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
     t1 = time.perf_counter()
     z32 = {"value": round(vals.size / (t1 - t0) / 1e6, 2), "unit": "Mcells/s", "cores": 1, "kind": "port",
-           "sample": f"a {zrows}x{zcols} raster ({vals.size / 1e6:.0f} Mcells = 1/64 of the 32768^2 one), 1000 zones: the restated "
+           "sample": f"a {zrows}x{zcols} raster ({vals.size / 1e6:.0f} Mcells = 1/64 of the 32768^2 one) with the same 1024x1024-cell zone blocks "
+                     f"(this corner holds 16 of the 1000 zone ids; the NumPy path's cost is the two argsorts over all cells, not the "
+                     f"number of zones): the restated "
                      f"NumPy path of the reference (two argsorts + per-zone NumPy reductions, zonal.py:121-163) in {t1 - t0:.1f} s; "
                      f"O(n log n), so the full raster runs at a slightly LOWER rate than this sample"}
     return {
@@ -911,6 +952,9 @@ def main():
     ap.add_argument("--per-step-events", action="store_true",
                     help="fused mode: bracket every launch with its own pair of HIP events (default: ONE pair around the "
                          "K timed launches; --unfused always uses per-kernel events)")
+    ap.add_argument("--write-n1", default="", metavar="PATH|1",
+                    help="N = 1, --workload s64|zonal32k: record ms per step in profiles/n1_strong.json (or PATH) -- the reference "
+                         "the N > 1 lines quote their speed-up against")
     ap.add_argument("--dry-rccl", action="store_true",
                     help="N > 1: only rendezvous, one halo exchange, one all-reduce and their checks; prints what RCCL "
                          "reports about the communicator (a 30-second run that tells init problems from perf problems)")
@@ -935,8 +979,21 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": SYM_S64 if args.workload == "s64" else SYM_ZONAL,
                              "achieved": body.get("algorithmic_gbs_per_gpu"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": None if body.get("algorithmic_gbs_per_gpu") is None else round(body["algorithmic_gbs_per_gpu"] / HBM_PEAK_GBS, 4),
-                             "traffic": None},
+                             "traffic": body.get("traffic_rank0"), "traffic_from": body.get("traffic_from")},
             }
+            if ctx.world > 1:
+                result["speedup_vs_n1"] = body.get("speedup_vs_n1")
+            elif args.write_n1 and ((args.workload == "s64" and args.s64_size == 65536) or
+                                    (args.workload == "zonal32k" and args.zonal_size == 32768)):
+                path = os.path.join(ROOT, "profiles", "n1_strong.json")
+                try:
+                    table = json.load(open(path))
+                except Exception:                     # noqa: BLE001
+                    table = {}
+                table[args.workload] = {"ms_per_step": body.get("ms_per_step"), "mcells_s": body.get("mcells_s"),
+                                        "build_id": ctx._lib.build_id(), "steps": args.steps}
+                with open(args.write_n1 if args.write_n1 != "1" else path, "w") as fh:
+                    json.dump(table, fh, indent=1, sort_keys=True)
     if ctx.rank == 0 and result is not None:
         print(json.dumps(result), flush=True)
     ctx.barrier()

@@ -108,7 +108,7 @@ def call(name, *a):
             _stencil(lambda v: orc.focal_apply(v, kern, 'mean'), i, o_f, rows, cols, ld_i, ld_o, ht, hb)
     elif name in ("xrs_focal_stats_f32", "xrs_focal_stats_f32_ex"):
         if name.endswith("_ex"):
-            a = a[:13] + a[14:]                      # (accuracy flags: the oracle is exact either way)
+            a = a[:11] + a[12:14] + a[15:]           # (workspace size, accuracy flags: the oracle is exact either way)
         i, outs, mask, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
         kern = _kernel(k, kr, kc)
         for idx, stat in enumerate(orc.FOCAL_STATS):
@@ -119,7 +119,9 @@ def call(name, *a):
         excl = tuple(float(v) for v in _arr(ex, nex, np.float64)) if nex else ()
         view = _plane(i, rows, cols, ld_i, ht, hb, np.float64 if is64 else np.float32).copy()
         _put(o, rows, cols, ld_o, orc.focal_mean3x3(view, excl)[ht:ht + rows], np.float64)
-    elif name == "xrs_convolve2d_f32":
+    elif name in ("xrs_convolve2d_f32", "xrs_convolve2d_f32_ex"):
+        if name.endswith("_ex"):
+            a = a[:10] + a[11:]                      # (workspace size)
         i, o, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
         kern = _kernel(k, kr, kc)
         _stencil(lambda v: orc.convolve_2d(v, kern), i, o, rows, cols, ld_i, ld_o, ht, hb)
@@ -249,6 +251,10 @@ def call(name, *a):
 class _FakeLib:
     @staticmethod
     def xrs_kxk_workspace_bytes(kr, kc):
+        return 16
+
+    @staticmethod
+    def xrs_focal_workspace_bytes(rows, cols, kr, kc):
         return 16
 
     @staticmethod

@@ -598,6 +598,83 @@ def test_flat_windows_have_exactly_zero_variance():
                                        equal_nan=True, err_msg=f"{name} {stat}")
 
 
+@pytest.mark.parametrize("K", [9, 15, 25])
+def test_separable_box_walk(K):
+    """np.ones((k, k)) -- the masks of the reference's own benchmark suite -- through the separable walk of boxsep.hip
+    (float64 running column sums, wave-wide prefix across) in front of the float32 walkers: a raster of several tiles,
+    called through the C ABI with a workspace so that the tile map can be read back -- clean tiles (interior AND raster
+    edge) must be the fast walk's own work (map byte 0), tiles that see a NaN / inf cell or a lake away from the shift must
+    be handed on (byte 1) -- and every statistic against the oracle everywhere, to the float32 rounding of float64 results."""
+    import ctypes
+    from xrspatial_amd import _lib
+    L = _lib.call
+    R = K // 2
+    k = np.ones((K, K))
+    rows, cols = 700, 1500
+    z = synth.smooth_dem((rows, cols), seed=K)
+    lib = _lib.load()
+    nbytes = int(lib.xrs_focal_workspace_bytes(rows, cols, K, K))
+    span = (K * K * 8 + 255) & ~255
+
+    def run(zz, mask, first=0, n=None, ht=0, hb=0):
+        n = zz.shape[0] if n is None else n
+        full = xs.DeviceArray.from_numpy(zz)
+        outs = {i: xs.DeviceArray((n, cols), np.float32) for i in range(7) if mask >> i & 1}
+        ptrs = (ctypes.c_void_p * 7)()
+        for i, o in outs.items():
+            ptrs[i] = o.ptr
+        work = xs.DeviceArray((nbytes,), np.uint8)
+        L("xrs_memset", work.ptr, 0, nbytes, None)          # (the launch clears the part of the map it uses; the rest stays 0)
+        L("xrs_focal_stats_f32_ex", full.ptr + first * cols * 4, ptrs, mask, n, cols, cols, cols, k.ctypes.data, K, K, work.ptr,
+          nbytes, ht, hb, 0, None)
+        L("xrs_stream_sync", None)
+        return {i: o.get() for i, o in outs.items()}, work.get()[span:]
+
+    names = {0: 'mean', 4: 'std', 5: 'var', 6: 'sum'}
+
+    def check(got, zz, lo, hi, what):
+        with np.errstate(all='ignore'):
+            for i, arr in got.items():
+                want = corc.focal_apply(zz, k, names[i], nthreads=8)[lo:hi]
+                if names[i] == 'sum':
+                    check_window_sum(arr, zz, k, f"{what} sum") if lo == 0 and hi == zz.shape[0] else None
+                    np.testing.assert_allclose(arr, want, rtol=1e-5, equal_nan=True, err_msg=f"{what} sum")
+                else:
+                    np.testing.assert_allclose(arr, want, rtol=3e-7, atol=0, equal_nan=True, err_msg=f"{what} {names[i]}")
+
+    # ---- a clean raster: every tile is the fast walk's (mean alone -> the wide kernel's map; moments -> the moments kernel's)
+    for mask in (1, 1 | 16 | 32, 1 | 16 | 32 | 64, 64):
+        got, todo = run(z, mask)
+        assert not todo.any(), f"clean raster, mask {mask}: tiles handed on: {np.flatnonzero(todo)}"
+        check(got, z, 0, rows, f"clean mask={mask}")
+        for i, arr in got.items():
+            parity_log.record('700x1500 clean', f'box {K}x{K} separable walk: {names[i]}', arr, corc.focal_apply(z, k, names[i], nthreads=8))
+    # ---- row shards with halo rows in the same allocation (interior tiles need the halo, edge tiles clip)
+    for first, n, ht, hb in ((200, 300, R, R), (0, 250, 0, R), (450, 250, R, 0)):
+        got, todo = run(z, 1 | 32, first, n, ht, hb)
+        assert not todo.any()
+        check(got, z, first, first + n, f"shard {first}+{n}")
+    # ---- tiles the fast walk must hand on: a NaN cell, an inf cell, a lake at a level away from the tile's shift, a flat tile
+    z2 = z.copy()
+    z2[100, 300] = np.nan
+    z2[400, 1200] = np.inf
+    z2[500:560, 600:700] = 1234.567
+    z2[0:40, 0:60] = -5.25
+    got, todo = run(z2, 1 | 16 | 32 | 64)
+    assert todo.any() and not todo.all()
+    check(got, z2, 0, rows, "holes")
+    lake = got[5][500 + R:560 - R, 600 + R:700 - R]
+    assert lake.size and (lake == 0).all()
+    np.testing.assert_array_equal(got[0][500 + R:560 - R, 600 + R:700 - R], np.float32(1234.567))
+    # ---- the same masks through the public API (workspace from the pool), convolve_2d / hotspots' normalised box included
+    pub = focal_stats(raster(z2), k, stats_funcs=['mean', 'std', 'var', 'sum'])
+    for j, i in enumerate((0, 4, 5, 6)):
+        np.testing.assert_array_equal(pub.data[j], got[i])
+    with np.errstate(all='ignore'):
+        np.testing.assert_allclose(convolve_2d(z, k / k.sum()), corc.convolve_2d(z, k / k.sum(), nthreads=8), rtol=1e-6, atol=0, equal_nan=True)
+        np.testing.assert_allclose(convolve_2d(z2, k / k.sum()), corc.convolve_2d(z2, k / k.sum(), nthreads=8), rtol=2e-6, atol=0, equal_nan=True)
+
+
 @pytest.mark.parametrize("radius", [4, 12])
 def test_exact_moments_option_and_guard_on_adversarial_rasters(radius, monkeypatch):
     """The accuracy contract of the large-window moments (focal.options, xrs_focal_stats_f32_ex): the default float32

@@ -116,7 +116,17 @@ def main():
     w25 = np.ascontiguousarray(k25 / k25.sum())
     k9 = circle_kernel(1, 1, 4)
     w9 = np.ascontiguousarray(k9 / k9.sum())
-    work = xs.DeviceArray((1 << 16,), np.uint8)
+    work = xs.DeviceArray((1 << 20,), np.uint8)       # kernel copy + tile map of the separable box walk (xrs_focal_workspace_bytes)
+    WB = work.nbytes
+    from xrspatial_amd.convolution import annulus_kernel
+    kb15, kb25 = np.ones((15, 15)), np.ones((25, 25))
+    wb25 = np.ascontiguousarray(kb25 / kb25.sum())
+    ka21 = np.ascontiguousarray(annulus_kernel(1, 1, 10, 6))       # 21x21 ring, inner radius 6
+    ka25 = np.ascontiguousarray(annulus_kernel(1, 1, 12, 4))       # 25x25 ring, inner radius 4
+
+    def fstats(k, ptrs, mask):
+        K = k.shape[0]
+        return lambda: L("xrs_focal_stats_f32_ex", dem.ptr, ptrs, mask, n, n, n, n, k.ctypes.data, K, K, work.ptr, WB, 0, 0, 0, S)
     ptr1 = (ctypes.c_void_p * 7)()
     ptr1[0] = outs[0].ptr
     ptr7 = (ctypes.c_void_p * 7)(*[o.ptr for o in outs])
@@ -219,9 +229,22 @@ def main():
         "focal3_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 8),
         "focal5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k5.ctypes.data, 5, 5, None, 0, 0, S), 32),
         "box3_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k3.ctypes.data, 3, 3, None, 0, 0, S), 32),
-        "box5_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, kb5.ctypes.data, 5, 5, None, 0, 0, S), 32),
-        "box11_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, kb11.ctypes.data, 11, 11, None, 0, 0, S), 8),
-        "box11_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, kb11.ctypes.data, 11, 11, None, 0, 0, S), 32),
+        "box5_stats7": (fstats(kb5, ptr7, 127), 32),
+        "box11_mean": (fstats(kb11, ptr1, 1), 8),
+        "box11_stats7": (fstats(kb11, ptr7, 127), 32),
+        "box11_mean_general": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, kb11.ctypes.data, 11, 11, None, 0, 0, S), 8),
+        "box15_mean": (fstats(kb15, ptr1, 1), 8),
+        "box15_stats7": (fstats(kb15, ptr7, 127), 32),
+        "box25_mean": (fstats(kb25, ptr1, 1), 8),
+        "box25_meanvarstd": (fstats(kb25, ptr7, 0b110001), 16),
+        "box25_minmaxrange": (fstats(kb25, ptr7, 0b1110), 16),
+        "box25_stats7": (fstats(kb25, ptr7, 127), 32),
+        "convolve25_box": (lambda: L("xrs_convolve2d_f32_ex", dem.ptr, outs[0].ptr, n, n, n, n, wb25.ctypes.data, 25, 25, work.ptr, WB, 0, 0, S), 8),
+        "annulus21_mean": (fstats(ka21, ptr1, 1), 8),
+        "annulus21_stats7": (fstats(ka21, ptr7, 127), 32),
+        "annulus25_mean": (fstats(ka25, ptr1, 1), 8),
+        "annulus25_stats7": (fstats(ka25, ptr7, 127), 32),
+        "focal21_stats7": (fstats(np.ascontiguousarray(circle_kernel(1, 1, 10)), ptr7, 127), 32),
         "focal7_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 8),
         "focal7_stats7": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr7, 127, n, n, n, n, k7.ctypes.data, 7, 7, None, 0, 0, S), 32),
         "focal13_mean": (lambda: L("xrs_focal_stats_f32", dem.ptr, ptr1, 1, n, n, n, n, k13.ctypes.data, 13, 13, None, 0, 0, S), 8),
@@ -261,7 +284,7 @@ def main():
     for name_, (fn, bpc) in cases.items():
         if only and name_ not in only:
             continue
-        reps = 2 if name_.startswith("focal25") else args.reps
+        reps = 3 if name_.startswith(("focal25", "annulus")) else args.reps
         med, mn = timer.time(fn, reps, warmup=2)
         gbs = cells * bpc / (med * 1e-3) / 1e9
         results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs,

@@ -91,7 +91,10 @@ _PROTOTYPES = {
     "xrs_focal_stats_f32": [c_void_p, ctypes.POINTER(c_void_p), c_uint, c_int64, c_int64, c_int64, c_int64,
                             c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "xrs_focal_stats_f32_ex": [c_void_p, ctypes.POINTER(c_void_p), c_uint, c_int64, c_int64, c_int64, c_int64,
-                               c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_uint, c_void_p],
+                               c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int, c_uint, c_void_p],
+    "xrs_focal_workspace_bytes": [c_int64, c_int64, c_int, c_int],
+    "xrs_convolve2d_f32_ex": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
+                              c_void_p, c_size_t, c_int, c_int, c_void_p],
     "xrs_focal_mean3x3_passes": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p],
     "xrs_focal_mean3x3": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
                           c_int, c_int, c_void_p],
@@ -132,7 +135,7 @@ _PROTOTYPES = {
     "xrs_allreduce_u8": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "xrs_allreduce_u64": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
 }
-_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t,
+_RESTYPES = {"xrs_kxk_workspace_bytes": c_size_t, "xrs_focal_workspace_bytes": c_size_t, "xrs_zonal_majority_workspace_bytes": c_size_t,
              "xrs_geodesic_workspace_bytes": c_size_t}
 
 EXPORTED = tuple(_PROTOTYPES)

@@ -1064,11 +1064,27 @@ size_t xrs_kxk_workspace_bytes(int krows, int kcols) {
     return (size_t)krows * kcols * sizeof(double);       // float64 weights of convolve2d
 }
 
+// the kernel copy (256-byte aligned) + the tile map of the separable box walk (boxsep.hip)
+static size_t weights_span(int krows, int kcols) { return ((size_t)krows * kcols * sizeof(double) + 255) & ~(size_t)255; }
+size_t xrs_focal_workspace_bytes(int64_t rows, int64_t cols, int krows, int kcols) {
+    if (krows <= 0 || kcols <= 0 || rows < 0 || cols < 0) return 0;
+    return weights_span(krows, kcols) + box_todo_bytes(rows, cols);
+}
+
 int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
                        int64_t ld_out, const double *kernel, int krows, int kcols, void *work_dev,
                        int halo_top, int halo_bot, void *stream) {
+    return xrs_convolve2d_f32_ex(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev,
+                                 xrs_kxk_workspace_bytes(krows, kcols), halo_top, halo_bot, stream);
+}
+
+int xrs_convolve2d_f32_ex(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                          int64_t ld_out, const double *kernel, int krows, int kcols, void *work_dev, size_t work_bytes,
+                          int halo_top, int halo_bot, void *stream) {
     if (int rc = check_common("xrs_convolve2d_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
                               halo_top, halo_bot)) return rc;
+    if (work_dev && work_bytes < xrs_kxk_workspace_bytes(krows, kcols)) return fail("xrs_convolve2d_f32_ex: workspace too small");
+    const bool box_map = work_dev && work_bytes >= xrs_focal_workspace_bytes(rows, cols, krows, kcols);
     if (!out_dev || !work_dev) return fail("xrs_convolve2d_f32: null output/workspace");
     if (rows == 0 || cols == 0) return 0;
     if (krows > MAX_K || kcols > MAX_K) {
@@ -1099,8 +1115,12 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
         }
 #endif
         rc = try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
-        if (rc < 0)
-            rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
+        if (rc < 0) {
+            // (np.ones / k^2: the separable walk of boxsep.hip in front; its tile map lives behind the weights when the caller
+            //  sized the workspace with xrs_focal_workspace_bytes)
+            unsigned char *todo = box_map ? static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) : nullptr;
+            rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s, todo);
+        }
         if (rc >= 0) return rc;
     }
     a.tiles_x = (cols + TW - 1) / TW;
@@ -1127,12 +1147,13 @@ int xrs_focal_stats_f32(const float *in_dev, float *const *outs_dev, unsigned st
                         int64_t cols, int64_t ld_in, int64_t ld_out, const double *kernel, int krows,
                         int kcols, void *work_dev, int halo_top, int halo_bot, void *stream) {
     return xrs_focal_stats_f32_ex(in_dev, outs_dev, stat_mask, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev,
-                                  halo_top, halo_bot, 0u, stream);
+                                  work_dev ? xrs_kxk_workspace_bytes(krows, kcols) : 0, halo_top, halo_bot, 0u, stream);
 }
 
 int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned stat_mask, int64_t rows,
                            int64_t cols, int64_t ld_in, int64_t ld_out, const double *kernel, int krows,
-                           int kcols, void *work_dev, int halo_top, int halo_bot, unsigned flags, void *stream) {
+                           int kcols, void *work_dev, size_t work_bytes, int halo_top, int halo_bot, unsigned flags,
+                           void *stream) {
     if (int rc = check_common("xrs_focal_stats_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
                               halo_top, halo_bot)) return rc;
     if (!outs_dev) return fail("xrs_focal_stats_f32: null outputs");
@@ -1149,9 +1170,14 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
     }
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = as_stream(stream);
-    if (krows > MAX_K || kcols > MAX_K)
+    if (krows > MAX_K || kcols > MAX_K) {
+        if (!work_dev || work_bytes < xrs_kxk_workspace_bytes(krows, kcols)) return fail("xrs_focal_stats_f32: windows beyond 63x63 need a workspace of xrs_kxk_workspace_bytes()");
         return launch_window_any_size(false, in_dev, a.out, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev, halo_top,
                                       halo_bot, s);
+    }
+    // np.ones((k, k)): scratch for the tile map of the separable walk (boxsep.hip), if the caller brought enough
+    unsigned char *const box_todo = (work_dev && work_bytes >= xrs_focal_workspace_bytes(rows, cols, krows, kcols))
+                                        ? static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) : nullptr;
     // Large circles / boxes: the float32 walkers of wide_impl.h / ext_impl.h / mom_impl.h.  XRS_FOCAL_EXACT_MOMENTS keeps
     // the float64 column walkers (mean / var / std within ~1 ulp of the reference's float64 accumulators, ~2x the time);
     // XRS_FOCAL_SEQUENTIAL_SUM keeps `sum` on the kernel that adds the taps in the reference's order in float32 (bit-exact
@@ -1168,7 +1194,7 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                                               kernel, krows, kcols, halo_top, halo_bot, s);
         if (rc < 0)
             rc = try_launch_focal_wide_box(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
-                                           kernel, krows, kcols, halo_top, halo_bot, s);
+                                           kernel, krows, kcols, halo_top, halo_bot, s, box_todo);
         if (rc >= 0) return rc;
     }
     if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
@@ -1194,7 +1220,7 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                                                  rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
                 if (rc < 0)
                     rc = try_launch_focal_mom_box(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD],
-                                                  rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+                                                  rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s, box_todo);
             }
             if (rc > 0) return rc;
             if (rc == 0) {

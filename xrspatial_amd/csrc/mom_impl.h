@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
     __shared__ __attribute__((aligned(16))) float lds_rows[4][(C::D + 1) * C::RBF];
     long ty, gx;
     if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
+    if (std::is_same<Shape, BoxShape>::value && a.todo && !a.todo[ty * a.groups_x + gx]) return;   // (boxsep.hip did this tile)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = (gx * 4 + wv) * C::TW;
@@ -468,6 +469,15 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     a.rim_first = RimFirst::mode_from_env();
     const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal moments: raster too large for one launch");
+    if (std::is_same<Shape, BoxShape>::value && a.todo) {
+        // np.ones((k, k)): the separable walk of boxsep.hip first; this kernel then redoes the tiles it marked (NaN / inf cells,
+        // flat windows away from its shift) and nothing else
+        const int rc = launch_box_sep(g.in, a.out_sum, a.out_mean, a.out_var, a.out_std, nullptr, 0.0, g.rows, g.cols, g.ld_in, g.ld_out,
+                                      C::K, C::K, g.halo_top, g.halo_bot, const_cast<unsigned char *>(a.todo), a.groups_x, a.tile_rows,
+                                      4 * C::TW, s);
+        if (rc > 0) return rc;
+        if (rc < 0) a.todo = nullptr;
+    }
     const int om = (a.out_sum ? MOM_SUM : 0) | (a.out_mean ? MOM_MEAN : 0) | (a.out_var ? MOM_VAR : 0) | (a.out_std ? MOM_STD : 0);
     constexpr int ALL = MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD, MVS = MOM_MEAN | MOM_VAR | MOM_STD;
     if (om == ALL) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, ALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
@@ -484,7 +494,7 @@ namespace xrs {
 // 0 = launched, -1 = not this shape with a radius of 4..12 cells (caller takes another kernel), > 0 = error.
 int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows, long cols,
                   long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
-                  hipStream_t s) {
+                  hipStream_t s, unsigned char *todo_dev) {
     if (krows != kcols || !(krows & 1)) return -1;
     if (!out_sum && !out_mean && !out_var && !out_std) return 0;
     MomArgs a;
@@ -492,6 +502,7 @@ int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_v
     a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
     a.out_sum = out_sum; a.out_mean = out_mean; a.out_var = out_var; a.out_std = out_std;
+    a.todo = todo_dev;
     switch (krows / 2) {
 #define XRS_MOM_CASE(RR) case RR: return launch_mom<RR, XRS_MOM_SHAPE>(a, kernel, s);
 #ifndef XRS_MOM_PROBE

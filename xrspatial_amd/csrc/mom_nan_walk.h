@@ -19,6 +19,7 @@ struct MomArgs {
     long n_groups, groups_x;      // workgroups = groups of 4 horizontally adjacent wave tiles
     int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
     int rim_first;                // work order (circle_walk.h RimFirst)
+    const unsigned char *todo;    // boxes behind boxsep.hip's fast walk: one byte per workgroup tile, 0 = nothing to do; else NULL
 };
 
 template <int R, typename Shape>

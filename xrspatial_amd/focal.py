@@ -43,7 +43,7 @@ def _focal_flags():
 
 def _stats_call(in_ptr, ptrs, mask, rows, cols, ld_in, ld_out, k, work, ht, hb, stream):
     _lib.call("xrs_focal_stats_f32_ex", in_ptr, ptrs, mask, rows, cols, ld_in, ld_out, k.ctypes.data, k.shape[0], k.shape[1],
-              work.ptr if work is not None else None, ht, hb, _focal_flags(), stream)
+              work.ptr if work is not None else None, work.nbytes if work is not None else 0, ht, hb, _focal_flags(), stream)
 
 
 class _BuiltinReducer:
@@ -90,10 +90,8 @@ def _focal_stats_hip(data, kernel, stats, stacked=None):
         ptrs[_STAT_INDEX[s]] = arr.ptr
         mask |= 1 << _STAT_INDEX[s]
     stream = get_stream()
-    work = _window_workspace(k)
+    work = _window_workspace(k, rows, cols)
     _stats_call(src.ptr, ptrs, mask, rows, cols, ld, ld, k, work, 0, 0, stream)
-    if work is not None:
-        _lib.call("xrs_stream_sync", stream)          # (the workspace must outlive the launch)
     if like_numpy:
         return {s: arr.get(stream) for s, arr in outs.items()}
     return outs
@@ -115,16 +113,21 @@ def _focal_stats_banded(host, kernel, stats):
             ptrs[_STAT_INDEX[s]] = ptr
         _stats_call(in_ptr, ptrs, mask, n_rows, cols, cols, cols, k, work, ht, hb, stream)
 
-    work = _window_workspace(k)      # (alive until pipelined_rows has drained its streams)
+    work = None if max(k.shape) <= 63 else _window_workspace(k)      # (alive until pipelined_rows has drained its streams;
+                                                                      #  the bands run on several streams: no shared tile map)
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
 
 
-def _window_workspace(k):
-    """Device workspace for windows beyond the tiled kernels' 63 x 63 (csrc/kxk_big.hip reads the mask from a device copy
-    of the kernel); None for everything smaller.  The caller keeps it alive until the launch has been synchronised."""
-    if max(k.shape) <= 63:
+def _window_workspace(k, rows=0, cols=0):
+    """Device scratch of a launch, or None: windows beyond the tiled kernels' 63 x 63 read the mask from a device copy of the
+    kernel (csrc/kxk_big.hip); np.ones((k, k)) masks -- the reference's benchmark kernels -- get the tile map of the
+    separable box walk (csrc/boxsep.hip; xrs_focal_workspace_bytes).  The block goes back to the pool behind the launch on
+    the launch's stream (device.py fences recycled blocks with an event), so nobody has to wait for it."""
+    big = max(k.shape) > 63
+    box = k.shape[0] == k.shape[1] and 7 <= k.shape[0] <= 25 and bool((k == 1.0).all())
+    if not (big or box):
         return None
-    return DeviceArray((int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])),), np.uint8)
+    return DeviceArray((int(_lib.load().xrs_focal_workspace_bytes(int(rows), int(cols), k.shape[0], k.shape[1])),), np.uint8)
 
 
 def _apply_sharded(data, kernel, stat):
@@ -138,10 +141,8 @@ def _apply_sharded(data, kernel, stat):
     out = src.like(np.float32)
     ptrs = (ctypes.c_void_p * 7)()
     ptrs[_STAT_INDEX[stat]] = out.ptr
-    work = _window_workspace(k)
+    work = _window_workspace(k, rows, cols)
     _stats_call(src.ptr, ptrs, 1 << _STAT_INDEX[stat], rows, cols, cols, cols, k, work, ht, hb, stream)
-    if work is not None:
-        _lib.call("xrs_stream_sync", stream)
     return out
 
 
@@ -159,10 +160,8 @@ def _focal_stats_sharded(data, kernel, stats):
     for s, arr in outs.items():
         ptrs[_STAT_INDEX[s]] = arr.ptr
         mask |= 1 << _STAT_INDEX[s]
-    work = _window_workspace(k)
+    work = _window_workspace(k, rows, cols)
     _stats_call(src.ptr, ptrs, mask, rows, cols, cols, cols, k, work, ht, hb, stream)
-    if work is not None:
-        _lib.call("xrs_stream_sync", stream)
     return outs
 
 

@@ -176,10 +176,6 @@ size_t xrs_kxk_workspace_bytes(int krows, int kcols);
 int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
                        int64_t ld_in, int64_t ld_out, const double *kernel, int krows, int kcols,
                        void *work_dev, int halo_top, int halo_bot, void *stream);
-/* the same with the size of the workspace stated (xrs_focal_workspace_bytes: see there) */
-int xrs_convolve2d_f32_ex(const float *in_dev, float *out_dev, int64_t rows, int64_t cols,
-                          int64_t ld_in, int64_t ld_out, const double *kernel, int krows, int kcols,
-                          void *work_dev, size_t work_bytes, int halo_top, int halo_bot, void *stream);
 
 /* focal statistics over the window cells where kernel == 1 exactly, window clipped
  * to the raster (no NaN border), NaN cells skipped; all requested statistics in ONE
@@ -205,11 +201,11 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                            int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                            const double *kernel, int krows, int kcols, void *work_dev, size_t work_bytes,
                            int halo_top, int halo_bot, unsigned flags, void *stream);
-/* Device scratch the *_ex entry points can use for a rows x cols raster: the float64 copy of the kernel
- * (xrs_kxk_workspace_bytes) plus one byte per tile for the separable box kernels -- np.ones((k, k)) masks, the ones the
- * reference's benchmark suite runs, take an O(1)-per-cell walk that hands the tiles it cannot stand for (NaN / inf cells,
- * flat windows) to the general kernel through that map.  With a smaller workspace (or none) the general kernel runs
- * everywhere: same results, more time. */
+/* Device scratch xrs_focal_stats_f32_ex can use for a rows x cols raster: the float64 copy of the kernel
+ * (xrs_kxk_workspace_bytes) plus one byte per tile for the separable box kernel -- np.ones((k, k)) masks, the ones the
+ * reference's benchmark suite runs, get their variance / standard deviation (and the mean and sum beside them) from an
+ * O(1)-per-cell walk that hands the tiles it cannot stand for (NaN / inf cells, flat windows) to the general kernel
+ * through that map.  With a smaller workspace (or none) the general kernel runs everywhere: same results, more time. */
 size_t xrs_focal_workspace_bytes(int64_t rows, int64_t cols, int krows, int kcols);
 
 /* focal.apply with a user callable (func other than the built-in reducers): the kernel-shaped float32 arrays that

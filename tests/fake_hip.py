@@ -119,9 +119,7 @@ def call(name, *a):
         excl = tuple(float(v) for v in _arr(ex, nex, np.float64)) if nex else ()
         view = _plane(i, rows, cols, ld_i, ht, hb, np.float64 if is64 else np.float32).copy()
         _put(o, rows, cols, ld_o, orc.focal_mean3x3(view, excl)[ht:ht + rows], np.float64)
-    elif name in ("xrs_convolve2d_f32", "xrs_convolve2d_f32_ex"):
-        if name.endswith("_ex"):
-            a = a[:10] + a[11:]                      # (workspace size)
+    elif name == "xrs_convolve2d_f32":
         i, o, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
         kern = _kernel(k, kr, kc)
         _stencil(lambda v: orc.convolve_2d(v, kern), i, o, rows, cols, ld_i, ld_o, ht, hb)

@@ -601,7 +601,7 @@ def test_flat_windows_have_exactly_zero_variance():
 @pytest.mark.parametrize("K", [9, 15, 25])
 def test_separable_box_walk(K):
     """np.ones((k, k)) -- the masks of the reference's own benchmark suite -- through the separable walk of boxsep.hip
-    (float64 running column sums, wave-wide prefix across) in front of the float32 walkers: a raster of several tiles,
+    (float64 running column sums, wave-wide prefix across) in front of the float32 moments walker: a raster of several tiles,
     called through the C ABI with a workspace so that the tile map can be read back -- clean tiles (interior AND raster
     edge) must be the fast walk's own work (map byte 0), tiles that see a NaN / inf cell or a lake away from the shift must
     be handed on (byte 1) -- and every statistic against the oracle everywhere, to the float32 rounding of float64 results."""
@@ -632,7 +632,7 @@ def test_separable_box_walk(K):
 
     names = {0: 'mean', 4: 'std', 5: 'var', 6: 'sum'}
 
-    def check(got, zz, lo, hi, what):
+    def check(got, zz, lo, hi, what, tol=3e-7):
         with np.errstate(all='ignore'):
             for i, arr in got.items():
                 want = corc.focal_apply(zz, k, names[i], nthreads=8)[lo:hi]
@@ -640,10 +640,11 @@ def test_separable_box_walk(K):
                     check_window_sum(arr, zz, k, f"{what} sum") if lo == 0 and hi == zz.shape[0] else None
                     np.testing.assert_allclose(arr, want, rtol=1e-5, equal_nan=True, err_msg=f"{what} sum")
                 else:
-                    np.testing.assert_allclose(arr, want, rtol=3e-7, atol=0, equal_nan=True, err_msg=f"{what} {names[i]}")
+                    np.testing.assert_allclose(arr, want, rtol=tol, atol=0, equal_nan=True, err_msg=f"{what} {names[i]}")
 
-    # ---- a clean raster: every tile is the fast walk's (mean alone -> the wide kernel's map; moments -> the moments kernel's)
-    for mask in (1, 1 | 16 | 32, 1 | 16 | 32 | 64, 64):
+    # ---- a clean raster: every tile is the fast walk's (any set of moments with var or std in it; the mean or the sum alone
+    # stay on the wide row walker)
+    for mask in (1 | 16 | 32, 1 | 16 | 32 | 64, 32, 1 | 16):
         got, todo = run(z, mask)
         assert not todo.any(), f"clean raster, mask {mask}: tiles handed on: {np.flatnonzero(todo)}"
         check(got, z, 0, rows, f"clean mask={mask}")
@@ -662,7 +663,7 @@ def test_separable_box_walk(K):
     z2[0:40, 0:60] = -5.25
     got, todo = run(z2, 1 | 16 | 32 | 64)
     assert todo.any() and not todo.all()
-    check(got, z2, 0, rows, "holes")
+    check(got, z2, 0, rows, "holes", tol=2e-6)          # (the handed-on tiles: the float32 walkers, their tolerance)
     lake = got[5][500 + R:560 - R, 600 + R:700 - R]
     assert lake.size and (lake == 0).all()
     np.testing.assert_array_equal(got[0][500 + R:560 - R, 600 + R:700 - R], np.float32(1234.567))
@@ -736,7 +737,8 @@ def test_uniform_weight_convolution_wide_walker(radius, shape_kind):
     got = convolve_2d(z, k)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=0, equal_nan=True)
     parity_log.record('700x1500', f'convolve_2d uniform {shape_kind} {K}x{K}', got, want)
-    if _lib.build_id().endswith('+ab'):              # (`make AB=1` libraries carry round 1's float64 column walker)
+    from xrspatial_amd import _lib
+    if _lib.build_id().endswith("+ab"):              # (`make AB=1` libraries carry round 1 float64 column walker)
         os.environ['XRS_CONV_GEN'] = '1'
         try:
             gen1 = convolve_2d(z, k)

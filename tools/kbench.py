@@ -239,7 +239,7 @@ def main():
         "box25_meanvarstd": (fstats(kb25, ptr7, 0b110001), 16),
         "box25_minmaxrange": (fstats(kb25, ptr7, 0b1110), 16),
         "box25_stats7": (fstats(kb25, ptr7, 127), 32),
-        "convolve25_box": (lambda: L("xrs_convolve2d_f32_ex", dem.ptr, outs[0].ptr, n, n, n, n, wb25.ctypes.data, 25, 25, work.ptr, WB, 0, 0, S), 8),
+        "convolve25_box": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, wb25.ctypes.data, 25, 25, work.ptr, 0, 0, S), 8),
         "annulus21_mean": (fstats(ka21, ptr1, 1), 8),
         "annulus21_stats7": (fstats(ka21, ptr7, 127), 32),
         "annulus25_mean": (fstats(ka25, ptr1, 1), 8),

@@ -93,8 +93,6 @@ _PROTOTYPES = {
     "xrs_focal_stats_f32_ex": [c_void_p, ctypes.POINTER(c_void_p), c_uint, c_int64, c_int64, c_int64, c_int64,
                                c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int, c_uint, c_void_p],
     "xrs_focal_workspace_bytes": [c_int64, c_int64, c_int, c_int],
-    "xrs_convolve2d_f32_ex": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
-                              c_void_p, c_size_t, c_int, c_int, c_void_p],
     "xrs_focal_mean3x3_passes": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p],
     "xrs_focal_mean3x3": [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int,
                           c_int, c_int, c_void_p],

@@ -123,11 +123,10 @@ def _convolve_2d_hip(data, kernel):
     src = to_device_f32(data)
     rows, cols, ld = plane_args(src)
     out = DeviceArray((rows, cols), np.float32)
-    # (kernel copy + the tile map of the separable box walk: np.ones / k^2 is what focal.hotspots convolves with)
-    work = DeviceArray((max(int(_lib.load().xrs_focal_workspace_bytes(rows, cols, k.shape[0], k.shape[1])), 16),), np.uint8)
+    work = DeviceArray((max(int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])), 16),), np.uint8)
     stream = get_stream()
-    _lib.call("xrs_convolve2d_f32_ex", src.ptr, out.ptr, rows, cols, ld, ld, k.ctypes.data, k.shape[0],
-              k.shape[1], work.ptr, work.nbytes, 0, 0, stream)
+    _lib.call("xrs_convolve2d_f32", src.ptr, out.ptr, rows, cols, ld, ld, k.ctypes.data, k.shape[0],
+              k.shape[1], work.ptr, 0, 0, stream)
     _lib.call("xrs_stream_sync", stream)      # `k` and `work` must outlive the launch
     return finish(out, like_numpy)
 
@@ -141,9 +140,9 @@ def _convolve_2d_sharded(data, kernel):
     ht, hb = src.halos(k.shape[0] // 2, stream)
     rows, cols = src.shape
     out = src.like(np.float32)
-    work = DeviceArray((max(int(_lib.load().xrs_focal_workspace_bytes(rows, cols, k.shape[0], k.shape[1])), 16),), np.uint8)
-    _lib.call("xrs_convolve2d_f32_ex", src.ptr, out.ptr, rows, cols, cols, cols, k.ctypes.data, k.shape[0],
-              k.shape[1], work.ptr, work.nbytes, ht, hb, stream)
+    work = DeviceArray((max(int(_lib.load().xrs_kxk_workspace_bytes(k.shape[0], k.shape[1])), 16),), np.uint8)
+    _lib.call("xrs_convolve2d_f32", src.ptr, out.ptr, rows, cols, cols, cols, k.ctypes.data, k.shape[0],
+              k.shape[1], work.ptr, ht, hb, stream)
     _lib.call("xrs_stream_sync", stream)      # `k` and `work` must outlive the launch
     return out
 

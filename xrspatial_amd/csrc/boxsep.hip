@@ -1,30 +1,37 @@
 // Separable statistics over BOX masks -- np.ones((k, k)), the kernels the reference's own benchmark suite runs
 // (benchmarks/benchmarks/focal.py:10-34: custom_kernel(np.ones(...)) for apply / focal_stats / hotspots) -- in O(1) work
-// per cell whatever k: focal mean / sum / var / std (xrspatial/focal.py:226-258 through _apply_numpy :305-326) and
-// convolve_2d with one weight value on the box (convolution.py:285-313, what focal.hotspots is fed).
+// per cell whatever k: focal var / std with the mean and the sum beside them (xrspatial/focal.py:226-258 through
+// _apply_numpy :305-326).  (The mean or the sum ALONE, and convolve_2d with one weight on the box, stay on the wide row
+// walker: this kernel measured no faster there -- 0.53 vs 0.55 ms at 25x25, 0.68 vs 0.47 at 11x11 -- its work per row is
+// a fixed ~170 instructions per wave whatever the number of moments.)
 //
 // A box is the one mask whose window sum factors: sum over the window = sum over its columns of (sum over the column's
 // rows).  So instead of 2R+1 ring additions per cell, row and moment (mom_impl.h, wide_impl.h: ~163 VALU instructions per
 // cell for the four moments at 25x25), a wave keeps ONE running column sum per column and moment:
-//   * a wave owns 256 columns x ~256 output rows and walks down; a lane owns 4 adjacent columns.  Per output row it loads
-//     the row ENTERING the window (y + ry) and the row LEAVING it (y - ry; read 2 ry + 1 rows earlier by the same wave, so
-//     it comes from L2 / the Infinity Cache, not from HBM) -- two 16-byte loads per lane, batches of 4 rows in flight;
+//   * a wave owns 64 NC columns x ~256 output rows and walks down; a lane owns NC adjacent columns.  Per output row the
+//     row ENTERING the window (y + ry) is added to the column sums and the row LEAVING it (y - ry) subtracted.  The leaving
+//     row was read 2 ry + 1 rows earlier: the rows of the window stay in a private LDS ring per wave (2 ry + 1 slots; the
+//     entering row is loaded into registers one step ahead and written to the slot of the row that just left), so every
+//     input cell is fetched ONCE.  (The first form of this kernel re-loaded the leaving row from global memory -- the chip's
+//     L2s do not hold 25 rows x all resident waves, the second read went to the fabric, and the 25x25 mean ran at 0.83 ms
+//     against 0.46 for the ring-adding walker it replaces.)  The ring is what limits residency (12.5 KiB per wave at 25x25:
+//     8 waves per CU), so a wave does TWO rows per step, their scans and prefix arrays independent of one another: the
+//     dependent chain of one row (scan, LDS round trip, float64 arithmetic: ~1000 cycles) hides behind the other's;
 //   * the column sums are FLOAT64 sums of d = v - c0 and d^2 (c0 = the cell at the tile centre): d is exact, the sums of d
 //     are exact, those of d^2 carry 2^-53 relative per update, so the add / subtract recurrence does not drift in any way
 //     float32 results can see, and the shift keeps var = (Q - S^2 / n) / n well conditioned: Q / (n var) = 1 + m^2 / var with
 //     m <= the tile's relief, against a guard at 2^24 (1 ulp of float32);
-//   * the horizontal box sum of the 256 column sums: lane-local prefix over the 4 columns, a wave-wide DPP scan of the lane
+//   * the horizontal box sum of the column sums: lane-local prefix over the NC columns, a wave-wide DPP scan of the lane
 //     totals (6 steps), the prefix array through LDS, and every output column is P[x + rx] - P[x - rx - 1] -- independent of
-//     rx.  A wave writes the 256 - 2 rx (rounded down to 4) columns whose windows lie inside its 256 columns;
-//   * nothing here knows the box size at compile time: one kernel for every k (and for rectangles);
-//   * ~40 VALU instructions per cell (~60 % of them float64) for all four moments, few registers (no ring), 5+ waves per
-//     SIMD: the kernel is bound by the 4 B read + 4 B per plane written.
+//     rx.  A wave writes the 64 NC - 2 rx columns whose windows lie inside its columns;
+//   * nothing here knows the box size at compile time: one kernel for every k (LDS allowing: the ring is sized at launch);
+//   * ~1 VALU instruction per cell and moment set instead of ~2.5, few registers (no accumulator ring).
 // What the fast walk cannot do -- NaN / inf cells (they would stay in a running sum for ever), windows whose variance drowns
 // in the cancellation (flat patches away from the shift: exact zero is the contract there) -- it does not try: the wave
 // marks its tile in `todo`, a byte map over the workgroup tiles of the float32 walker that owns the mask shape
 // (focal_mom_kernel / focal_wide_kernel with BoxShape), and that kernel, launched right behind this one, redoes exactly
 // the marked tiles with its NaN-aware and exact paths.  Raster edges stay here (clipped windows: n = rows x cols inside,
-// cells outside contribute d = 0).
+// cells outside contribute d = 0; plain predicated loads of the entering and the leaving row, no ring).
 #include "circle_walk.h"
 #include "lds_dma.h"
 
@@ -32,20 +39,28 @@ using namespace xrs;
 
 namespace {
 
-enum : int { BOX_SUM = 1, BOX_MEAN = 2, BOX_VAR = 4, BOX_STD = 8, BOX_CONV = 16 };
+enum : int { BOX_SUM = 1, BOX_MEAN = 2, BOX_VAR = 4, BOX_STD = 8 };
+
+#ifndef XRS_BOX_NC
+#define XRS_BOX_NC 2                  // columns per lane: wave tiles of 128 columns (512-byte ring rows)
+#endif
+#ifndef XRS_BOX_D
+#define XRS_BOX_D 4                   // rows in flight by LDS-DMA
+#endif
 
 struct BoxArgs {
     const float *in;
     long rows, cols, ld_in, ld_out;
     int halo_top, halo_bot;
-    float *out_sum, *out_mean, *out_var, *out_std, *out_conv;
+    float *out_sum, *out_mean, *out_var, *out_std;
     int rx, ry;                   // half-widths of the box (columns, rows)
-    int w_out;                    // output columns per wave tile: (256 - 2 rx) rounded down to a multiple of 4
+    int w_out;                    // output columns per wave tile: 64 NC - 2 rx, rounded down to a multiple of NC
     int tile_rows;                // output rows per wave tile
+    int n_slots;                  // ring slots per wave: 2 ry + 2 + rows ahead (even)
+    int wave_lds;                 // bytes of LDS per wave: the ring, then 2 rows x 2 moments of prefix arrays
     long tiles_x, tiles_y, groups_x;   // wave tiles; workgroups = 4 horizontally adjacent wave tiles
     int rim_first;
     double n_full, inv_n_full;    // cells of an unclipped window
-    double wgt;                   // BOX_CONV: the weight
     // the fall-back kernel's workgroup tiles (todo[ty * fb_groups_x + gx] = 1: redo rows [ty * fb_tile_rows, +fb_tile_rows)
     // x columns [gx * fb_group_cols, +fb_group_cols))
     unsigned char *todo;
@@ -53,104 +68,189 @@ struct BoxArgs {
     int fb_tile_rows, fb_group_cols;
 };
 
-constexpr int BOX_U_INTERIOR = 4;     // rows per batch of loads (edge tiles: 1 -- their predicated walk would otherwise set
-                                      // the kernel's register count: 168 instead of 126)
-constexpr int BOX_SLOTS = 328;        // prefix slots per wave and moment: 1 sentinel + 256 columns + what idle lanes read
+template <int NC>
+struct BoxGeo {
+    static constexpr int TWC = 64 * NC;                    // columns of column sums per wave
+    static constexpr int ROWB = TWC * 4;                   // bytes per ring row
+    static constexpr int PEVEN = 66;                       // prefix array (NC = 2): [0] = 0, [1 + l] = odd column 2 l + 1, [PEVEN + l] = even column 2 l
+    static constexpr int PSLOTS = PEVEN + 64;              // float64 slots per prefix array
+    static_assert(NC == 2, "one 16-byte LDS-DMA moves a pair of 512-byte rows");
+};
+// rows in flight by LDS-DMA (pairs of rows: one DMA instruction each).  The ring is what limits residency: with the
+// squares' two extra prefix arrays 4 rows ahead keep two workgroups on a CU at 25x25, without them 8 do
+constexpr int box_ahead(bool with_squares) { return with_squares ? XRS_BOX_D : 2 * XRS_BOX_D; }
 
-// ---- wave-wide inclusive scan of one float64 per lane: Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then
-// the row totals across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3).  A lane without a source keeps 0.
+// ---- wave-wide inclusive scan of one float64 per lane: Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8 with
+// bound_ctrl: a lane without a source reads 0), then the row totals across (row_bcast 15 into rows 1 and 3, row_bcast 31
+// into rows 2 and 3; the rows that are not written keep 0).  N independent values at once, step by step: one scan is a chain
+// of 6 dependent (2 DPP moves + 1 float64 add), and the compiler keeps chains in source order -- interleaved here, the N
+// chains hide one another's latency.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
+__device__ __forceinline__ double dpp_bcast_f64(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_scan_f64(double v) {
-    v += dpp_f64<0x111, 0xf>(v);
-    v += dpp_f64<0x112, 0xf>(v);
-    v += dpp_f64<0x114, 0xf>(v);
-    v += dpp_f64<0x118, 0xf>(v);
-    v += dpp_f64<0x142, 0xa>(v);
-    v += dpp_f64<0x143, 0xc>(v);
-    return v;
+template <int N>
+__device__ __forceinline__ void wave_scan_f64(double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x111>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x112>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x114>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x118>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_bcast_f64<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_bcast_f64<0x143, 0xc>(v[i]);
 }
 
-template <int OM, bool EDGE>
+// RING = true: a full tile whose whole input window lies inside the raster: rows arrive in the wave's LDS ring by LDS-DMA
+// and are read from it twice (entering, leaving); RING = false: tiles at the raster / shard edge and the last tile column:
+// predicated global loads of the entering and the leaving row, c0 for every cell outside (d = 0), clipped counts.
+// NO: planes written per row AT LEAST (the vmcnt bookkeeping of the DMA ring: fewer than the truth is safe)
+template <int OM, int NC, bool RING, int NO>
 struct BoxWalk {
     static constexpr bool Q = (OM & (BOX_VAR | BOX_STD)) != 0;
-    static constexpr int BOX_U = EDGE ? 1 : BOX_U_INTERIOR;
+    static constexpr bool EDGE = !RING;
+    using G = BoxGeo<NC>;
     const BoxArgs &a;
-    double *p1, *p2;              // this wave's prefix arrays (slot 0 = 0; slot 1 + i = columns 0 .. i)
+    float *ring;                  // this wave's n_slots rows of TWC cells
+    double *p1;                   // this wave's four prefix arrays of PSLOTS float64 each (across_n)
     long xs, x_out0, y0, y_end;
     int lane, rx, ry;
     double c0;
     float c0f;
-    double C1[4], C2[4];          // (C2 unused -- and optimised away -- without the squares)
+    double C1[NC], C2[NC];        // (C2 unused -- and optimised away -- without the squares)
     unsigned long long failm;     // lanes with a result the fast walk must not stand for (wave-uniform)
 
-    __device__ __forceinline__ BoxWalk(const BoxArgs &a_, double *p1_, double *p2_, long xs_, long xo, long y0_, long ye, int lane_)
-        : a(a_), p1(p1_), p2(p2_), xs(xs_), x_out0(xo), y0(y0_), y_end(ye), lane(lane_), rx(a_.rx), ry(a_.ry) {}
+    __device__ __forceinline__ BoxWalk(const BoxArgs &a_, unsigned char *lds, long xs_, long xo, long y0_, long ye, int lane_)
+        : a(a_), xs(xs_), x_out0(xo), y0(y0_), y_end(ye), lane(lane_), rx(a_.rx), ry(a_.ry) {
+        ring = reinterpret_cast<float *>(lds);
+        p1 = reinterpret_cast<double *>(lds + (size_t)a_.n_slots * G::ROWB);
+    }
 
-    // the lane's 4 cells of input row yy (EDGE: c0 for everything outside the raster / the shard's halo rows: d = 0)
-    __device__ __forceinline__ void load4(long yy, float (&v)[4]) const {
-        if (!EDGE) {
-            const xrs_f4u q = load_f4u(a.in + yy * a.ld_in + xs + 4 * lane);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            return;
-        }
+    // EDGE: the lane's NC cells of input row yy (c0 for everything outside the raster / the shard's halo rows: d = 0)
+    __device__ __forceinline__ void load_cells(long yy, float (&v)[NC]) const {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = c0f;
+        for (int j = 0; j < NC; ++j) v[j] = c0f;
         if (yy < -(long)a.halo_top || yy >= a.rows + a.halo_bot) return;          // wave-uniform
         const float *p = a.in + yy * a.ld_in;
-        const long x = xs + 4 * lane;
+        const long x = xs + NC * lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NC; ++j)
             if (x + j >= 0 && x + j < a.cols) v[j] = p[x + j];
     }
-
-    __device__ __forceinline__ void enter(const float (&v)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double d = (double)v[j] - c0;
-            C1[j] += d;
-            if (Q) C2[j] = fma(d, d, C2[j]);
-        }
+    typedef float vNC __attribute__((ext_vector_type(NC)));
+    // RING: input rows yy, yy + 1 -> ring slots 2 pair, 2 pair + 1 with ONE 16-byte LDS-DMA: lanes 0..31 move the 512 bytes of
+    // the first row, lanes 32..63 those of the second (`stride` bytes further; 0 past the tile: the row again, nobody reads it)
+    __device__ __forceinline__ void dma_pair(long yy, unsigned stride, int pair, unsigned ring_addr) const {
+        const float *p = uniform_ptr(a.in + yy * a.ld_in + xs);
+        glds16_s(p, 16u * (unsigned)(lane & 31) + (lane >= 32 ? stride : 0u), ring_addr + (unsigned)pair * (2 * G::ROWB));
     }
-    __device__ __forceinline__ void leave(const float (&v)[4]) {
+    __device__ __forceinline__ void ring_get(int slot, float (&v)[NC]) const {
+        const vNC q = *reinterpret_cast<const vNC *>(ring + (size_t)slot * G::TWC + NC * lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double d = (double)v[j] - c0;
-            C1[j] -= d;
-            if (Q) C2[j] = fma(-d, d, C2[j]);
-        }
+        for (int j = 0; j < NC; ++j) v[j] = q[j];
     }
 
-    // box sums of the column sums for the lane's 4 OUTPUT columns x_out0 + 4 lane + o (column index rx + 4 lane + o of the tile)
-    __device__ __forceinline__ void across(const double (&C)[4], double *p, double (&B)[4]) const {
-        double pre[4];
-        pre[0] = C[0];
+    // the sums of d = v - c0 (EDGE: cells outside the raster arrive as c0, d = 0) or, in the ring walk, of v itself (float32
+    // cells add exactly in float64; one subtraction fewer per cell) and of d^2
+    __device__ __forceinline__ double term1(float v) const { return RING ? (double)v : (double)v - c0; }
+    __device__ __forceinline__ void enter(const float (&v)[NC]) {
 #pragma unroll
-        for (int j = 1; j < 4; ++j) pre[j] = pre[j - 1] + C[j];
-        const double before = wave_scan_f64(pre[3]) - pre[3];        // the columns of the lanes to the left
+        for (int j = 0; j < NC; ++j) {
+            C1[j] += term1(v[j]);
+            if (Q) { const double d = (double)v[j] - c0; C2[j] = fma(d, d, C2[j]); }
+        }
+    }
+    __device__ __forceinline__ void leave(const float (&v)[NC]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[1 + 4 * lane + j] = before + pre[j];
+        for (int j = 0; j < NC; ++j) {
+            C1[j] -= term1(v[j]);
+            if (Q) { const double d = (double)v[j] - c0; C2[j] = fma(-d, d, C2[j]); }
+        }
+    }
+
+    // Box sums of the column sums for the lane's NC OUTPUT columns x_out0 + NC lane + o (column rx + NC lane + o of the tile),
+    // for N independent sets at once (the rows of a step x the moments): set i uses the prefix array pp + i * PSLOTS.
+    // Layout of a prefix array (NC = 2): slot 1 + c holds the inclusive prefix up to column c, stored by column parity --
+    // [0 .. 64]: slot 0 (= 0) and the odd columns (c = 2 l + 1 at 1 + l), [PEVEN ..]: the even columns (c = 2 l at PEVEN + l) -- so
+    // that every access is one float64 per lane at an 8-byte lane stride: conflict free (interleaved, the two float64 of a
+    // lane sat 16 bytes apart and every LDS access was a 2-way bank conflict: 46 % of the LDS cycles).
+    template <int N>
+    __device__ __forceinline__ void across_n(const double (&C)[N][NC], double *pp, double (&B)[N][NC]) const {
+        static_assert(NC == 2, "prefix layout by column parity");
+        double tot[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) tot[i] = C[i][0] + C[i][1];
+        double inc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) inc[i] = tot[i];
+        wave_scan_f64<N>(inc);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double *p = pp + i * G::PSLOTS;
+            const double before = inc[i] - tot[i];                      // the columns of the lanes to the left
+            p[G::PEVEN + lane] = before + C[i][0];                            // column 2 lane
+            p[1 + lane] = inc[i];                                       // column 2 lane + 1
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                                // (LDS serves one wave's instructions in order)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int lc = NC * lane < a.w_out ? lane : 0;                  // (lanes without outputs re-read lane 0's)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) B[o] = p[1 + 4 * lane + o + 2 * rx] - p[4 * lane + o];
+        for (int i = 0; i < N; ++i) {
+            const double *p = pp + i * G::PSLOTS;
+            // output o = 0: columns 2 lc + 2 rx (even) minus 2 lc - 1 (odd; slot 0 for lc = 0);  o = 1: 2 lc + 1 + 2 rx (odd) minus 2 lc (even)
+            B[i][0] = p[G::PEVEN + lc + rx] - p[lc];
+            B[i][1] = p[1 + lc + rx] - p[G::PEVEN + lc];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                // (the next row's writes come after these reads)
+        __builtin_amdgcn_wave_barrier();                                // (the next step's writes come after these reads)
     }
 
-    __device__ __forceinline__ void emit(long yo) {
-        double B1[4], B2[4];
-        across(C1, p1, B1);
-        if (Q) across(C2, p2, B2);
-        else { B2[0] = B2[1] = B2[2] = B2[3] = 0.0; }
-        const bool out_lane = 4 * lane < a.w_out;
-        const long xo = x_out0 + 4 * lane;
-        float r_sum[4], r_mean[4], r_var[4], r_std[4], r_conv[4];
+    // one output row from the column sums (S, QQ)
+    __device__ __forceinline__ void emit(long yo, const double (&S)[NC], const double (&QQ)[NC]) {
+        double C[Q ? 2 : 1][NC], B[Q ? 2 : 1][NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { C[0][j] = S[j]; if (Q) C[Q ? 1 : 0][j] = QQ[j]; }
+        across_n<Q ? 2 : 1>(C, p1, B);
+        double zero[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) zero[j] = 0.0;
+        finish(yo, B[0], Q ? B[Q ? 1 : 0] : zero);
+    }
+    // two output rows (yo from Sa / Qa, yo + 1 from Sb / Qb): all their scans step by step together
+    __device__ __forceinline__ void emit2(long yo, const double (&Sa)[NC], const double (&Qa)[NC], const double (&Sb)[NC],
+                                          const double (&Qb)[NC]) {
+        constexpr int N = Q ? 4 : 2;
+        double C[N][NC], B[N][NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            C[0][j] = Sa[j]; C[1][j] = Sb[j];
+            if (Q) { C[Q ? 2 : 0][j] = Qa[j]; C[Q ? 3 : 1][j] = Qb[j]; }
+        }
+        across_n<N>(C, p1, B);
+        double zero[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) zero[j] = 0.0;
+        finish(yo, B[0], Q ? B[Q ? 2 : 0] : zero);
+        finish(yo + 1, B[1], Q ? B[Q ? 3 : 1] : zero);
+    }
+
+    __device__ __forceinline__ void finish(long yo, const double (&B1)[NC], const double (&B2)[NC]) {
+        const bool out_lane = NC * lane < a.w_out;
+        const long xo = x_out0 + NC * lane;
+        float r_sum[NC], r_mean[NC], r_var[NC], r_std[NC];
         bool bad = false;
         // EDGE: rows of the window inside the raster (wave-uniform), columns per output
         double ny = 0.0;
@@ -162,7 +262,7 @@ struct BoxWalk {
             rows_full = hi - lo == 2 * ry;
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < NC; ++o) {
             double n = a.n_full, inv = a.inv_n_full;
             bool full = true;
             if (EDGE) {
@@ -171,108 +271,166 @@ struct BoxWalk {
                 full = rows_full && hi - lo == 2 * rx;
                 if (!full) { n = ny * (double)(hi - lo + 1); inv = 1.0 / n; }
             }
-            // mean of the shifted values, exact whenever it is representable (a flat window: d itself)
-            double q = B1[o] * inv;
-            q = fma(fma(-q, n, B1[o]), inv, q);
+            // B1: the window sum about 0 (ring walk) or about c0 (edge walk); sd: about c0, s0: about 0
+            const double sd = RING ? fma(-n, c0, B1[o]) : B1[o];
+            const double s0 = RING ? B1[o] : fma(n, c0, B1[o]);
             if (Q) {
-                const double e = fma(-B1[o], q, B2[o]);                  // n * variance
+                const double e = fma(-sd, sd * inv, B2[o]);              // n * variance
                 bad |= !(e >= 0x1p-24 * B2[o]);                         // (a NaN / inf anywhere fails it too)
                 const double var = e * inv;
                 r_var[o] = (float)var;
-                r_std[o] = sqrtf((float)var);
+                r_std[o] = __builtin_amdgcn_sqrtf((float)var);               // (v_sqrt_f32: 1 ulp; sqrtf's fix-up costs 8 instructions per cell)
             } else {
                 bad |= !(fabs(B1[o]) < INFINITY);
             }
-            r_mean[o] = (float)(c0 + q);
-            r_sum[o] = (float)fma(n, c0, B1[o]);
-            if (OM & BOX_CONV) r_conv[o] = full ? (float)(a.wgt * fma(n, c0, B1[o])) : nan_f32();
+            r_mean[o] = (float)(s0 * inv);
+            r_sum[o] = (float)s0;
         }
         const bool live = out_lane && (!EDGE || xo < a.cols);
         failm |= __builtin_amdgcn_ballot_w64(live && bad);
         if (!live) return;
         const long off = yo * a.ld_out + xo;
         if (!EDGE) {
-            typedef float st4 __attribute__((ext_vector_type(4), aligned(4)));
-            auto put = [&](float *plane, const float (&r)[4]) {
-                st4 v; v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
-                __builtin_nontemporal_store(v, reinterpret_cast<st4 *>(plane + off));
+            typedef float stN __attribute__((ext_vector_type(NC), aligned(4)));
+            auto put = [&](float *plane, const float (&r)[NC]) {
+                stN v;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) v[o] = r[o];
+                __builtin_nontemporal_store(v, reinterpret_cast<stN *>(plane + off));
             };
             if ((OM & BOX_SUM) && a.out_sum) put(a.out_sum, r_sum);
             if ((OM & BOX_MEAN) && a.out_mean) put(a.out_mean, r_mean);
             if ((OM & BOX_VAR) && a.out_var) put(a.out_var, r_var);
             if ((OM & BOX_STD) && a.out_std) put(a.out_std, r_std);
-            if ((OM & BOX_CONV) && a.out_conv) put(a.out_conv, r_conv);
         } else {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < NC; ++o) {
                 if (xo + o >= a.cols) break;
                 if ((OM & BOX_SUM) && a.out_sum) a.out_sum[off + o] = r_sum[o];
                 if ((OM & BOX_MEAN) && a.out_mean) a.out_mean[off + o] = r_mean[o];
                 if ((OM & BOX_VAR) && a.out_var) a.out_var[off + o] = r_var[o];
                 if ((OM & BOX_STD) && a.out_std) a.out_std[off + o] = r_std[o];
-                if ((OM & BOX_CONV) && a.out_conv) a.out_conv[off + o] = r_conv[o];
             }
+        }
+    }
+
+    __device__ __forceinline__ void init() {
+        failm = 0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { C1[j] = 0.0; C2[j] = 0.0; }
+        // the shift: the cell at the tile centre (any finite value works; a near one keeps d small)
+        const long yc = y0 + (y_end - y0) / 2;
+        long xc = x_out0 + a.w_out / 2;
+        xc = xc < a.cols ? xc : a.cols - 1;
+        const float v = a.in[yc * a.ld_in + xc];
+        c0f = isfinite(v) ? v : 0.0f;
+        c0 = (double)c0f;
+        if (lane == 0) {
+            p1[0] = 0.0; p1[G::PSLOTS] = 0.0;
+            if (Q) { p1[2 * G::PSLOTS] = 0.0; p1[3 * G::PSLOTS] = 0.0; }
         }
     }
 
     // true: every result of the tile stands; false: the tile goes to the fall-back kernel
     __device__ __forceinline__ bool run() {
-        failm = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) C1[j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) C2[j] = 0.0;
-        // the shift: the cell at the tile centre (any finite value works; a near one keeps d small)
-        {
-            const long yc = y0 + (y_end - y0) / 2;
-            long xc = x_out0 + a.w_out / 2;
-            xc = xc < a.cols ? xc : a.cols - 1;
-            const float v = a.in[yc * a.ld_in + xc];
-            c0f = isfinite(v) ? v : 0.0f;
-            c0 = (double)c0f;
-        }
-        if (lane == 0) { p1[0] = 0.0; if (Q) p2[0] = 0.0; }
-        // run-in: rows y0 - ry .. y0 + ry - 1
-        for (long yy = y0 - ry; yy < y0 + ry; yy += BOX_U) {
-            float v[BOX_U][4];
-#pragma unroll
-            for (int u = 0; u < BOX_U; ++u) {
-                const long yr = yy + u < y0 + ry ? yy + u : y0 + ry - 1;     // (clamped: loaded, not used)
-                load4(yr, v[u]);
+        init();
+        if (RING) {
+            // Input row i of the tile (raster row y0 - ry + i) lives in ring slot i mod n_slots from its DMA until it has left
+            // the window; rows travel in PAIRS (2 p, 2 p + 1) -> slots (2 p, 2 p + 1) mod n_slots (n_slots even: a pair never
+            // wraps).  Step s takes pair s: the first ry steps only add its rows (run-in), the others emit output rows
+            // y0 + 2 (s - ry) and the next one and take pair s - ry out again.  The DMA of a step (pair s + A + 1, A = pairs
+            // ahead; n_slots = 2 ry + 2 + 2 A) overwrites exactly the pair that leaves in it: issued after the step's reads.
+            constexpr int A = box_ahead(Q) / 2;
+            const int np = a.n_slots / 2;
+            const unsigned ring_addr = lds_addr(ring);
+            const long y_first = y0 - ry, y_last = y_end - 1 + ry;
+            const unsigned row_bytes = (unsigned)(a.ld_in * 4);
+            auto dma = [&](int pq, int pair) {
+                long yy = y_first + 2 * pq;                              // (past the tile: the last row, twice; nobody reads it)
+                const unsigned stride = yy + 1 <= y_last ? row_bytes : 0u;
+                yy = yy <= y_last ? yy : y_last;
+                dma_pair(yy, stride, pair, ring_addr);
+            };
+            auto next = [&](int pair) { return pair + 1 == np ? 0 : pair + 1; };
+            int pair_dma = 0;
+            for (int r = 0; r <= A; ++r) { dma(r, pair_dma); pair_dma = next(pair_dma); }           // pairs 0 .. A
+            int pair_in = 0, pair_out = 0;
+            int pr = 0;
+            // ---- run-in: rows 0 .. 2 ry - 1
+            for (; pr < ry; ++pr) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A) : "memory");      // pair pr landed: at most the A pairs behind it in flight
+                float v0[NC], v1[NC];
+                ring_get(2 * pair_in, v0);
+                ring_get(2 * pair_in + 1, v1);
+                pair_in = next(pair_in);
+                enter(v0);
+                enter(v1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma(pr + A + 1, pair_dma); pair_dma = next(pair_dma);
             }
+            // ---- the walk (the tile has an even number of rows: every step emits two)
+            const int n_steps = (int)(y_end - y0) / 2;
+            for (int st = 0; st < n_steps; ++st, ++pr) {
+                const long yo = y0 + 2 * st;
+                // younger than this step's pair: A DMAs and, once A steps have emitted, the stores of the A steps in between
+                if (st >= A) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A + 2 * A * NO) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A) : "memory");
+                float e0[NC], e1[NC], l0[NC], l1[NC];
+                ring_get(2 * pair_in, e0);
+                ring_get(2 * pair_in + 1, e1);
+                pair_in = next(pair_in);
+                ring_get(2 * pair_out, l0);
+                ring_get(2 * pair_out + 1, l1);
+                pair_out = next(pair_out);
+                // column sums under output row yo (Sa, Qa) and yo + 1 (Sb, Qb), and what the next step starts from
+                double Sa[NC], Qa[NC], Sb[NC], Qb[NC];
 #pragma unroll
-            for (int u = 0; u < BOX_U; ++u)
-                if (yy + u < y0 + ry) enter(v[u]);
-        }
-        const long y_last_in = EDGE ? (long)0x7fffffffffffL : y_end - 1 + ry;      // (EDGE tests every row itself)
-        for (long yo = y0; yo < y_end; yo += BOX_U) {
-            float e[BOX_U][4], l[BOX_U][4];
-#pragma unroll
-            for (int u = 0; u < BOX_U; ++u) {
-                const long ye = yo + u + ry;
-                load4(ye < y_last_in ? ye : y_last_in, e[u]);
-                load4(yo + u - ry, l[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < BOX_U; ++u) {
-                if (yo + u < y_end) {                                    // wave-uniform
-                    enter(e[u]);
-                    emit(yo + u);
-                    leave(l[u]);
+                for (int j = 0; j < NC; ++j) {
+                    Sa[j] = C1[j] + (double)e0[j];
+                    Sb[j] = (Sa[j] - (double)l0[j]) + (double)e1[j];
+                    C1[j] = Sb[j] - (double)l1[j];
+                    if (Q) {
+                        const double de0 = (double)e0[j] - c0, de1 = (double)e1[j] - c0;
+                        const double dl0 = (double)l0[j] - c0, dl1 = (double)l1[j] - c0;
+                        Qa[j] = fma(de0, de0, C2[j]);
+                        Qb[j] = fma(de1, de1, fma(-dl0, dl0, Qa[j]));
+                        C2[j] = fma(-dl1, dl1, Qb[j]);
+                    } else {
+                        Qa[j] = Qb[j] = 0.0;
+                    }
                 }
-                // (one row at a time: left alone, the scheduler converts all four rows of the batch to float64 up front --
-                //  64 more registers -- and interleaves the four emits: 168 VGPRs instead of ~100)
-                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the ring reads have returned: the leaving pair's slots may be refilled)
+                dma(pr + A + 1, pair_dma); pair_dma = next(pair_dma);
+                emit2(yo, Sa, Qa, Sb, Qb);
+                if ((st & 7) == 7 && failm) return false;                // (a NaN / inf stays in the running sums: stop soon, not at once)
             }
+            if (failm) return false;
+            return true;
+        }
+        for (long yy = y0 - ry; yy < y0 + ry; ++yy) {                   // run-in: rows y0 - ry .. y0 + ry - 1
+            float v[NC];
+            load_cells(yy, v);
+            enter(v);
+        }
+        for (long yo = y0; yo < y_end; ++yo) {
+            float e[NC], l[NC];
+            load_cells(yo + ry, e);
+            load_cells(yo - ry, l);
+            enter(e);
+            emit(yo, C1, C2);
+            leave(l);
             if (failm) return false;
         }
         return true;
     }
 };
 
-template <int OM>
+constexpr int box_planes(int om) { return (om & 1) + (om >> 1 & 1) + (om >> 2 & 1) + (om >> 3 & 1); }
+
+template <int OM, int NC, int NO = box_planes(OM)>
 __global__ void __launch_bounds__(256) box_sep_kernel(const BoxArgs a) {
-    __shared__ __attribute__((aligned(16))) double prefix[4][2][BOX_SLOTS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char box_lds[];
+    using G = BoxGeo<NC>;
     long ty, gx;
     if (!RimFirst(a.groups_x, a.tiles_y, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     const int lane = threadIdx.x & 63;
@@ -283,14 +441,15 @@ __global__ void __launch_bounds__(256) box_sep_kernel(const BoxArgs a) {
     const long xs = x_out0 - a.rx;
     const long y0 = ty * a.tile_rows;
     const long y_end = y0 + a.tile_rows < a.rows ? y0 + a.tile_rows : a.rows;
-    const bool interior = xs >= 0 && xs + 256 <= a.cols && x_out0 + a.w_out <= a.cols && y0 - a.ry >= -(long)a.halo_top &&
-                          y_end + a.ry <= a.rows + a.halo_bot;
+    const bool interior = xs >= 0 && xs + G::TWC <= a.cols && x_out0 + a.w_out <= a.cols && y0 - a.ry >= -(long)a.halo_top &&
+                          y_end + a.ry <= a.rows + a.halo_bot && ((y_end - y0) & 1) == 0;
+    unsigned char *lds = box_lds + (size_t)wv * a.wave_lds;
     bool ok;
     if (interior) {
-        BoxWalk<OM, false> w(a, prefix[wv][0], prefix[wv][1], xs, x_out0, y0, y_end, lane);
+        BoxWalk<OM, NC, true, NO> w(a, lds, xs, x_out0, y0, y_end, lane);
         ok = w.run();
     } else {
-        BoxWalk<OM, true> w(a, prefix[wv][0], prefix[wv][1], xs, x_out0, y0, y_end, lane);
+        BoxWalk<OM, NC, false, NO> w(a, lds, xs, x_out0, y0, y_end, lane);
         ok = w.run();
     }
     if (ok || lane != 0) return;
@@ -300,59 +459,66 @@ __global__ void __launch_bounds__(256) box_sep_kernel(const BoxArgs a) {
         for (long fx = x_out0 / a.fb_group_cols; fx <= x_hi / a.fb_group_cols; ++fx) a.todo[fy * a.fb_groups_x + fx] = 1;
 }
 
-int wg_per_cu_of(const void *fn) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n < 1) return 4;
-    return n;
-}
+typedef void (*BoxKernel)(const BoxArgs);
 
 }  // namespace
 
 namespace xrs {
 
-// Launches the fast walk for an all-ones krows x kcols box.  0 = launched (the caller launches its own kernel on the tiles of
-// `todo` behind it), -1 = not for this walk (window too wide for a 256-column tile), > 0 = error.
+// Launches the fast walk for an all-ones krows x kcols box (a set of moments with var or std in it).  0 = launched (the
+// caller launches its own kernel on the tiles of `todo` behind it), -1 = not for this walk (no var / std wanted, window too
+// wide for a wave tile, ring too large for the LDS), > 0 = error.
 // `todo` (fb_groups_x * ceil(rows / fb_tile_rows) bytes, device) is cleared here.
-int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, float *out_conv, double wgt,
+int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std,
                    long rows, long cols, long ld_in, long ld_out, int krows, int kcols, int halo_top, int halo_bot,
                    unsigned char *todo, long fb_groups_x, int fb_tile_rows, int fb_group_cols, hipStream_t s) {
-    if (!todo || krows < 3 || kcols < 3 || !(krows & 1) || !(kcols & 1) || kcols > 65 || krows > 255) return -1;
+    constexpr int NC = XRS_BOX_NC;
+    using G = BoxGeo<NC>;
+    if (!todo || !(out_var || out_std) || krows < 3 || kcols < 3 || !(krows & 1) || !(kcols & 1) || kcols > 65 || 2 * (kcols / 2) > G::TWC / 2) return -1;
     BoxArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out; a.halo_top = halo_top; a.halo_bot = halo_bot;
-    a.out_sum = out_sum; a.out_mean = out_mean; a.out_var = out_var; a.out_std = out_std; a.out_conv = out_conv;
+    a.out_sum = out_sum; a.out_mean = out_mean; a.out_var = out_var; a.out_std = out_std;
     a.rx = kcols / 2; a.ry = krows / 2;
-    a.w_out = (256 - 2 * a.rx) & ~3;
+    a.w_out = ((G::TWC - 2 * a.rx) / NC) * NC;
+    const bool with_q = true;
+    a.n_slots = 2 * a.ry + 2 + box_ahead(with_q);
+    a.wave_lds = (a.n_slots * G::ROWB + (with_q ? 4 : 2) * G::PSLOTS * (int)sizeof(double) + 15) & ~15;
+    if ((unsigned long)ld_in * 4ul >= (1ul << 31)) return -1;            // (the second row of a DMA pair is addressed by a 32-bit lane offset)
+    const size_t lds = 4 * (size_t)a.wave_lds;
+    if (lds > 156 * 1024) return -1;
     a.n_full = (double)krows * kcols;
     a.inv_n_full = 1.0 / a.n_full;
-    a.wgt = wgt;
     a.todo = todo; a.fb_groups_x = fb_groups_x; a.fb_tile_rows = fb_tile_rows; a.fb_group_cols = fb_group_cols;
     a.tiles_x = (cols + a.w_out - 1) / a.w_out;
     a.groups_x = (a.tiles_x + 3) / 4;
-    const int om = (out_sum ? BOX_SUM : 0) | (out_mean ? BOX_MEAN : 0) | (out_var ? BOX_VAR : 0) | (out_std ? BOX_STD : 0) |
-                   (out_conv ? BOX_CONV : 0);
-    if (!om) return 0;
+    const int om = (out_sum ? BOX_SUM : 0) | (out_mean ? BOX_MEAN : 0) | (out_var ? BOX_VAR : 0) | (out_std ? BOX_STD : 0);
     constexpr int ALL = BOX_SUM | BOX_MEAN | BOX_VAR | BOX_STD, MVS = BOX_MEAN | BOX_VAR | BOX_STD;
     // the instantiation: the common sets exactly, anything else through the superset that has them (absent planes are NULL)
-    const void *fn;
+    BoxKernel fn;
     int kind;
-    if (om == BOX_MEAN) { fn = reinterpret_cast<const void *>(&box_sep_kernel<BOX_MEAN>); kind = 0; }
-    else if (om == BOX_SUM) { fn = reinterpret_cast<const void *>(&box_sep_kernel<BOX_SUM>); kind = 1; }
-    else if (om == BOX_CONV) { fn = reinterpret_cast<const void *>(&box_sep_kernel<BOX_CONV>); kind = 2; }
-    else if (om == MVS) { fn = reinterpret_cast<const void *>(&box_sep_kernel<MVS>); kind = 3; }
-    else if (!(om & BOX_CONV)) { fn = reinterpret_cast<const void *>(&box_sep_kernel<ALL>); kind = 4; }
-    else return -1;
+    if (om == MVS) { fn = &box_sep_kernel<MVS, NC>; kind = 0; }
+    else if (om == ALL) { fn = &box_sep_kernel<ALL, NC>; kind = 1; }
+    else { fn = &box_sep_kernel<ALL, NC, 1>; kind = 2; }               // any other subset: absent planes are NULL
+    int dev = 0;
+    XRS_HIP(hipGetDevice(&dev));
+    if (lds > 64 * 1024) {
+        // dynamic LDS beyond 64 KiB has to be allowed per kernel and device (the call synchronises: once per thread, kernel, device)
+        static thread_local unsigned long long allowed[3] = {0, 0, 0};
+        if (dev < 0 || dev >= 64 || !(allowed[kind] >> dev & 1)) {
+            XRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            if (dev >= 0 && dev < 64) allowed[kind] |= 1ull << dev;
+        }
+    }
     // tile height: whole rounds of resident workgroups, each tile paying 2 ry rows of run-in (as walk3_tile_base)
     static thread_local int n_cu = 0;
     if (!n_cu) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
+        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    static thread_local int wg_cu[5] = {0, 0, 0, 0, 0};
-    if (!wg_cu[kind]) wg_cu[kind] = wg_per_cu_of(fn);
-    const long slots = (long)n_cu * wg_cu[kind];
+    int wg_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, reinterpret_cast<const void *>(fn), 256, lds) != hipSuccess || wg_cu < 1) wg_cu = 1;
+    const long slots = (long)n_cu * wg_cu;
     int best = 256;
     double best_cost = 1e300;
     const char *force = ab_env("XRS_BOX_TILE_ROWS");
@@ -369,14 +535,7 @@ int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_
     if (grid > 0x7fffffffL) return fail("box statistics: raster too large for one launch");
     const long fb_tiles_y = (rows + fb_tile_rows - 1) / fb_tile_rows;
     XRS_HIP(hipMemsetAsync(todo, 0, (size_t)(fb_groups_x * fb_tiles_y), s));
-    const dim3 g((unsigned)grid), b(256);
-    switch (kind) {
-        case 0: hipLaunchKernelGGL((box_sep_kernel<BOX_MEAN>), g, b, 0, s, a); break;
-        case 1: hipLaunchKernelGGL((box_sep_kernel<BOX_SUM>), g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((box_sep_kernel<BOX_CONV>), g, b, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((box_sep_kernel<MVS>), g, b, 0, s, a); break;
-        default: hipLaunchKernelGGL((box_sep_kernel<ALL>), g, b, 0, s, a); break;
-    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
 }

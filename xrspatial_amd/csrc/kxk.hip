@@ -1074,17 +1074,8 @@ size_t xrs_focal_workspace_bytes(int64_t rows, int64_t cols, int krows, int kcol
 int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
                        int64_t ld_out, const double *kernel, int krows, int kcols, void *work_dev,
                        int halo_top, int halo_bot, void *stream) {
-    return xrs_convolve2d_f32_ex(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols, work_dev,
-                                 xrs_kxk_workspace_bytes(krows, kcols), halo_top, halo_bot, stream);
-}
-
-int xrs_convolve2d_f32_ex(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
-                          int64_t ld_out, const double *kernel, int krows, int kcols, void *work_dev, size_t work_bytes,
-                          int halo_top, int halo_bot, void *stream) {
     if (int rc = check_common("xrs_convolve2d_f32", in_dev, rows, cols, ld_in, ld_out, kernel, krows, kcols,
                               halo_top, halo_bot)) return rc;
-    if (work_dev && work_bytes < xrs_kxk_workspace_bytes(krows, kcols)) return fail("xrs_convolve2d_f32_ex: workspace too small");
-    const bool box_map = work_dev && work_bytes >= xrs_focal_workspace_bytes(rows, cols, krows, kcols);
     if (!out_dev || !work_dev) return fail("xrs_convolve2d_f32: null output/workspace");
     if (rows == 0 || cols == 0) return 0;
     if (krows > MAX_K || kcols > MAX_K) {
@@ -1115,12 +1106,8 @@ int xrs_convolve2d_f32_ex(const float *in_dev, float *out_dev, int64_t rows, int
         }
 #endif
         rc = try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
-        if (rc < 0) {
-            // (np.ones / k^2: the separable walk of boxsep.hip in front; its tile map lives behind the weights when the caller
-            //  sized the workspace with xrs_focal_workspace_bytes)
-            unsigned char *todo = box_map ? static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) : nullptr;
-            rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s, todo);
-        }
+        if (rc < 0)
+            rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     a.tiles_x = (cols + TW - 1) / TW;
@@ -1194,7 +1181,7 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                                               kernel, krows, kcols, halo_top, halo_bot, s);
         if (rc < 0)
             rc = try_launch_focal_wide_box(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
-                                           kernel, krows, kcols, halo_top, halo_bot, s, box_todo);
+                                           kernel, krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {

@@ -472,7 +472,7 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     if (std::is_same<Shape, BoxShape>::value && a.todo) {
         // np.ones((k, k)): the separable walk of boxsep.hip first; this kernel then redoes the tiles it marked (NaN / inf cells,
         // flat windows away from its shift) and nothing else
-        const int rc = launch_box_sep(g.in, a.out_sum, a.out_mean, a.out_var, a.out_std, nullptr, 0.0, g.rows, g.cols, g.ld_in, g.ld_out,
+        const int rc = launch_box_sep(g.in, a.out_sum, a.out_mean, a.out_var, a.out_std, g.rows, g.cols, g.ld_in, g.ld_out,
                                       C::K, C::K, g.halo_top, g.halo_bot, const_cast<unsigned char *>(a.todo), a.groups_x, a.tile_rows,
                                       4 * C::TW, s);
         if (rc > 0) return rc;

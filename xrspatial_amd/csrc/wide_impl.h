@@ -60,7 +60,6 @@ struct WideArgs {
     int rim_first;                // work order (circle_walk.h RimFirst)
     long n_groups;                // workgroups = groups of 4 horizontally adjacent wave tiles
     long groups_x;
-    const unsigned char *todo;    // boxes behind boxsep.hip's fast walk: one byte per workgroup tile, 0 = nothing to do; else NULL
 };
 
 template <int R, typename Shape>
@@ -390,7 +389,6 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
     __shared__ __attribute__((aligned(16))) float lds_rows[4][C::LDS_WAVE];
     long ty, gx;                   // (rim tiles first: circle_walk.h)
     if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
-    if (std::is_same<Shape, BoxShape>::value && a.todo && !a.todo[ty * a.groups_x + gx]) return;   // (boxsep.hip did this tile)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = (gx * 4 + wv) * C::TW;
@@ -462,23 +460,12 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     a.rim_first = RimFirst::mode_from_env();
     const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
-    unsigned char *const todo = const_cast<unsigned char *>(a.todo);
-    const bool sep = std::is_same<Shape, BoxShape>::value && todo != nullptr;
-    auto box_first = [&](float *o_mean, float *o_sum) -> int {
-        // np.ones((k, k)): the separable walk of boxsep.hip first; this kernel then redoes only the tiles it marked
-        const int rc = launch_box_sep(g.in, o_sum, o_mean, nullptr, nullptr, nullptr, 0.0, g.rows, g.cols, g.ld_in, g.ld_out, C::K, C::K,
-                                      g.halo_top, g.halo_bot, todo, a.groups_x, a.tile_rows, 4 * C::TW, s);
-        a.todo = rc == 0 ? todo : nullptr;
-        return rc > 0 ? rc : 0;
-    };
     if (out_mean) {
-        if (sep) if (int rc = box_first(out_mean, nullptr)) return rc;
         a.out = out_mean;
         hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_MEAN>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
     if (out_sum) {
-        if (sep) if (int rc = box_first(nullptr, out_sum)) return rc;     // (stream order: the mean's kernels have read the map)
         a.out = out_sum;
         hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_SUM>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
@@ -504,13 +491,6 @@ int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double
     a.rim_first = RimFirst::mode_from_env();
     const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("convolve_2d: raster too large for one launch");
-    if (std::is_same<Shape, BoxShape>::value && a.todo) {
-        unsigned char *const todo = const_cast<unsigned char *>(a.todo);
-        const int rc = launch_box_sep(g.in, nullptr, nullptr, nullptr, nullptr, out, a.wgt, g.rows, g.cols, g.ld_in, g.ld_out, C::K, C::K,
-                                      g.halo_top, g.halo_bot, todo, a.groups_x, a.tile_rows, 4 * C::TW, s);
-        if (rc > 0) return rc;
-        if (rc < 0) a.todo = nullptr;
-    }
     hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_CONV>), dim3((unsigned)grid), dim3(256), 0, s, a);
     XRS_LAUNCH_CHECK();
     return 0;
@@ -549,28 +529,25 @@ namespace xrs {
 // 0 = launched, -1 = not this shape with a radius of 3..12 cells (caller takes another kernel), > 0 = error.
 // (mean and sum together: two launches)
 int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in, long ld_out,
-                   const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s, unsigned char *todo_dev) {
+                   const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
     if (krows != kcols || !(krows & 1)) return -1;
     if (!out_mean && !out_sum) return 0;
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
-    a.todo = todo_dev;
     return dispatch_wide(a, out_mean, out_sum, kernel, krows / 2, s);
 }
 
 // convolve_2d with one weight value on this shape (normalised circle_kernel / np.ones): 0 = launched, -1 = not that,
 // > 0 = error.  `weights_dev`: the kernel as float64 in device memory, for windows that hold a non-finite cell.
 int XRS_WIDE_CONV_ENTRY(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
-                        const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s,
-                        unsigned char *todo_dev) {
+                        const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
     if (krows != kcols || !(krows & 1)) return -1;
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
-    a.todo = todo_dev;
     return dispatch_wide_conv(a, out, kernel, weights_dev, krows / 2, s);
 }
 

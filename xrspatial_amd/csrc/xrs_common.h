@@ -254,20 +254,17 @@ int try_launch_focal_circle_f64(const float *in, float *out_mean, float *out_var
 
 // kxk_wide_circle.hip / kxk_wide_box.hip: focal mean / window sum, radius 3..12 cells, float32 on shifted values with a
 // guarded fall-back to the float64 walker (wide_impl.h).  0 = launched, -1 = not such a mask, > 0 = error.
-// `todo_dev` (boxes only; NULL = none): scratch for boxsep.hip's fast walk, xrs_focal_workspace_bytes() of it
 int try_launch_focal_wide_circle(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in,
                                  long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
-                                 hipStream_t s, unsigned char *todo_dev = nullptr);
+                                 hipStream_t s);
 int try_launch_focal_wide_box(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in,
                               long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
-                              hipStream_t s, unsigned char *todo_dev = nullptr);
+                              hipStream_t s);
 // the same TUs: convolve_2d with one weight value on a circle / box of radius 3..12 cells (WIDE_CONV)
 int try_launch_conv_wide_circle(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
-                                const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s,
-                                unsigned char *todo_dev = nullptr);
+                                const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 int try_launch_conv_wide_box(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
-                             const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s,
-                             unsigned char *todo_dev = nullptr);
+                             const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 // kxk_circle2.hip / kxk_box2.hip: all seven statistics in one pass, radius 4..12 cells (walk2_impl.h).
 int try_launch_focal_circle2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
                              float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
@@ -312,11 +309,12 @@ int try_launch_focal_mom_circle(const float *in, float *out_sum, float *out_mean
 int try_launch_focal_mom_box(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows,
                              long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
                              int halo_bot, hipStream_t s, unsigned char *todo_dev = nullptr);
-// boxsep.hip: the separable fast walk for np.ones((krows, kcols)) -- any subset of sum / mean / var / std, or convolve_2d
-// with the one weight `wgt` -- in front of a fall-back kernel whose workgroup tiles (fb_group_cols x fb_tile_rows cells,
-// fb_groups_x per tile row) it marks in `todo` where it cannot stand for its results.  0 = launched, -1 = not for this
-// walk (the caller runs its kernel everywhere), > 0 = error.
-int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, float *out_conv, double wgt,
+// boxsep.hip: the separable fast walk for np.ones((krows, kcols)) -- mean / var / std / sum sets WITH var or std (for the
+// mean or the sum alone it measured no faster than the wide row walker: 0.53 vs 0.55 ms at 25x25, 0.68 vs 0.47 at 11x11) --
+// in front of a fall-back kernel whose workgroup tiles (fb_group_cols x fb_tile_rows cells, fb_groups_x per tile row) it
+// marks in `todo` where it cannot stand for its results.  0 = launched, -1 = not for this walk (the caller runs its kernel
+// everywhere), > 0 = error.
+int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std,
                    long rows, long cols, long ld_in, long ld_out, int krows, int kcols, int halo_top, int halo_bot,
                    unsigned char *todo, long fb_groups_x, int fb_tile_rows, int fb_group_cols, hipStream_t s);
 // bytes of `todo` that is always enough for a rows x cols raster (host side of xrs_focal_workspace_bytes)

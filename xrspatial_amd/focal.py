@@ -124,7 +124,7 @@ def _window_workspace(k, rows=0, cols=0):
     separable box walk (csrc/boxsep.hip; xrs_focal_workspace_bytes).  The block goes back to the pool behind the launch on
     the launch's stream (device.py fences recycled blocks with an event), so nobody has to wait for it."""
     big = max(k.shape) > 63
-    box = k.shape[0] == k.shape[1] and 7 <= k.shape[0] <= 25 and bool((k == 1.0).all())
+    box = k.shape[0] == k.shape[1] and 9 <= k.shape[0] <= 25 and bool((k == 1.0).all())
     if not (big or box):
         return None
     return DeviceArray((int(_lib.load().xrs_focal_workspace_bytes(int(rows), int(cols), k.shape[0], k.shape[1])),), np.uint8)

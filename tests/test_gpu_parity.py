@@ -598,6 +598,76 @@ def test_flat_windows_have_exactly_zero_variance():
                                        equal_nan=True, err_msg=f"{name} {stat}")
 
 
+@pytest.mark.parametrize("shape_kind", ["circle", "box"])
+@pytest.mark.parametrize("K", [5, 7])
+def test_small_window_strip_walker(K, shape_kind):
+    """5x5 / 7x7 circles and boxes with moments among the statistics: the strip walker of sw_impl.h (LDS-DMA row ring, shared
+    row patterns, float64 moments, flat windows through max == min).  A raster large enough to have INTERIOR tiles (the
+    fast body and, where a NaN / inf sits under a window, the NaN-aware body on the DMA ring) next to the rim tiles (the
+    NaN-aware body on predicated loads): every statistic against the oracle -- extrema bit-exact, moments to the float32
+    rounding of float64 results -- lakes exactly flat, all-NaN windows, row shards with halos."""
+    import ctypes
+    from xrspatial_amd import _lib
+    R = K // 2
+    k = circle_kernel(1, 1, R) if shape_kind == "circle" else np.ones((K, K))
+    rows, cols = 700, 1500
+    stats = ['mean', 'max', 'min', 'range', 'std', 'var', 'sum']
+
+    def check(got, zz, lo, hi, what):
+        with np.errstate(all='ignore'):
+            for st in stats:
+                want = corc.focal_apply(zz, k, st, nthreads=8)[lo:hi]
+                arr = got[st]
+                if st in ('max', 'min', 'range'):
+                    np.testing.assert_array_equal(arr, want, err_msg=f"{what} {st}")
+                elif st == 'sum':
+                    np.testing.assert_allclose(arr, want, rtol=1e-5, atol=0, equal_nan=True, err_msg=f"{what} sum")
+                else:
+                    np.testing.assert_allclose(arr, want, rtol=3e-7, atol=0, equal_nan=True, err_msg=f"{what} {st}")
+
+    z = synth.smooth_dem((rows, cols), seed=K)
+    got = focal_stats(raster(z), k, stats_funcs=stats)
+    res = {st: got.data[i] for i, st in enumerate(stats)}
+    check(res, z, 0, rows, "clean")
+    check_window_sum(res['sum'], z, k, "clean sum")
+    for st in stats:
+        parity_log.record('700x1500 clean', f'{shape_kind} {K}x{K} strip walker: {st}', res[st], corc.focal_apply(z, k, st, nthreads=8))
+    z2 = z.copy()
+    rng = np.random.default_rng(K)
+    z2[rng.random(z2.shape) < 0.0005] = np.nan                  # scattered nodata: interior tiles through the NaN-aware body
+    z2[300:300 + 3 * K, 700:700 + 3 * K] = np.nan               # windows without a valid cell
+    z2[500, 100] = np.inf
+    z2[520, 1300] = -np.inf
+    z2[200:260, 300:400] = 777.25                               # a lake: mean = the value, var = std = 0 exactly
+    z2[600:640, 1100:1200] = np.float32(16777217.0)
+    got = focal_stats(raster(z2), k, stats_funcs=stats)
+    res = {st: got.data[i] for i, st in enumerate(stats)}
+    check(res, z2, 0, rows, "holes")
+    for (r0, r1, c0, c1, val) in ((200, 260, 300, 400, 777.25), (600, 640, 1100, 1200, 16777217.0)):
+        inner = (slice(r0 + R, r1 - R), slice(c0 + R, c1 - R))
+        ok = ~np.isnan(corc.focal_apply(z2, k, 'mean', nthreads=8)[inner])
+        assert (res['var'][inner][ok] == 0).all() and (res['std'][inner][ok] == 0).all()
+        full = np.isfinite(z2[r0:r1, c0:c1]).all()
+        if full:
+            np.testing.assert_array_equal(res['mean'][inner], np.float32(val))
+    # subsets of the statistics (other instantiation: planes that are not wanted are NULL)
+    sub = focal_stats(raster(z2), k, stats_funcs=['var', 'mean'])
+    np.testing.assert_array_equal(sub.data[0], res['var'])
+    np.testing.assert_array_equal(sub.data[1], res['mean'])
+    # row shards with halo rows in the same allocation, through the C ABI
+    full_dev = xs.DeviceArray.from_numpy(z2)
+    kk = np.ascontiguousarray(k, dtype=np.float64)
+    for first, n, ht, hb in ((200, 300, R, R), (0, 250, 0, R), (450, 250, R, 0)):
+        outs = {st: xs.DeviceArray((n, cols), np.float32) for st in stats}
+        ptrs = (ctypes.c_void_p * 7)()
+        for i, st in enumerate(orc.FOCAL_STATS):
+            ptrs[i] = outs[st].ptr
+        _lib.call("xrs_focal_stats_f32", full_dev.ptr + first * cols * 4, ptrs, 127, n, cols, cols, cols, kk.ctypes.data, K, K, None,
+                  ht, hb, None)
+        _lib.call("xrs_stream_sync", None)
+        check({st: outs[st].get() for st in stats}, z2, first, first + n, f"shard {first}+{n}")
+
+
 @pytest.mark.parametrize("K", [9, 15, 25])
 def test_separable_box_walk(K):
     """np.ones((k, k)) -- the masks of the reference's own benchmark suite -- through the separable walk of boxsep.hip

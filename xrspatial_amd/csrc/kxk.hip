@@ -1320,6 +1320,13 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                                    rows, cols, ld_in, ld_out, 1.0, 1.0, 0.0, 0.0, halo_top, halo_bot, stream);
     }
     if (stat_mask == (1u << XRS_STAT_MEAN)) return dispatch_focal<true>(a, vec, lds, s);
+    if ((krows == 5 || krows == 7) && krows == kcols && !gen1 && !(seq_sum && a.out[XRS_STAT_SUM]) && !ab_env("XRS_FOCAL_SW_OFF") &&
+        (a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD] || a.out[XRS_STAT_MEAN])) {
+        // small circles / boxes with moments among the statistics: everything from one pass of the strip walker (sw_impl.h)
+        int rc = try_launch_focal_sw_circle(in_dev, a.out, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc < 0) rc = try_launch_focal_sw_box(in_dev, a.out, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
+        if (rc >= 0) return rc;
+    }
     if (krows <= 7 && krows == kcols && (krows >= 5 || ab_env("XRS_FOCAL_WALK3")) && !prefer_strip()) {
         // small circles / boxes (5x5, 7x7): all requested statistics from one column-walker kernel
         const bool f32_stats = a.out[XRS_STAT_SUM] || a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];

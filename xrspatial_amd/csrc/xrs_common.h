@@ -309,6 +309,12 @@ int try_launch_focal_mom_circle(const float *in, float *out_sum, float *out_mean
 int try_launch_focal_mom_box(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows,
                              long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
                              int halo_bot, hipStream_t s, unsigned char *todo_dev = nullptr);
+// kxk_sw_circle.hip / kxk_sw_box.hip (sw_impl.h): any of the seven statistics over circles / boxes of radius 2, 3 cells from one
+// pass of the strip walker (outs: XRS_STAT_* order, NULL = not wanted).  0 = launched, -1 = not such a mask, > 0 = error.
+int try_launch_focal_sw_circle(const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,
+                               const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
+int try_launch_focal_sw_box(const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,
+                            const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 // boxsep.hip: the separable fast walk for np.ones((krows, kcols)) -- mean / var / std / sum sets WITH var or std (for the
 // mean or the sum alone it measured no faster than the wide row walker: 0.53 vs 0.55 ms at 25x25, 0.68 vs 0.47 at 11x11) --
 // in front of a fall-back kernel whose workgroup tiles (fb_group_cols x fb_tile_rows cells, fb_groups_x per tile row) it

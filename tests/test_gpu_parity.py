@@ -435,9 +435,14 @@ def test_third_generation_walkers_interior_and_rim_tiles():
     import ctypes
     rng = np.random.default_rng(11)
     for radius, kind, shape in ((12, 'circle', (560, 1330)), (12, 'box', (420, 800)), (7, 'circle', (450, 900)),
-                                (4, 'circle', (300, 700)), (5, 'box', (431, 1025))):
+                                (4, 'circle', (300, 700)), (5, 'box', (431, 1025)),
+                                # annulus_kernel(1, 1, R, RI): the same walkers, rows across the hole as differences of centred
+                                # runs (moments) / extrema over shells of cell pairs
+                                (10, 'annulus6', (450, 900)), (12, 'annulus4', (560, 1330)), (12, 'annulus11', (420, 800)),
+                                (5, 'annulus2', (431, 1025)), (4, 'annulus1', (300, 700))):
         K = 2 * radius + 1
-        k = circle_kernel(1, 1, radius) if kind == 'circle' else np.ones((K, K))
+        k = (circle_kernel(1, 1, radius) if kind == 'circle' else np.ones((K, K)) if kind == 'box'
+             else annulus_kernel(1, 1, radius, int(kind[7:])))
         steep = synth.smooth_dem(shape, seed=radius)
         holes = steep.copy()
         holes[200, 300] = np.nan

@@ -28,26 +28,80 @@ struct CircleShape {      // circle_kernel on square cells: largest dx with dx^2
         while ((h + 1) * (h + 1) + dy * dy <= R * R) ++h;
         return h;
     }
+    static constexpr int hwi(int, int) { return -1; }      // no hole
 };
 struct BoxShape {         // np.ones((2R+1, 2R+1))
     static constexpr int hw(int R, int) { return R; }
+    static constexpr int hwi(int, int) { return -1; }
+};
+// annulus_kernel(1, 1, R, RI) = circle_kernel(R) - circle_kernel(RI) (convolution.py:199-259): a row at offset dy is the
+// centred run of half-width hw(dy) WITHOUT the centred run of half-width hwi(dy) (-1: no hole in this row) -- two runs,
+// but every sum over them is a difference of two centred-run sums, and every extremum one over a "shell" of cell pairs.
+template <int RI>
+struct AnnulusShape {
+    static constexpr int hw(int R, int dy) { return CircleShape::hw(R, dy); }
+    static constexpr int hwi(int, int dy) { return dy <= RI ? CircleShape::hw(RI, dy) : -1; }
+};
+template <typename Shape>
+constexpr bool shape_has_hole(int R) {
+    for (int dy = 0; dy <= R; ++dy)
+        if (Shape::hwi(R, dy) >= 0) return true;
+    return false;
+}
+// rows at offsets d1, d2 (>= 0) are the same run pattern; d is the smallest offset with its pattern
+template <typename Shape>
+constexpr bool shape_same_row(int R, int d1, int d2) { return Shape::hw(R, d1) == Shape::hw(R, d2) && Shape::hwi(R, d1) == Shape::hwi(R, d2); }
+template <typename Shape>
+constexpr bool shape_first_row(int R, int d) {
+    for (int e = 0; e < d; ++e)
+        if (shape_same_row<Shape>(R, e, d)) return false;
+    return true;
+}
+template <typename Shape>
+constexpr int shape_row_cells(int R, int dy) {             // taps of the row at offset |dy|
+    return 2 * Shape::hw(R, dy) + 1 - (Shape::hwi(R, dy) >= 0 ? 2 * Shape::hwi(R, dy) + 1 : 0);
+}
+
+// the rows of a shape as compile-time tables: hw / hwi per |dy| and pat[d] = the smallest offset with the same (hw, hwi).
+// (Evaluating Shape::hw -- a loop -- per iteration of the walkers' unrolled loops is fine for one call; the row-pattern tests
+// of the hole shapes needed four to six and stopped folding: the round loop came out with 2400 scalar instructions.)
+template <int R, typename Shape>
+struct ShapeRows {
+    int hw[R + 1], hwi[R + 1], pat[R + 1];
+    constexpr ShapeRows() : hw{}, hwi{}, pat{} {
+        for (int d = 0; d <= R; ++d) { hw[d] = Shape::hw(R, d); hwi[d] = Shape::hwi(R, d); }
+        for (int d = 0; d <= R; ++d) {
+            pat[d] = d;
+            for (int e = d - 1; e >= 0; --e)
+                if (hw[e] == hw[d] && hwi[e] == hwi[d]) pat[d] = e;
+        }
+    }
 };
 
 template <typename Shape>
 constexpr int shape_taps(int R) {
     int n = 0;
-    for (int dy = -R; dy <= R; ++dy) n += 2 * Shape::hw(R, dy < 0 ? -dy : dy) + 1;
+    for (int dy = -R; dy <= R; ++dy) n += shape_row_cells<Shape>(R, dy < 0 ? -dy : dy);
     return n;
+}
+
+// host: the inner radius of a K x K mask that could be annulus_kernel(1, 1, K / 2, RI): the zeros of the centre row run from
+// the centre to dx = RI (circle_kernel(RI) has half-width RI in its middle row); -1: the centre cell is set (no hole)
+inline int annulus_inner_radius(const double *kernel, int K) {
+    const int R = K / 2;
+    int ri = -1;
+    while (ri + 1 <= R && kernel[R * K + R + ri + 1] != 1.0) ++ri;
+    return ri;
 }
 
 template <int R, typename Shape>
 inline bool is_shape(const double *kernel) {
     constexpr int K = 2 * R + 1;
     for (int ky = 0; ky < K; ++ky) {
-        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy);
+        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy), hi = Shape::hwi(R, dy);
         for (int kx = 0; kx < K; ++kx) {
             const int dx = kx < R ? R - kx : kx - R;
-            if ((kernel[ky * K + kx] == 1.0) != (dx <= h)) return false;
+            if ((kernel[ky * K + kx] == 1.0) != (dx <= h && dx > hi)) return false;
         }
     }
     return true;
@@ -147,7 +201,8 @@ inline int walk3_tile_base(long rows, long groups_x, int radius, int u, int wg_p
 struct RimFirst {
     long gw, gh, n_rim, n_all;
     // mode 1: rim first; 0: row-major tiles in one contiguous band per XCD (rounds 1-2: XRS_RIM_FIRST=0, A/B runs)
-    __host__ __device__ RimFirst(long gw_, long gh_, int mode = 1) : gw(gw_), gh(gh_) {
+    __host__ __device__ __forceinline__ RimFirst(long gw_, long gh_, int mode = 1) : gw(gw_), gh(gh_) {      // (forced: a CALL of this
+                                                                                                        //  constructor from the largest kernels faulted at address 0)
         n_all = gw * gh;
         n_rim = mode == 0 ? -1 : (gw <= 2 || gh <= 2) ? n_all : 2 * gw + 2 * (gh - 2);
     }
@@ -242,19 +297,43 @@ struct WalkF32 {
 
     __device__ __forceinline__ void row(const float (&v)[K]) {
         if (WANT_MM) {
-            float lo = v[R], hi = v[R];
+            if (!shape_has_hole<Shape>(R)) {
+                float lo = v[R], hi = v[R];
 #pragma unroll
-            for (int h = 0; h <= R; ++h) {
-                if (h > 0) {
-                    lo = fminf(fminf(lo, v[R - h]), v[R + h]);
-                    hi = fmaxf(fmaxf(hi, v[R - h]), v[R + h]);
+                for (int h = 0; h <= R; ++h) {
+                    if (h > 0) {
+                        lo = fminf(fminf(lo, v[R - h]), v[R + h]);
+                        hi = fmaxf(fmaxf(hi, v[R - h]), v[R + h]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int dy = j - R;
+                        if (Shape::hw(R, dy < 0 ? -dy : dy) == h) {
+                            mn[j] = fminf(mn[j], lo);
+                            mx[j] = fmaxf(mx[j], hi);
+                        }
+                    }
                 }
+            } else {
+                // rows with a hole: the extrema over the shell of cell pairs hwi < |dx| <= hw, per distinct row pattern
+                constexpr ShapeRows<R, Shape> T{};
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int dy = j - R;
-                    if (Shape::hw(R, dy < 0 ? -dy : dy) == h) {
-                        mn[j] = fminf(mn[j], lo);
-                        mx[j] = fmaxf(mx[j], hi);
+                for (int d = 0; d <= R; ++d) {
+                    if (T.pat[d] != d) continue;
+                    const int h1 = T.hw[d], h0 = T.hwi[d];
+                    float lo = h0 < 0 ? v[R] : INFINITY, hi = h0 < 0 ? v[R] : -INFINITY;
+#pragma unroll
+                    for (int h = (h0 < 0 ? 1 : h0 + 1); h <= h1; ++h) {
+                        lo = fminf(fminf(lo, v[R - h]), v[R + h]);
+                        hi = fmaxf(fmaxf(hi, v[R - h]), v[R + h]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int dy = j - R;
+                        if (T.pat[dy < 0 ? -dy : dy] == d) {
+                            mn[j] = fminf(mn[j], lo);
+                            mx[j] = fmaxf(mx[j], hi);
+                        }
                     }
                 }
             }
@@ -265,12 +344,14 @@ struct WalkF32 {
             for (int k = 0; k < K; ++k) z[k] = isnan(v[k]) ? 0.0f : v[k];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int h = Shape::hw(R, R - j);
+                const int h = Shape::hw(R, R - j), h0 = Shape::hwi(R, R - j);
 #pragma unroll
-                for (int k = R - h; k <= R + h; ++k) sp[j] += (walk_v2f)(z[k]);
+                for (int k = R - h; k <= R + h; ++k)
+                    if (k - R > h0 || R - k > h0) sp[j] += (walk_v2f)(z[k]);
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) sc += z[k];
+            for (int k = 0; k < K; ++k)
+                if (k - R > Shape::hwi(R, 0) || R - k > Shape::hwi(R, 0)) sc += z[k];
         }
     }
 
@@ -336,7 +417,7 @@ __device__ __forceinline__ void walk_exact_window(const WalkGeom &g, long yo, lo
         const int ky = idx / K, kx = idx - ky * K;
         const int dy = ky < R ? R - ky : ky - R, dx = kx < R ? R - kx : kx - R;
         const long yr = yo - R + ky, xr = xs - R + kx;
-        const bool ok = idx < NT && dx <= Shape::hw(R, dy) && yr >= y_lo && yr < y_hi && xr >= 0 && xr < g.cols;
+        const bool ok = idx < NT && dx <= Shape::hw(R, dy) && dx > Shape::hwi(R, dy) && yr >= y_lo && yr < y_hi && xr >= 0 && xr < g.cols;
         return ok ? g.in[yr * g.ld_in + xr] : nan_f32();
     };
     rocprim::warp_reduce<double, 64>::storage_type st;
@@ -387,6 +468,42 @@ struct WalkF64 {
 
     __device__ __forceinline__ void row(const float (&v)[K]) {
         const double shift = (double)cf;
+        if (shape_has_hole<Shape>(R)) {
+            // rows with a hole: every distinct row pattern summed over its own cells (hwi < |dx| <= hw), centre outwards
+            constexpr ShapeRows<R, Shape> T{};
+#pragma unroll
+            for (int d = 0; d <= R; ++d) {
+                if (T.pat[d] != d) continue;
+                const int h1 = T.hw[d], h0 = T.hwi[d];
+                double S = 0.0, Q = 0.0;
+                int C = 0;
+#pragma unroll
+                for (int h = (h0 < 0 ? 0 : h0 + 1); h <= h1; ++h) {
+#pragma unroll
+                    for (int side = 0; side < (h == 0 ? 1 : 2); ++side) {
+                        const float val = v[side == 0 ? R - h : R + h];
+                        const bool ok = !isnan(val);
+                        const double dd = ok ? (double)val - shift : 0.0;
+                        S += dd;
+                        C += ok ? 1 : 0;
+                        if (WANT_VAR) {
+                            Q = fma(dd, dd, Q);
+                            amax = fmaxf(amax, isfinite(val) ? fabsf(val - cf) : 0.0f);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (T.pat[dy < 0 ? -dy : dy] == d) {
+                        sd[j] += S;
+                        cn[j] += C;
+                        if (WANT_VAR) sq[j] += Q;
+                    }
+                }
+            }
+            return;
+        }
         double S = 0.0, Q = 0.0;
         int C = 0;
 #pragma unroll

@@ -117,17 +117,49 @@ struct ExtWalk {
         }
     }
 
-    // running extrema over the centred runs of one staged row: lo[h] / hi[h] = min / max of cells R - h .. R + h
+    // What an output row needs from one staged row at offset dy: index IDX(|dy|) of the arrays row_levels() fills.
+    // Shapes without a hole: the running extrema over the centred runs, lo[h] / hi[h] = min / max of cells R - h .. R + h,
+    // indexed by the half-width h = hw(dy): R v_min3 + R v_max3.  Shapes with a hole (annuli): indexed by |dy| itself -- rows
+    // outside the hole take the centred run's value, rows across it the extrema over the SHELL of cell pairs
+    // hwi < |dx| <= hw (a chain of hw - hwi v_min3 per distinct row pattern; minNum / maxNum skip NaN cells as before).
+    static constexpr bool HOLE = shape_has_hole<Shape>(R);
+    static constexpr int IDX(int dy) { return HOLE ? dy : Shape::hw(R, dy); }
     __device__ __forceinline__ void row_levels(unsigned row_addr, float (&lo)[R + 1], float (&hi)[R + 1]) const {
         float v[K];
         lds_cfloat *row = lds_row_ptr(row_addr + 4u * (unsigned)lane);
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = row[k];
-        lo[0] = hi[0] = v[R];
+        if (!HOLE) {
+            lo[0] = hi[0] = v[R];
 #pragma unroll
-        for (int h = 1; h <= R; ++h) {
-            lo[h] = ext_min3(lo[h - 1], v[R - h], v[R + h]);
-            hi[h] = ext_max3(hi[h - 1], v[R - h], v[R + h]);
+            for (int h = 1; h <= R; ++h) {
+                lo[h] = ext_min3(lo[h - 1], v[R - h], v[R + h]);
+                hi[h] = ext_max3(hi[h - 1], v[R - h], v[R + h]);
+            }
+            return;
+        }
+        // centred runs for the rows outside the hole (as far out as the widest of them)
+        constexpr ShapeRows<R, Shape> T{};
+        constexpr int HMAX = [] { int m = 0; constexpr ShapeRows<R, Shape> t{}; for (int d = 0; d <= R; ++d) if (t.hwi[d] < 0 && t.hw[d] > m) m = t.hw[d]; return m; }();
+        float clo[R + 1], chi[R + 1];
+        clo[0] = chi[0] = v[R];
+#pragma unroll
+        for (int h = 1; h <= HMAX; ++h) {
+            clo[h] = ext_min3(clo[h - 1], v[R - h], v[R + h]);
+            chi[h] = ext_max3(chi[h - 1], v[R - h], v[R + h]);
+        }
+#pragma unroll
+        for (int d = 0; d <= R; ++d) {
+            const int h1 = T.hw[d], h0 = T.hwi[d];
+            if (h0 < 0) { lo[d] = clo[h1 <= HMAX ? h1 : 0]; hi[d] = chi[h1 <= HMAX ? h1 : 0]; continue; }
+            if (T.pat[d] != d) { lo[d] = lo[T.pat[d]]; hi[d] = hi[T.pat[d]]; continue; }
+            float a = ext_min(v[R - (h0 + 1)], v[R + (h0 + 1)]), b = ext_max(v[R - (h0 + 1)], v[R + (h0 + 1)]);
+#pragma unroll
+            for (int h = h0 + 2; h <= h1; ++h) {
+                a = ext_min3(a, v[R - h], v[R + h]);
+                b = ext_max3(b, v[R - h], v[R + h]);
+            }
+            lo[d] = a; hi[d] = b;
         }
     }
 
@@ -182,7 +214,7 @@ struct ExtWalk {
         for (int dy1 = -R; dy1 < R; ++dy1) {
             constexpr int dummy = 0; (void)dummy;
             const int idx = ((PH - dy1) % K + K) % K;
-            const int h1 = Shape::hw(R, dy1 < 0 ? -dy1 : dy1), h2 = Shape::hw(R, dy1 + 1 < 0 ? -(dy1 + 1) : dy1 + 1);
+            const int h1 = IDX(dy1 < 0 ? -dy1 : dy1), h2 = IDX(dy1 + 1 < 0 ? -(dy1 + 1) : dy1 + 1);
             if (dy1 == -R) {           // a new output row: its first two contributions
                 mn[idx] = ext_min(lo1[h1], lo2[h2]);
                 mx[idx] = ext_max(hi1[h1], hi2[h2]);
@@ -194,7 +226,7 @@ struct ExtWalk {
         // ---- row i completes the output row R rows up (its slot restarts with row i + 1 at dy = -R); row i + 1
         // completes the next one (its slot restarts in the next step)
         constexpr int IA = ((PH - R) % K + K) % K, IB = ((PH - R + 1) % K + K) % K;
-        constexpr int HR = Shape::hw(R, R);
+        constexpr int HR = IDX(R);
         const float loA = ext_min(mn[IA], lo1[HR]), hiA = ext_max(mx[IA], hi1[HR]);
         if (i >= 2 * R) {
             emit(y0 + (i - 2 * R), loA, hiA);
@@ -274,6 +306,7 @@ int launch_ext(ExtArgs &a, const double *kernel, hipStream_t s) {
 
 namespace xrs {
 
+#ifndef XRS_EXT_ANNULUS_RMIN
 // 0 = launched, -1 = not this shape with a radius of 4..12 cells (caller takes another kernel), > 0 = error.
 int XRS_EXT_ENTRY(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols, long ld_in,
                   long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
@@ -294,5 +327,40 @@ int XRS_EXT_ENTRY(const float *in, float *out_max, float *out_min, float *out_ra
         default: return -1;
     }
 }
+#else
+// annulus_kernel(1, 1, R, RI) for XRS_EXT_ANNULUS_RMIN <= R <= XRS_EXT_ANNULUS_RMAX, 1 <= RI < R: one instantiation per pair.
+// 0 = launched, -1 = not such an annulus, > 0 = error.
+template <int RR, int RI>
+int ext_annulus_pair(ExtArgs &a, const double *kernel, int ri, hipStream_t s) {
+    if constexpr (RI >= RR) return -1;
+    else {
+        if (ri == RI) return launch_ext<RR, AnnulusShape<RI>>(a, kernel, s);
+        return ext_annulus_pair<RR, RI + 1>(a, kernel, ri, s);
+    }
+}
+template <int RR>
+int ext_annulus_radius(ExtArgs &a, const double *kernel, int r, int ri, hipStream_t s) {
+    if constexpr (RR > XRS_EXT_ANNULUS_RMAX) return -1;
+    else {
+        if (r == RR) return ext_annulus_pair<RR, 1>(a, kernel, ri, s);
+        return ext_annulus_radius<RR + 1>(a, kernel, r, ri, s);
+    }
+}
+int XRS_EXT_ENTRY(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols, long ld_in,
+                  long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
+    if (krows != kcols || !(krows & 1)) return -1;
+    const int r = krows / 2;
+    if (r < XRS_EXT_ANNULUS_RMIN || r > XRS_EXT_ANNULUS_RMAX) return -1;
+    const int ri = annulus_inner_radius(kernel, krows);
+    if (ri < 1) return -1;
+    if (!out_max && !out_min && !out_range) return 0;
+    ExtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
+    a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
+    a.out_max = out_max; a.out_min = out_min; a.out_range = out_range;
+    return ext_annulus_radius<XRS_EXT_ANNULUS_RMIN>(a, kernel, r, ri, s);
+}
+#endif
 
 }  // namespace xrs

@@ -1055,6 +1055,18 @@ int dispatch_focal(const KxkArgs &a, bool vec, size_t lds, hipStream_t s) {
     return launch_focal<0, 0, MEAN_ONLY ? 0 : 1>(a, vec, lds, s);
 }
 
+// mean / var / std / sum over annulus_kernel(1, 1, R, RI): the moments walker's translation unit for the outer radius
+int launch_mom_annulus(const float *in, float *o_sum, float *o_mean, float *o_var, float *o_std, long rows, long cols, long ld_in,
+                       long ld_out, const double *kernel, int krows, int kcols, int ht, int hb, hipStream_t s) {
+    if (krows != kcols) return -1;
+    switch (krows / 2) {
+#define XRS_ANN(RR) case RR: return try_launch_focal_mom_annulus##RR(in, o_sum, o_mean, o_var, o_std, rows, cols, ld_in, ld_out, kernel, krows, kcols, ht, hb, s);
+        XRS_ANN(4) XRS_ANN(5) XRS_ANN(6) XRS_ANN(7) XRS_ANN(8) XRS_ANN(9) XRS_ANN(10) XRS_ANN(11) XRS_ANN(12)
+#undef XRS_ANN
+        default: return -1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1182,6 +1194,11 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
         if (rc < 0)
             rc = try_launch_focal_wide_box(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
                                            kernel, krows, kcols, halo_top, halo_bot, s);
+        // annulus_kernel(1, 1, R, RI): the moments walker with only the mean / sum planes (its level differences are the
+        // wide walker's; there is no second family of 66 instantiations for them)
+        if (rc < 0 && krows >= 9)
+            rc = launch_mom_annulus(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,
+                                    krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
@@ -1201,6 +1218,12 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                 if (rc < 0)
                     rc = try_launch_focal_ext_box(in_dev, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], rows,
                                                   cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s_mm);
+                // annulus_kernel(1, 1, R, RI): the same walkers, one instantiation per radius pair
+                typedef int (*ExtFn)(const float *, float *, float *, float *, long, long, long, long, const double *, int, int, int, int, hipStream_t);
+                const ExtFn ann[3] = {try_launch_focal_ext_annulus_a, try_launch_focal_ext_annulus_b, try_launch_focal_ext_annulus_c};
+                for (int i = 0; i < 3 && rc < 0; ++i)
+                    rc = ann[i](in_dev, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], rows, cols, ld_in, ld_out, kernel,
+                                krows, kcols, halo_top, halo_bot, s_mm);
             }
             if (rc == 0 && want_mom) {
                 rc = try_launch_focal_mom_circle(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD],
@@ -1208,6 +1231,8 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                 if (rc < 0)
                     rc = try_launch_focal_mom_box(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD],
                                                   rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s, box_todo);
+                if (rc < 0) rc = launch_mom_annulus(in_dev, o_sum, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols,
+                                                    ld_in, ld_out, kernel, krows, kcols, halo_top, halo_bot, s);
             }
             if (rc > 0) return rc;
             if (rc == 0) {

@@ -1,0 +1,7 @@
+// mean / var / std / sum over annulus_kernel(1, 1, 10, RI), RI = 1 .. 9: the float32 trailing-shift moments walker.
+// (one column per lane: with two, the row-pattern differences on top of the radius-10 rings spill ~100 scratch accesses into the
+//  round loop, each reload draining the DMA ring -- 3.4 ms instead of 1.45 for the circle; one column has none)
+#define XRS_MOM_NC 1
+#define XRS_MOM_ANNULUS_R 10
+#define XRS_MOM_ENTRY try_launch_focal_mom_annulus10
+#include "mom_impl.h"

@@ -44,9 +44,13 @@ __device__ __forceinline__ int mom_clipped_count(long yo, long x, long y_lo, lon
     for (int dy = -R; dy <= R; ++dy) {
         const long yr = yo + dy;
         if (yr < y_lo || yr >= y_hi) continue;
-        const int h = Shape::hw(R, dy < 0 ? -dy : dy);
+        const int h = Shape::hw(R, dy < 0 ? -dy : dy), h0 = Shape::hwi(R, dy < 0 ? -dy : dy);
         const long a = x - h < 0 ? 0 : x - h, b = x + h > cols - 1 ? cols - 1 : x + h;
         n += b >= a ? (int)(b - a + 1) : 0;
+        if (h0 >= 0) {                                       // the hole's cells inside the raster
+            const long a0 = x - h0 < 0 ? 0 : x - h0, b0 = x + h0 > cols - 1 ? cols - 1 : x + h0;
+            n -= b0 >= a0 ? (int)(b0 - a0 + 1) : 0;
+        }
     }
     return n;
 }
@@ -192,25 +196,61 @@ struct MomWalk {
         for (int o = 0; o < NC; ++o) w0[o] = w[HL + o];
 #pragma unroll
         for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
+        if constexpr (!shape_has_hole<Shape>(R)) {
+            // every distinct half-width once, into the ring slots of the output rows that see this row with it
 #pragma unroll
-        for (int h = 0; h <= R; ++h) {
-            if (!C::level_used(h)) continue;
-            float S[NC];
-#pragma unroll
-            for (int o = 0; o < NC; ++o) {
-                const int hi = HL + o + h, lo = HL + o - h - 1;
-                S[o] = h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
-            }
-            if (!EDGE && !SQ && h == R) c_next = PHASE == 0 ? S[0] : c_next + S[0];       // (hw(0) == R for every shape)
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int dy = j - R;
-                if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
-                const int idx = ((PHASE - dy) % K + K) % K;
+            for (int h = 0; h <= R; ++h) {
+                if (!C::level_used(h)) continue;
+                float S[NC];
 #pragma unroll
                 for (int o = 0; o < NC; ++o) {
-                    if (SQ) accQ[idx][o] += S[o];
-                    else accS[idx][o] += S[o];
+                    const int hi = HL + o + h, lo = HL + o - h - 1;
+                    S[o] = h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
+                }
+                if (!EDGE && !SQ && h == R) c_next = PHASE == 0 ? S[0] : c_next + S[0];       // (hw(0) == R for every shape)
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
+                    const int idx = ((PHASE - dy) % K + K) % K;
+#pragma unroll
+                    for (int o = 0; o < NC; ++o) {
+                        if (SQ) accQ[idx][o] += S[o];
+                        else accS[idx][o] += S[o];
+                    }
+                }
+            }
+        } else {
+            // a shape with a hole (annuli): every distinct ROW PATTERN once -- the centred run of half-width hw minus the one of
+            // half-width hwi -- through compile-time tables (ShapeRows: evaluated once, not per loop iteration)
+            constexpr ShapeRows<R, Shape> T{};
+            auto run = [&](int h, int o) -> float {          // the centred run of half-width h under owned column o (static h, o)
+                const int hi = HL + o + h, lo = HL + o - h - 1;
+                return h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
+            };
+            if (!EDGE && !SQ) {                                // (the widest run is nobody's level here: its own subtraction)
+                const float W = run(R, 0);
+                c_next = PHASE == 0 ? W : c_next + W;
+            }
+#pragma unroll
+            for (int d = 0; d <= R; ++d) {
+                if (T.pat[d] != d) continue;
+                float S[NC];
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    S[o] = run(T.hw[d], o);
+                    if (T.hwi[d] >= 0) S[o] -= run(T.hwi[d] >= 0 ? T.hwi[d] : 0, o);
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (T.pat[dy < 0 ? -dy : dy] != d) continue;
+                    const int idx = ((PHASE - dy) % K + K) % K;
+#pragma unroll
+                    for (int o = 0; o < NC; ++o) {
+                        if (SQ) accQ[idx][o] += S[o];
+                        else accS[idx][o] += S[o];
+                    }
                 }
             }
         }
@@ -460,7 +500,7 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     WalkGeom &g = a.g;
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
     static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
-    if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_mom_kernel<R, Shape, MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD>, XRS_MOM_WAVES);
+    if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_mom_kernel<R, Shape, shape_has_hole<Shape>(R) ? 0 : (MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD)>, XRS_MOM_WAVES);
     a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::U, wg_per_cu)) - 2 * R;
     const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
@@ -480,9 +520,15 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     }
     const int om = (a.out_sum ? MOM_SUM : 0) | (a.out_mean ? MOM_MEAN : 0) | (a.out_var ? MOM_VAR : 0) | (a.out_std ? MOM_STD : 0);
     constexpr int ALL = MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD, MVS = MOM_MEAN | MOM_VAR | MOM_STD;
-    if (om == ALL) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, ALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (om == MVS) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, MVS>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((focal_mom_kernel<R, Shape, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    // (annuli: one instantiation per (outer, inner) radius pair, the run-time plane set -- 66 pairs up to radius 12)
+    if constexpr (shape_has_hole<Shape>(R)) {
+        (void)om; (void)ALL; (void)MVS;
+        hipLaunchKernelGGL((focal_mom_kernel<R, Shape, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else {
+        if (om == ALL) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, ALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else if (om == MVS) hipLaunchKernelGGL((focal_mom_kernel<R, Shape, MVS>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((focal_mom_kernel<R, Shape, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    }
     XRS_LAUNCH_CHECK();
     return 0;
 }
@@ -491,6 +537,7 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
 
 namespace xrs {
 
+#ifndef XRS_MOM_ANNULUS_R
 // 0 = launched, -1 = not this shape with a radius of 4..12 cells (caller takes another kernel), > 0 = error.
 int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows, long cols,
                   long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
@@ -513,5 +560,31 @@ int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_v
         default: return -1;
     }
 }
+#else
+// annulus_kernel(1, 1, XRS_MOM_ANNULUS_R, RI), 1 <= RI < R: one instantiation per inner radius (one translation unit per
+// outer radius: the moments kernel is the slow one to compile).  0 = launched, -1 = not such an annulus, > 0 = error.
+template <int RI>
+int mom_annulus_pair(MomArgs &a, const double *kernel, int ri, hipStream_t s) {
+    if constexpr (RI >= XRS_MOM_ANNULUS_R) return -1;
+    else {
+        if (ri == RI) return launch_mom<XRS_MOM_ANNULUS_R, AnnulusShape<RI>>(a, kernel, s);
+        return mom_annulus_pair<RI + 1>(a, kernel, ri, s);
+    }
+}
+int XRS_MOM_ENTRY(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows, long cols,
+                  long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                  hipStream_t s) {
+    if (krows != kcols || krows / 2 != XRS_MOM_ANNULUS_R || !(krows & 1)) return -1;
+    const int ri = annulus_inner_radius(kernel, krows);
+    if (ri < 1) return -1;
+    if (!out_sum && !out_mean && !out_var && !out_std) return 0;
+    MomArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
+    a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
+    a.out_sum = out_sum; a.out_mean = out_mean; a.out_var = out_var; a.out_std = out_std;
+    return mom_annulus_pair<1>(a, kernel, ri, s);
+}
+#endif
 
 }  // namespace xrs

@@ -62,7 +62,7 @@ struct MomCfg {
     static constexpr int seen(int idx) {
         const int dy_next = idx <= R ? -idx : K - idx;
         int n = 0;
-        for (int dy = -R; dy < dy_next; ++dy) n += 2 * Shape::hw(R, dy < 0 ? -dy : dy) + 1;
+        for (int dy = -R; dy < dy_next; ++dy) n += shape_row_cells<Shape>(R, dy < 0 ? -dy : dy);
         return n;
     }
 };
@@ -172,22 +172,50 @@ struct MomWalkN {
         const float p0 = p[R];
 #pragma unroll
         for (int k = 1; k < K; ++k) p[k] += p[k - 1];
+        if constexpr (!shape_has_hole<Shape>(R)) {
 #pragma unroll
-        for (int h = 0; h <= R; ++h) {
-            if (!C::level_used(h)) continue;
-            const float S = h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
-            if (h == R) {                                      // (hw(0) == R for every shape)
-                if (WHAT == 0) snapN += S;
-                if (WHAT == 1) snapS += S;
+            for (int h = 0; h <= R; ++h) {
+                if (!C::level_used(h)) continue;
+                const float S = h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
+                if (h == R) {                                  // (hw(0) == R for every shape)
+                    if (WHAT == 0) snapN += S;
+                    if (WHAT == 1) snapS += S;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
+                    const int idx = ((PHASE - dy) % K + K) % K;
+                    if (WHAT == 0) accN[idx] += S;
+                    else if (WHAT == 1) accS[idx] += S;
+                    else accQ[HAVE_Q ? idx : 0] += S;
+                }
+            }
+        } else {
+            // a shape with a hole (annuli): every distinct row pattern once, run(hw) - run(hwi) (compile-time tables)
+            constexpr ShapeRows<R, Shape> T{};
+            auto run = [&](int h) -> float {                 // the centred run of half-width h (static h)
+                return h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
+            };
+            {                                                  // the widest run: the shift's next estimate
+                const float W = run(R);
+                if (WHAT == 0) snapN += W;
+                if (WHAT == 1) snapS += W;
             }
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int dy = j - R;
-                if (Shape::hw(R, dy < 0 ? -dy : dy) != h) continue;
-                const int idx = ((PHASE - dy) % K + K) % K;
-                if (WHAT == 0) accN[idx] += S;
-                else if (WHAT == 1) accS[idx] += S;
-                else accQ[HAVE_Q ? idx : 0] += S;
+            for (int d = 0; d <= R; ++d) {
+                if (T.pat[d] != d) continue;
+                float S = run(T.hw[d]);
+                if (T.hwi[d] >= 0) S -= run(T.hwi[d] >= 0 ? T.hwi[d] : 0);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int dy = j - R;
+                    if (T.pat[dy < 0 ? -dy : dy] != d) continue;
+                    const int idx = ((PHASE - dy) % K + K) % K;
+                    if (WHAT == 0) accN[idx] += S;
+                    else if (WHAT == 1) accS[idx] += S;
+                    else accQ[HAVE_Q ? idx : 0] += S;
+                }
             }
         }
     }

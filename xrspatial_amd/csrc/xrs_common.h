@@ -309,6 +309,24 @@ int try_launch_focal_mom_circle(const float *in, float *out_sum, float *out_mean
 int try_launch_focal_mom_box(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std, long rows,
                              long cols, long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
                              int halo_bot, hipStream_t s, unsigned char *todo_dev = nullptr);
+// kxk_ext_ann_*.hip / kxk_mom_ann*.hip: the same two walkers for annulus_kernel(1, 1, R, RI), 4 <= R <= 12, 1 <= RI < R (one
+// instantiation per pair; the moments walkers one translation unit per outer radius).  0 = launched, -1 = not such an annulus.
+int try_launch_focal_ext_annulus_a(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols,
+                                   long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                                   hipStream_t s);
+int try_launch_focal_ext_annulus_b(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols,
+                                   long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                                   hipStream_t s);
+int try_launch_focal_ext_annulus_c(const float *in, float *out_max, float *out_min, float *out_range, long rows, long cols,
+                                   long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
+                                   hipStream_t s);
+#define XRS_DECL_MOM_ANNULUS(RR)                                                                                              \
+    int try_launch_focal_mom_annulus##RR(const float *in, float *out_sum, float *out_mean, float *out_var, float *out_std,   \
+                                         long rows, long cols, long ld_in, long ld_out, const double *kernel, int krows,     \
+                                         int kcols, int halo_top, int halo_bot, hipStream_t s);
+XRS_DECL_MOM_ANNULUS(4) XRS_DECL_MOM_ANNULUS(5) XRS_DECL_MOM_ANNULUS(6) XRS_DECL_MOM_ANNULUS(7) XRS_DECL_MOM_ANNULUS(8)
+XRS_DECL_MOM_ANNULUS(9) XRS_DECL_MOM_ANNULUS(10) XRS_DECL_MOM_ANNULUS(11) XRS_DECL_MOM_ANNULUS(12)
+#undef XRS_DECL_MOM_ANNULUS
 // kxk_sw_circle.hip / kxk_sw_box.hip (sw_impl.h): any of the seven statistics over circles / boxes of radius 2, 3 cells from one
 // pass of the strip walker (outs: XRS_STAT_* order, NULL = not wanted).  0 = launched, -1 = not such a mask, > 0 = error.
 int try_launch_focal_sw_circle(const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,

@@ -487,6 +487,22 @@ def run_headline(ctx):
                                                                           w25.ctypes.data, 25, 25, work.ptr, 0, 0, stream), reps=3), 4)
         ok["focal_max_min_range_25x25_circle"] = round(timed(lambda: L("xrs_focal_stats_f32", dem_ptr, ptr7, 0b1110, rows, cols, cols, cols,
                                                                        k25.ctypes.data, 25, 25, None, 0, 0, stream), reps=3), 4)
+        # the reference's own benchmark masks (asv: custom_kernel(np.ones(...))) and a ring: through the *_ex entry with the
+        # workspace the host layer passes (tile map of the separable box walk)
+        from xrspatial_amd.convolution import annulus_kernel
+        wsb = int(ctx._lib.load().xrs_focal_workspace_bytes(rows, cols, 25, 25))
+        fwork = xs.DeviceArray((wsb,), np.uint8)
+
+        def stats_ex(k, ptrs, mask, reps=3):
+            kk = np.ascontiguousarray(k, dtype=np.float64)
+            return round(timed(lambda: L("xrs_focal_stats_f32_ex", dem_ptr, ptrs, mask, rows, cols, cols, cols, kk.ctypes.data,
+                                         kk.shape[0], kk.shape[1], fwork.ptr, wsb, 0, 0, 0, stream), reps=reps), 4)
+        ok["focal_stats7_25x25_box"] = stats_ex(np.ones((25, 25)), ptr7, 127)
+        ok["focal_stats7_15x15_box"] = stats_ex(np.ones((15, 15)), ptr7, 127)
+        ok["focal_mean_var_std_25x25_box"] = stats_ex(np.ones((25, 25)), ptr7, 0b110001)
+        ok["focal_stats7_21x21_annulus_10_6"] = stats_ex(annulus_kernel(1, 1, 10, 6), ptr7, 127)
+        ok["focal_stats7_7x7_circle"] = stats_ex(circle_kernel(1, 1, 3), ptr7, 127)
+        del fwork
         ok["slope_frac_of_hbm_peak"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         ok["slope_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / copy_gbs, 3)
         ok["focal_mean_25x25_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["focal_mean_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)

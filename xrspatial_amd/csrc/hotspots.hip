@@ -8,7 +8,7 @@
 //   xrs_hotspots_classify_f32   z in float32 exactly as the reference forms it, int8 out (4 B in + 1 B out per cell).
 #include "xrs_common.h"
 
-#include <rocprim/warp/warp_reduce.hpp>
+#include "wave_reduce.h"
 
 using namespace xrs;
 
@@ -83,11 +83,9 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *x, long n, Mo
             s2 = fma(d, d, s2);
             ++cnt;
         }
-    rocprim::warp_reduce<double, 64>::storage_type sd;
-    rocprim::warp_reduce<unsigned, 64>::storage_type su;
-    rocprim::warp_reduce<double, 64>().reduce(s1, s1, sd);
-    rocprim::warp_reduce<double, 64>().reduce(s2, s2, sd);
-    rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
+    s1 = wave_reduce<WrSum>(s1);                       // (wave_reduce.h: DPP row folds + v_readlane)
+    s2 = wave_reduce<WrSum>(s2);
+    cnt = wave_reduce<WrSum>(cnt);
     // one set of atomics per workgroup (three addresses shared by the whole grid)
     __shared__ double w1[4], w2[4];
     __shared__ unsigned wc[4];

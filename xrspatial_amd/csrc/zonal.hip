@@ -19,7 +19,7 @@
 // at the 1e-16 level.
 #include "xrs_common.h"
 
-#include <rocprim/warp/warp_reduce.hpp>
+#include "wave_reduce.h"
 
 using namespace xrs;
 
@@ -206,15 +206,12 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
                 p.c += 1; p.s += d; p.q += d * d;
                 p.mn = v[k] < p.mn ? v[k] : p.mn; p.mx = v[k] > p.mx ? v[k] : p.mx;
             }
-            // wave64 reductions with DPP cross-lane moves (VALU only: the LDS pipe stays free for the atomics)
-            rocprim::warp_reduce<unsigned, 64>::storage_type su;
-            rocprim::warp_reduce<double, 64>::storage_type sd;
-            typename rocprim::warp_reduce<VT, 64>::storage_type sv;
-            rocprim::warp_reduce<unsigned, 64>().reduce(p.c, p.c, su);
-            rocprim::warp_reduce<double, 64>().reduce(p.s, p.s, sd);
-            rocprim::warp_reduce<double, 64>().reduce(p.q, p.q, sd);
-            rocprim::warp_reduce<VT, 64>().reduce(p.mn, p.mn, sv, rocprim::minimum<VT>());
-            rocprim::warp_reduce<VT, 64>().reduce(p.mx, p.mx, sv, rocprim::maximum<VT>());
+            // wave64 reductions with DPP cross-lane moves (wave_reduce.h; VALU only: the LDS pipe stays free for the atomics)
+            p.c = wave_reduce<WrSum>(p.c);
+            p.s = wave_reduce<WrSum>(p.s);
+            p.q = wave_reduce<WrSum>(p.q);
+            p.mn = wave_reduce<WrMin>(p.mn);
+            p.mx = wave_reduce<WrMax>(p.mx);
             if ((threadIdx.x & 63) == 0 && p.c) acc.add(p);
             continue;
         }
@@ -258,14 +255,11 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
             const bool row_one_zone = (row_bits & 0xfffeu) == 0 && !(row_empty & 1u);
             if (__any(row_one_zone)) {
                 Part<VT> r = p;
-                rocprim::warp_reduce<unsigned, 16>::storage_type su;
-                rocprim::warp_reduce<double, 16>::storage_type sd;
-                typename rocprim::warp_reduce<VT, 16>::storage_type sv;
-                rocprim::warp_reduce<unsigned, 16>().reduce(p.c, r.c, su);
-                rocprim::warp_reduce<double, 16>().reduce(p.s, r.s, sd);
-                rocprim::warp_reduce<double, 16>().reduce(p.q, r.q, sd);
-                rocprim::warp_reduce<VT, 16>().reduce(p.mn, r.mn, sv, rocprim::minimum<VT>());
-                rocprim::warp_reduce<VT, 16>().reduce(p.mx, r.mx, sv, rocprim::maximum<VT>());
+                r.c = row16_reduce<WrSum>(p.c);
+                r.s = row16_reduce<WrSum>(p.s);
+                r.q = row16_reduce<WrSum>(p.q);
+                r.mn = row16_reduce<WrMin>(p.mn);
+                r.mx = row16_reduce<WrMax>(p.mx);
                 if (row_one_zone) {
                     if ((threadIdx.x & 15) == 0) acc.add(r);
                     p.z = -1;

@@ -11,7 +11,7 @@
 // Non-integral ids or ranges above the caller's limit make the host layer fall back to its own path.
 #include "xrs_common.h"
 
-#include <rocprim/warp/warp_reduce.hpp>
+#include "wave_reduce.h"
 
 using namespace xrs;
 
@@ -105,11 +105,9 @@ __global__ void __launch_bounds__(256) scan_kernel(const T *z, long n, ScanResul
             ++cnt;
         }
     });
-    rocprim::warp_reduce<double, 64>::storage_type sd;
-    rocprim::warp_reduce<unsigned, 64>::storage_type su;
-    rocprim::warp_reduce<double, 64>().reduce(mn, mn, sd, rocprim::minimum<double>());
-    rocprim::warp_reduce<double, 64>().reduce(mx, mx, sd, rocprim::maximum<double>());
-    rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
+    mn = wave_reduce<WrMin>(mn);
+    mx = wave_reduce<WrMax>(mx);
+    cnt = wave_reduce<WrSum>(cnt);
     const bool wave_integral = __all(integral);
     // one set of atomics per workgroup
     __shared__ double wmn[4], wmx[4];
@@ -146,11 +144,9 @@ __global__ void __launch_bounds__(256) scan_presence_i32_kernel(const int32_t *z
         if (v != last && (unsigned)v < (unsigned)window) present[v] = 1;    // benign race: every writer stores 1
         last = v;
     });
-    rocprim::warp_reduce<int, 64>::storage_type si;
-    rocprim::warp_reduce<unsigned, 64>::storage_type su;
-    rocprim::warp_reduce<int, 64>().reduce(mn, mn, si, rocprim::minimum<int>());
-    rocprim::warp_reduce<int, 64>().reduce(mx, mx, si, rocprim::maximum<int>());
-    rocprim::warp_reduce<unsigned, 64>().reduce(cnt, cnt, su);
+    mn = wave_reduce<WrMin>(mn);
+    mx = wave_reduce<WrMax>(mx);
+    cnt = wave_reduce<WrSum>(cnt);
     __shared__ int wmn[4], wmx[4];
     __shared__ unsigned wc[4];
     if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; wmn[w] = mn; wmx[w] = mx; wc[w] = cnt; }

@@ -21,7 +21,7 @@ for s in $STEPS; do
     bench)
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
     pmc)
-      timeout 900 python tools/pmc_profile.py copy_kernel,pass_hill_focal5,pass_hill_slope_focal5,focal5_mean,hillshade,slope,aspect,focal25_mean,focal25_stats7,focal25_meanvarstd,focal25_minmaxrange,zonal_1000,zonal_1000_scattered,zonal_5000 \
+      timeout 900 python tools/pmc_profile.py copy_kernel,pass_hill_focal5,pass_hill_slope_focal5,focal5_mean,hillshade,slope,aspect,focal25_mean,focal25_stats7,focal25_meanvarstd,focal25_minmaxrange,focal5_stats7,focal7_stats7,box25_stats7,box25_meanvarstd,annulus21_stats7,zonal_1000,zonal_1000_scattered,zonal_5000 \
         --out $OUT/pmc.json --traffic $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"; tail -3 $OUT/pmc.log ;;
     stats)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$TAG -o s -- \
@@ -40,6 +40,13 @@ for s in $STEPS; do
       timeout 600 python tools/kbench.py --reps 10 --only copy_kernel,stream_1r2w,stream_1r3w,stream_1r7w,hillshade,slope,aspect,curvature,terrain_fused4,pass_aspect_focal5,pass_all4_focal5,pass_hill_focal5,pass_hill_slope_focal5,pass_curv_hill_focal5,pass_hill_focal3,focal5_mean,focal3_mean,focal25_mean,focal25_stats7,focal13_mean,focal13_stats7,box11_mean,box11_stats7 --fast-inputs > $OUT/kb_small.log 2>&1; tail -20 $OUT/kb_small.log ;;
     nan)
       timeout 600 python tools/nan_probe.py > $OUT/nan_probe.log 2>&1; echo "nan rc=$?"; grep -E "focal25|fused|hillshade" $OUT/nan_probe.log | tail -30 ;;
+    n1)
+      # the one-GPU references of the strong-scaling workloads (bench.py quotes speedup_vs_n1 against them): -> profiles/n1_strong.json
+      timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 --write-n1 $OUT/n1_strong.json > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json | head -c 400; echo
+      timeout 600 python bench.py --workload zonal32k --steps 10 --warmup 3 --write-n1 $OUT/n1_strong.json > $OUT/bench_zonal32k.json 2> $OUT/bench_zonal32k.err; cat $OUT/bench_zonal32k.json | head -c 400; echo
+      cat $OUT/n1_strong.json ;;
+    fuzz)
+      for seed in 51 52; do timeout 600 python tests/fuzz_parity.py --seed $seed --cases 500 > $OUT/fuzz_s$seed.log 2>&1; tail -3 $OUT/fuzz_s$seed.log; done ;;
     s64bench)
       timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
     *) echo "unknown step $s" ;;

@@ -31,6 +31,10 @@ for label, frac, block in (("clean", 0.0, False), ("scattered 0.1%", 0.001, Fals
              "focal5_stats7": lambda: focal.focal_stats(A, k5), "focal25_mean": lambda: focal.apply(A, k25),
              "focal25_stats7": lambda: focal.focal_stats(A, k25), "focal25_mean_var_std": lambda: focal.focal_stats(A, k25, stats_funcs=['mean', 'var', 'std']),
              "focal25_max_min_range": lambda: focal.focal_stats(A, k25, stats_funcs=['max', 'min', 'range']),
+             "box25_stats7": lambda: focal.focal_stats(A, np.ones((25, 25))),
+             "box25_mean_var_std": lambda: focal.focal_stats(A, np.ones((25, 25)), stats_funcs=['mean', 'var', 'std']),
+             "focal7_stats7": lambda: focal.focal_stats(A, circle_kernel(1, 1, 3)),
+             "annulus21_stats7": lambda: focal.focal_stats(A, xs.convolution.annulus_kernel(1, 1, 10, 6)),
              "convolve5": lambda: xs.convolution.convolve_2d(dev, k5 / k5.sum()), "focal.mean": lambda: focal.mean(A)}
     for name, fn in cases.items():
         med, mn = t.time(lambda: (fn(), None)[1], 5, warmup=2)

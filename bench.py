@@ -1001,14 +1001,14 @@ def main():
                 result["speedup_vs_n1"] = body.get("speedup_vs_n1")
             elif args.write_n1 and ((args.workload == "s64" and args.s64_size == 65536) or
                                     (args.workload == "zonal32k" and args.zonal_size == 32768)):
-                path = os.path.join(ROOT, "profiles", "n1_strong.json")
+                path = os.path.join(ROOT, "profiles", "n1_strong.json") if args.write_n1 == "1" else args.write_n1
                 try:
                     table = json.load(open(path))
                 except Exception:                     # noqa: BLE001
                     table = {}
                 table[args.workload] = {"ms_per_step": body.get("ms_per_step"), "mcells_s": body.get("mcells_s"),
                                         "build_id": ctx._lib.build_id(), "steps": args.steps}
-                with open(args.write_n1 if args.write_n1 != "1" else path, "w") as fh:
+                with open(path, "w") as fh:
                     json.dump(table, fh, indent=1, sort_keys=True)
     if ctx.rank == 0 and result is not None:
         print(json.dumps(result), flush=True)

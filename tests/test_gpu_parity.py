@@ -235,6 +235,22 @@ def test_terrain_random_ints(dtype):
     np.testing.assert_allclose(xs.hillshade(agg).data, orc.hillshade(data), rtol=RTOL, equal_nan=True)
 
 
+@pytest.mark.parametrize("east", [1e-30, 1e-12, 1e13, 4e13, 6e13, 1e14, 1e20, 1e29])
+def test_aspect_a_hair_west_of_north(east):
+    """A downhill direction a hair west of north.  Less than 4.98e-17 rad off, the reference's float64 arc tangent IS the
+    double nearest pi/2 and `_run_numpy` (aspect.py:80-86) answers 90 - 90 = 0; beyond, 360 - a tiny angle rounds to float32
+    360.  (Found by tests/fuzz_parity.py: one cell of 358 x 908.)"""
+    z = np.zeros((5, 7), np.float32)
+    z[3, 2] = 1e30                      # dz/dy of cell (2, 2): huge
+    z[2, 3] = east                      # dz/dx of cell (2, 2): positive and up to 60 orders of magnitude smaller
+    want = orc.aspect(z)
+    got = xs.aspect(raster(z)).data
+    if east <= 1e20:
+        assert want[2, 2] == (0.0 if east < 4.98e13 else 360.0)
+    np.testing.assert_array_equal(got[2, 2], want[2, 2])
+    np.testing.assert_allclose(got, want, rtol=RTOL, equal_nan=True)
+
+
 def test_flat_and_tiny():
     for shape in [(2, 4), (1, 1), (1, 7), (3, 3)]:
         out = xs.curvature(raster(np.zeros(shape), res=(1, 1))).data

@@ -78,6 +78,9 @@ struct ExtWalk {
     float *lds;                    // this wave's RB row buffers
     long xw, x, y0, y_end, y_first;
     int n_in, lane;
+    const float *dma_src;          // interior: (wave-uniform) first staged cell of the next row to DMA
+    int dma_adv;
+    long out_off;                  // offset of the wave tile's next output row in every plane
 
     __device__ __forceinline__ ExtWalk(const ExtArgs &a_, float *lds_, long xw_, long y0_, long ye, int lane_)
         : a(a_), g(a_.g), lds(lds_), xw(xw_), x(xw_ + lane_), y0(y0_), y_end(ye), lane(lane_) {}
@@ -95,9 +98,12 @@ struct ExtWalk {
     }
 
     // interior: input row `il` (clamped past the tile) -> ring slot `slot`; staged cell s <-> raster column xw - R + s
-    __device__ __forceinline__ void dma_row(int il, int slot) const {
-        const int ilc = il < n_in ? il : n_in - 1;
-        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (xw - R));
+    // (the rows are taken in order: the source pointer advances by a row per call -- dma_adv more times, rows past the tile
+    //  repeat the last -- instead of being re-derived from the row index with a 64-bit scalar multiply)
+    __device__ __forceinline__ void dma_row(int slot) {
+        const float *p = uniform_ptr(dma_src);
+        dma_src += dma_adv > 0 ? g.ld_in : 0;
+        --dma_adv;
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
         glds4_s(p, 4u * (unsigned)lane, dst);
         glds4_s(p, 4u * (unsigned)(64 + (lane < 2 * R ? lane : 2 * R - 1)), dst + 256);        // (lanes >= 2R: a slot nobody reads)
@@ -110,8 +116,11 @@ struct ExtWalk {
         y_first = y0 - R;
         n_in = (int)(y_end - y0) + 2 * R;                // (interior tiles: a whole number of rounds)
         ring_addr = lds_addr(lds);
+        out_off = y0 * g.ld_out + xw;
         if (!EDGE) {
-            for (int r = 0; r < D; ++r) dma_row(r, r);
+            dma_src = uniform_ptr(g.in + y_first * g.ld_in + (xw - R));
+            dma_adv = n_in - 1;
+            for (int r = 0; r < D; ++r) dma_row(r);
             slot_in = D;
             slot_out = 0;
         }
@@ -163,9 +172,11 @@ struct ExtWalk {
         }
     }
 
-    __device__ __forceinline__ void emit(long yo, float lo, float hi) const {
+    // (output rows are emitted in order from y0: the offset of the wave tile's row advances by a row per call)
+    __device__ __forceinline__ void emit(long yo, float lo, float hi) {
+        const long off = out_off;                             // (wave-uniform row address + 4 * lane)
+        out_off += g.ld_out;
         if (EDGE && (x >= g.cols || yo >= y_end)) return;
-        const long off = yo * g.ld_out + xw;                  // (wave-uniform row address + 4 * lane)
         if (a.out_max) st_row_nt(uniform_ptr(a.out_max + off), 4u * (unsigned)lane, hi);
         if (a.out_min) st_row_nt(uniform_ptr(a.out_min + off), 4u * (unsigned)lane, lo);
         if (a.out_range) st_row_nt(uniform_ptr(a.out_range + off), 4u * (unsigned)lane, hi - lo);
@@ -189,9 +200,9 @@ struct ExtWalk {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             row1 = ring_addr; row2 = ring_addr + C::RBF * 4;
         } else {
-            dma_row(i + D, slot_in);
+            dma_row(slot_in);
             slot_in = slot_in + 1 == C::RB ? 0 : slot_in + 1;
-            dma_row(i + D + 1, slot_in);
+            dma_row(slot_in);
             slot_in = slot_in + 1 == C::RB ? 0 : slot_in + 1;
             // Rows i, i + 1 were issued D / 2 steps ago.  Younger vector-memory operations: the DMAs of rows i + 2 ..
             // i + D + 1 (2 each) and -- once the walk emits, from row 2R on -- 2 NO stores per step in between.

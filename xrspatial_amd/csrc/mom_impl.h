@@ -86,6 +86,9 @@ struct MomWalk {
     float *lds;
     long x_tile, y0, y_first;
     int lane;
+    const float *dma_src;          // interior: (wave-uniform) first staged cell of the next row to DMA; the rows are taken in order,
+    int dma_adv;                   // so the pointer advances by a row per DMA (dma_adv more times: rows past the tile repeat the last)
+    long out_off;                  // interior: offset of the wave tile's next output row in every plane
 
     __device__ __forceinline__ MomWalk(const MomArgs &a_, float *lds_, long xt, long y0_, long ye, int lane_)
         : a(a_), g(a_.g), lds(lds_), x_tile(xt), y0(y0_), lane(lane_) { y_end = ye; }
@@ -111,9 +114,10 @@ struct MomWalk {
         badm |= __builtin_amdgcn_ballot_w64(hole);
     }
 
-    __device__ __forceinline__ void dma_row(int il, int slot) const {
-        const int ilc = il < n_in ? il : n_in - 1;
-        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - HL));
+    __device__ __forceinline__ void dma_row(int slot) {
+        const float *p = uniform_ptr(dma_src);
+        dma_src += dma_adv > 0 ? g.ld_in : 0;
+        --dma_adv;
         constexpr int QMAX = C::CELLS / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), ring_addr + (unsigned)slot * (C::RBF * 4));
     }
@@ -159,7 +163,10 @@ struct MomWalk {
         const float c0 = 0.25f * ((p0[0] + p0[NC - 1]) + (p0[g.ld_in] + p0[g.ld_in + NC - 1]));
         c = isfinite(c0) ? c0 : 0.0f;
         c_next = c;
-        for (int r = 0; r < D; ++r) dma_row(r, r);
+        dma_src = uniform_ptr(g.in + y_first * g.ld_in + (x_tile - HL));
+        dma_adv = n_in - 1;
+        out_off = y0 * g.ld_out + x_tile;
+        for (int r = 0; r < D; ++r) dma_row(r);
         slot_in = D;
         slot_out = 0;
     }
@@ -274,7 +281,7 @@ struct MomWalk {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             row = ring_addr + (unsigned)(NC * 4) * (unsigned)lane;
         } else {
-            dma_row(i + D, slot_in);
+            dma_row(slot_in);
             slot_in = slot_in + 1 == D + 1 ? 0 : slot_in + 1;
             // row i was issued D steps ago; younger: D DMAs and -- once the walk emits, from row 2R on -- NO stores per step
             if (i >= 2 * R + D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D * (1 + NO)) : "memory");
@@ -332,7 +339,8 @@ struct MomWalk {
         if (!EDGE && i >= 2 * R) {
             // (row base in scalar registers + one 32-bit lane offset; written as inline asm because the compiler otherwise
             // keeps a 64-bit lane address per output plane alive across the whole walk: 8 registers this kernel does not have)
-            const long rowoff = (y0 + (i - 2 * R)) * g.ld_out + x_tile;
+            const long rowoff = out_off;
+            out_off += g.ld_out;
             constexpr float inv = 1.0f / (float)C::NTAPS;
             stNC r_sum, r_mean, r_var, r_std;
 #pragma unroll

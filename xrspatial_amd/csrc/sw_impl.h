@@ -101,6 +101,8 @@ struct SwWalk {
     unsigned illp;                 // per row of the round (4 bits each): bit o set = output o of this lane needs the exact path
     unsigned long long illm;       // any lane, any row of the round (wave-uniform)
     int slot_in, slot_out, t, n_in;
+    const float *dma_src;          // interior: (wave-uniform) first staged cell of the next row to DMA
+    int dma_adv;
     unsigned ring_addr;
 
     const SwArgs &a;
@@ -113,9 +115,11 @@ struct SwWalk {
         : a(a_), g(a_.g), lds(lds_), x_tile(xt), y0(y0_), y_end(ye), lane(lane_) {}
 
     // interior: input row il (clamped past the tile) -> ring slot; staged cell s <-> raster column x_tile - HS + s
-    __device__ __forceinline__ void dma_row(int il, int slot) const {
-        const int ilc = il < n_in ? il : n_in - 1;
-        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - C::HS));
+    // (rows in order: the source pointer advances by a row per call, dma_adv more times, instead of a 64-bit multiply per row)
+    __device__ __forceinline__ void dma_row(int slot) {
+        const float *p = uniform_ptr(dma_src);
+        dma_src += dma_adv > 0 ? g.ld_in : 0;
+        --dma_adv;
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
         constexpr int QMAX = (C::CELLS < 256 ? C::CELLS : 256) / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), dst);
@@ -169,7 +173,9 @@ struct SwWalk {
         c = (double)(isfinite(v) ? v : have ? v_any : 0.0f);
         if (!EDGE) {
             ring_addr = lds_addr(lds);
-            for (int r = 0; r < D; ++r) dma_row(r, r);
+            dma_src = uniform_ptr(g.in + y_first * g.ld_in + (x_tile - C::HS));
+            dma_adv = n_in - 1;
+            for (int r = 0; r < D; ++r) dma_row(r);
             slot_in = D;
             slot_out = 0;
         }
@@ -180,7 +186,7 @@ struct SwWalk {
         const int i = t + PHASE;
         if (EDGE && i >= n_in) return;
         if (!EDGE) {
-            dma_row(i + D, slot_in);
+            dma_row(slot_in);
             slot_in = slot_in + 1 == D + 1 ? 0 : slot_in + 1;
             // row i was issued D steps ago; younger: D rows of DMAs and -- once the walk emits -- the stores of D steps
             if (i >= 2 * R + D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D * (C::NDMA + NO)) : "memory");

@@ -167,9 +167,10 @@ __device__ __forceinline__ float aspect_from_horn(const Horn &g) {
     float r = z * fmaf(p, t, 57.29577951f);                 // D atan(z), 0 .. 45 degrees
     r = ay > ax ? 90.0f - r : r;
     r = fy > 0.0f ? 180.0f - r : r;                          // x = -fy < 0
-    // y = -fx < 0: 360 - r.  Within 90 * 2^-53 degrees of north the reference's float64 `_aspect` IS 90 and it answers 0, not 360
-    // (aspect.py:80-86; the differential fuzzer found the cell): the same here
-    r = fx > 0.0f ? (r < 1.0e-14f ? 0.0f : 360.0f - r) : r;
+    // y = -fx < 0: 360 - r.  A hair west of north the reference's float64 arc tangent IS pi/2 (the double nearest pi/2 lies
+    // 6.12e-17 below it, half an ulp is 1.11e-16: directions less than 4.98e-17 rad = 2.85e-15 degrees off round to it), its
+    // `ang > 90` is false and it answers 90 - 90 = 0, not 360 (aspect.py:80-86; the differential fuzzer found such a cell)
+    r = fx > 0.0f ? (r < 2.85e-15f ? 0.0f : 360.0f - r) : r;
     r = __builtin_isunordered(fx, fy) ? nan_f32() : r;       // (fmax / fmin skip a NaN operand)
     return (fx == 0.0f && fy == 0.0f) ? -1.0f : r;
 }

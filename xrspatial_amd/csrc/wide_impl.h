@@ -42,6 +42,7 @@
 #include "lds_dma.h"
 #include "mom_nan_walk.h"
 
+#include <type_traits>
 #include <utility>
 
 using namespace xrs;
@@ -78,6 +79,19 @@ struct WideCfg {
     static constexpr int STG = TW + 64;                    // staged cells per row (TW + 2*HL used; every lane writes one halo slot)
     static_assert(2 * HL <= 64, "the halo cells are loaded by one lane each");
     static constexpr int NTAPS = shape_taps<Shape>(R);
+#ifndef XRS_WIDE_SLIDE
+#define XRS_WIDE_SLIDE 1
+#endif
+    // np.ones boxes: every row of the window has the same half-width, so the window sum SLIDES down the raster -- V -= H(row
+    // that left), V += H(entering row) -- with the ring holding the last row sums H instead of 2R+1 partial window sums: 3
+    // ring operations per row and column instead of 2R+1.  That ring is not rotated (its slots change once per row, a rotation
+    // would be 2R+1 moves per round, and so would the register copies at the end of a switch over the round's position in
+    // it -- both measured): it has KR = a whole number of rounds >= 2R+1 slots, the loop body is all KR / U rounds in a straight
+    // line, and a full tile walks a multiple of KR input rows.  V is re-summed from the ring once per KR rows, so the
+    // recurrence rounds at most 2 KR times between two exact states.  Same box, same run (tools/ab_wide.sh): 25x25 mean
+    // 0.55 -> 0.465 ms, uniform-weight 25x25 convolution 0.51 -> 0.465; 15x15 the same either way, 11x11 5 % slower (their
+    // ring was 15 / 11 additions to begin with): radius >= 10 only.
+    static constexpr bool SLIDE = XRS_WIDE_SLIDE && R >= 10 && std::is_same<Shape, BoxShape>::value;
 #ifndef XRS_WALK_U
 #define XRS_WALK_U 5
 #endif
@@ -85,12 +99,14 @@ struct WideCfg {
 #ifndef XRS_WIDE_D
 #define XRS_WIDE_D 8
 #endif
+    static constexpr int KR = SLIDE ? U * ((K + U - 1) / U) : K;   // ring slots
     static constexpr int D = XRS_WIDE_D;                   // interior tiles: rows in flight by LDS-DMA; D + 1 row buffers per wave
     static constexpr int RBF = (TW + 2 * HL > 256) ? (STG > 320 ? STG : 320) : 256;   // floats per ring row (the 16-byte DMA writes a whole KiB, the dword one 256 B more)
     static constexpr int LDS_WAVE = (D + 1) * RBF;    // floats of LDS per wave (a DMA writes whole KiB)
     // input rows a full tile walks: whole rounds covering `base` output rows + the 2R rows of run-in (round 3: the
     // tile height is chosen at launch, walk3_tile_base)
-    static constexpr int nin(int base) { return ((base + 2 * R + U - 1) / U) * U; }
+    static constexpr int UU = SLIDE ? KR : U;              // rows per trip of the walk loop = granularity of a tile's input rows
+    static constexpr int nin(int base) { return ((base + 2 * R + UU - 1) / UU) * UU; }
     static constexpr int NE = 2 * R;                       // the first input row whose completion emits an output row
     static constexpr bool level_used(int h) {
         for (int dy = 0; dy <= R; ++dy)
@@ -126,11 +142,15 @@ struct WideWalk {
     static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW;
 
     // ---- state
-    float acc[K][NC];
+    float acc[C::KR][NC];          // ring: partial window sums of the 2R+1 output rows in flight (SLIDE: the last KR row sums H)
+    float vsum[C::SLIDE ? NC : 1]; // SLIDE: the sliding window sum V
     float pf_own[EDGE ? U : 1][NC];   // EDGE: the rows of the current round, loaded up front
     float pf_halo[EDGE ? U : 1];
     int slot_in, slot_out;         // interior: ring slots of the next DMA / of the row being processed
     unsigned ring_addr;            // LDS byte address of this wave's ring
+    const float *dma_src;          // interior: (wave-uniform) first staged cell of the next row to DMA ...
+    int dma_adv;                   // ... and how many more times it advances (rows past the tile repeat the last one)
+    float *out_row;                // interior: (wave-uniform) first cell of the next output row of this wave tile
     float amax, mmin;
     bool bad;
     int t;                         // input row counter: row y_first + t
@@ -169,9 +189,11 @@ struct WideWalk {
 
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < K; ++j)
+        for (int j = 0; j < C::KR; ++j)
 #pragma unroll
             for (int o = 0; o < NC; ++o) acc[j][o] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < (C::SLIDE ? NC : 1); ++o) vsum[o] = 0.0f;
         amax = 0.0f;
         mmin = INFINITY;
         bad = false;
@@ -189,17 +211,23 @@ struct WideWalk {
         } else {
             ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
             ring_addr = __builtin_amdgcn_readfirstlane(ring_addr);
-            for (int r = 0; r < C::D; ++r) dma_row(r, r);
+            dma_src = uniform_ptr(g.in + y_first * g.ld_in + (x_tile - HL));
+            dma_adv = n_in - 1;
+            out_row = out + y0 * g.ld_out + x_tile;
+            for (int r = 0; r < C::D; ++r) dma_row(r);
             slot_in = C::D;
             slot_out = 0;
         }
     }
 
     // interior: input row `il` (clamped past the tile) -> ring slot `slot`, as a linear image of the TW + 2*HL staged cells
-    __device__ __forceinline__ void dma_row(int il, int slot) const {
+    // (the rows are taken in order: the source pointer advances by one row per call instead of being re-derived from the
+    // row index -- a 64-bit scalar multiply per row)
+    __device__ __forceinline__ void dma_row(int slot) {
         constexpr int CELLS = TW + 2 * HL;
-        const int ilc = il < n_in ? il : n_in - 1;
-        const float *p = uniform_ptr(g.in + (y_first + ilc) * g.ld_in + (x_tile - HL));     // (scalar base + lane offset)
+        const float *p = uniform_ptr(dma_src);                                              // (scalar base + lane offset)
+        dma_src += dma_adv > 0 ? g.ld_in : 0;
+        --dma_adv;
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
         constexpr int QMAX = (CELLS < 256 ? CELLS : 256) / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), dst);
@@ -209,26 +237,27 @@ struct WideWalk {
 
     // One row of the round.  There are no exits inside a round of U steps: with early returns the compiler sinks the
     // ring updates of all phases into the loop latch and spills their operands.
-    template <int PHASE>
+    template <int PHASE, int BASE>
     __device__ __forceinline__ void step() {
         const int i = t + PHASE;
         if (EDGE) {
-            if (i < n_in) process<PHASE>(pf_own[PHASE], pf_halo[PHASE], i);
+            if (i < n_in) process<PHASE, BASE>(pf_own[PHASE], pf_halo[PHASE], i);
         } else {
-            dma_row(i + C::D, slot_in);                          // row i + D on its way while row i is processed
+            dma_row(slot_in);                                    // row i + D on its way while row i is processed
             slot_in = slot_in + 1 == C::D + 1 ? 0 : slot_in + 1;
             // Row i's DMAs were issued D steps ago.  Vector-memory operations younger than them: D * NDMA DMAs, plus --
             // once the walk emits (one store per step from row 2R on) -- the D stores in between: waiting for exactly that
             // many leaves the full D rows in flight; before that, counting no stores is the safe side.
             if (i >= 2 * R + C::D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::D * (NDMA + 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::D * NDMA) : "memory");
-            process<PHASE>(pf_own[0], 0.0f, i);
+            process<PHASE, BASE>(pf_own[0], 0.0f, i);
             slot_out = slot_out + 1 == C::D + 1 ? 0 : slot_out + 1;
         }
     }
 
-    template <int PHASE>
+    template <int PHASE, int BASE>   // BASE: SLIDE's ring slot of the round's first row (0 otherwise)
     __device__ __forceinline__ void process(const float (&q)[NC], float hq, int i) {
+        constexpr int SLOT = (BASE + PHASE) % C::KR;
         const long yy = y_first + i;
         const bool row_in = !EDGE || (yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot);  // wave-uniform
         if (row_in) {
@@ -283,9 +312,20 @@ struct WideWalk {
 #pragma unroll
             for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
             if (CONV) bad |= !isfinite(w[NV - 1]);            // the lanes' totals cover every cell the tile read in this row
+            if (C::SLIDE) {
+                // input row i lives in slot i mod KR; the row that leaves the window, i - (2R+1), K slots behind
+                constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    const int hi = HL + o + R, lo = HL + o - R - 1;
+                    vsum[o] -= acc[LEFT][o];
+                    acc[SLOT][o] = lo >= 0 ? w[hi] - w[lo] : w[hi];
+                    vsum[o] += acc[SLOT][o];
+                }
+            }
             // ---- every distinct half-width once, into the ring slots of the output rows that see this row with it
 #pragma unroll
-            for (int h = 0; h <= R; ++h) {
+            for (int h = 0; h <= R && !C::SLIDE; ++h) {
                 if (!C::level_used(h)) continue;
                 float S[NC];
 #pragma unroll
@@ -302,6 +342,14 @@ struct WideWalk {
                     for (int o = 0; o < NC; ++o) acc[idx][o] += S[o];
                 }
             }
+        } else if (C::SLIDE) {
+            // (EDGE) a row outside the raster: its row sum is 0
+            constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) {
+                vsum[o] -= acc[LEFT][o];
+                acc[SLOT][o] = 0.0f;
+            }
         }
         // ---- the output row R rows up is complete
         constexpr int DONE = ((PHASE - R) % K + K) % K;
@@ -317,7 +365,7 @@ struct WideWalk {
                     n = rows_in ? n_full[o]
                                 : (float)clipped_count<R, Shape>(yo, xo + o, -(long)g.halo_top, g.rows + g.halo_bot, g.cols);
                 }
-                const float s = acc[DONE][o];
+                const float s = C::SLIDE ? vsum[o] : acc[DONE][o];
                 if (CONV) {
                     // full windows only: NaN within R cells of the raster (or shard halo) edge
                     const bool full = !EDGE || (yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot &&
@@ -339,24 +387,52 @@ struct WideWalk {
                 stNC rq;
 #pragma unroll
                 for (int o = 0; o < NC; ++o) rq[o] = res[o];
-                __builtin_nontemporal_store(rq, reinterpret_cast<stNC *>(po));
+                if constexpr (NC == 2) st_row_nt(out_row, 8u * (unsigned)lane, rq);
+                else __builtin_nontemporal_store(rq, reinterpret_cast<stNC *>(out_row + NC * lane));
+                out_row += g.ld_out;
             } else {
 #pragma unroll
                 for (int o = 0; o < NC; ++o)
                     if (xo + o < g.cols) po[o] = res[o];
             }
         }
+        if (!C::SLIDE) {
 #pragma unroll
-        for (int o = 0; o < NC; ++o) acc[DONE][o] = 0.0f;
+            for (int o = 0; o < NC; ++o) acc[DONE][o] = 0.0f;
+        }
     }
 
-    template <int... P>
+    template <int BASE, int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         if (EDGE) (load_row(t + P, pf_own[P], pf_halo[P]), ...);      // edge tiles: all loads of the round first
-        (step<P>(), ...);
-        // the round started at row t with ring slot (j - t) mod K for output row j; the next one starts at t + U
-        ring_rotate<K, U>(acc);
+        (step<P, BASE>(), ...);
         t += U;
+        if constexpr (!C::SLIDE) {
+            // the round started at row t with ring slot (j - t) mod K for output row j; the next one starts at t + U
+            ring_rotate<K, U>(acc);
+        } else if constexpr (BASE + U == C::KR) {
+            // V afresh from the K newest slots (the ring's last row is the newest): a balanced tree, error <= 5 u |V|
+            float v[K][NC];
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int o = 0; o < NC; ++o) v[j][o] = acc[C::KR - 1 - j][o];
+#pragma unroll
+            for (int n = K; n > 1; n = (n + 1) / 2)
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j)
+#pragma unroll
+                    for (int o = 0; o < NC; ++o) v[j][o] += v[n - 1 - j][o];
+#pragma unroll
+            for (int o = 0; o < NC; ++o) vsum[o] = v[0][o];
+        }
+    }
+
+    // SLIDE: all positions of a round in the ring, one after the other
+    template <int... B>
+    __device__ __forceinline__ void ring_cycle(std::integer_sequence<int, B...>) {
+        constexpr auto phases = std::make_integer_sequence<int, U>{};
+        (round<B * U>(phases), ...);
     }
 
     // true: every result of the tile is good; false: the caller redoes the tile with the float64 walker
@@ -364,7 +440,8 @@ struct WideWalk {
         init();
         constexpr auto phases = std::make_integer_sequence<int, U>{};
         while (t < n_in) {
-            round(phases);
+            if constexpr (C::SLIDE) ring_cycle(std::make_integer_sequence<int, C::KR / U>{});
+            else round<0>(phases);
             if (__any(bad)) return false;                    // a non-finite cell: stop early
         }
         // error bound of the float32 sums (header): |delta mean| <= u * A * (K * (2 * NV^2 + K) + K * NTAPS) / n
@@ -375,7 +452,9 @@ struct WideWalk {
             mm = fminf(mm, __shfl_xor(mm, sft));
         }
         constexpr float UNIT = 5.9604645e-8f;
-        constexpr float COEF = UNIT * (float)(K * (2 * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
+        // SLIDE: 2R+1 row sums with 2 NV^2 u A each, the re-summation tree (5 u |V|) and 2 KR roundings of |V| <= NTAPS A
+        constexpr float COEF = UNIT * (float)(C::SLIDE ? K * 2 * NV * NV + (5 + 2 * C::KR) * C::NTAPS
+                                                       : K * (2 * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
         return !__any(bad) && (COEF * a <= 0.9e-5f * mm);
     }
 };
@@ -452,7 +531,7 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
     static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
     if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_wide_kernel<R, Shape, WIDE_MEAN>, XRS_WIDE_WAVES);
-    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::U, wg_per_cu)) - 2 * R;
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::UU, wg_per_cu)) - 2 * R;
     const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;
@@ -481,7 +560,7 @@ int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double
     g.tiles_x = (g.cols + C::TW - 1) / C::TW;
     static thread_local int wg_per_cu = 0;                     // (per instantiation: registers depend on the radius)
     if (!wg_per_cu) wg_per_cu = walk3_wg_per_cu(focal_wide_kernel<R, Shape, WIDE_MEAN>, XRS_WIDE_WAVES);
-    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::U, wg_per_cu)) - 2 * R;
+    a.tile_rows = C::nin(walk3_tile_base(g.rows, (g.tiles_x + 3) / 4, R, C::UU, wg_per_cu)) - 2 * R;
     const long tiles_y = (g.rows + a.tile_rows - 1) / a.tile_rows;
     g.n_tiles = g.tiles_x * tiles_y;
     a.groups_x = (g.tiles_x + 3) / 4;

@@ -356,6 +356,11 @@ def run_headline(ctx):
         L("xrs_raster_pass_f32", dem_ptr + off, None, None, None, out_hill.ptr + off, out_focal.ptr + off,
           kernel.ctypes.data, kr, kc, None, n, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, stream)
 
+    def launch_fused_edges(edge, top, bot):
+        # both edges of the shard in one launch over two segments of tile rows
+        L("xrs_raster_pass_edges_f32", dem_ptr, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data, kr, kc,
+          None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, edge, stream)
+
     comm = ctx.comm
     halo_via = ctx.halo_via
     # N > 1 with RCCL: only the 16 rows at either end of a shard wait for the neighbours' rows; the interior
@@ -371,7 +376,7 @@ def run_headline(ctx):
             if events:
                 L("xrs_event_record", events[0], stream)
             overlap.step(lambda s: L("xrs_halo_exchange_f32", comm.handle, dem_ptr, rows, cols, cols, HALO, s),
-                         launch_fused_rows, ht, hb)
+                         launch_fused_rows, ht, hb, launch_edges=launch_fused_edges)
             if events:
                 L("xrs_event_record", events[1], stream)
                 L("xrs_event_record", events[2], stream)

@@ -131,6 +131,19 @@ int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev
                         double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
                         int halo_top, int halo_bot, void *stream);
 
+/* The same pass over only the first and the last `edge_rows` rows of the raster (a row shard whose halo rows have just
+ * arrived: the rows in between were launched earlier, while the exchange was in flight -- what a dask graph does with
+ * map_overlap(depth, boundary=nan), slope.py:86-97, the scheduler does here with two streams).  ONE launch over two
+ * segments of tile rows when the fused kernel takes the request (3x3 / 5x5 masks: results are those of xrs_raster_pass_f32
+ * on the whole raster, bit for bit), the two sub-range calls otherwise (what any row split of that request gives).  Rows
+ * between the edges are not written, except up to 15 rows
+ * above the last edge, which receive the values the whole-raster pass gives them.  2 * edge_rows >= rows: the whole raster. */
+int xrs_raster_pass_edges_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                              float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                              int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                              double cellsize_x, double cellsize_y, double azimuth, double angle_altitude,
+                              int halo_top, int halo_bot, int64_t edge_rows, void *stream);
+
 /* Geodesic slope / aspect (method='geodesic'): WGS-84 ECEF -> local ENU plane fit per 3x3 window, float64
  * arithmetic, float32 out, NaN border, NaN if any of the nine elevations is NaN.  Replaces
  * _cpu_geodesic_slope / _cpu_geodesic_aspect (xrspatial/geodesic.py:181-229) behind slope.py:167-174 and

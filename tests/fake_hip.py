@@ -106,6 +106,21 @@ def call(name, *a):
         if o_f:
             kern = _kernel(k, kr, kc)
             _stencil(lambda v: orc.focal_apply(v, kern, 'mean'), i, o_f, rows, cols, ld_i, ld_o, ht, hb)
+    elif name == "xrs_raster_pass_edges_f32":
+        # the first and last `edge` rows, as the two sub-range calls of the C ABI's contract
+        i, o_s, o_a, o_c, o_h, o_f, k, kr, kc, w, rows, cols, ld_i, ld_o, cx, cy, az, alt, ht, hb, edge, st = a
+        rows, edge = int(rows), int(edge)
+        if 2 * edge >= rows:
+            return call("xrs_raster_pass_f32", i, o_s, o_a, o_c, o_h, o_f, k, kr, kc, w, rows, cols, ld_i, ld_o, cx, cy, az,
+                        alt, ht, hb, st)
+        if edge == 0:
+            return 0
+        at = lambda p, rws, ld: (_host_ptr(p) + rws * int(ld) * 4) if p else None
+        call("xrs_raster_pass_f32", i, o_s, o_a, o_c, o_h, o_f, k, kr, kc, w, edge, cols, ld_i, ld_o, cx, cy, az, alt, ht,
+             rows - edge, st)
+        off = rows - edge
+        call("xrs_raster_pass_f32", at(i, off, ld_i), at(o_s, off, ld_o), at(o_a, off, ld_o), at(o_c, off, ld_o),
+             at(o_h, off, ld_o), at(o_f, off, ld_o), k, kr, kc, w, edge, cols, ld_i, ld_o, cx, cy, az, alt, rows - edge, hb, st)
     elif name in ("xrs_focal_stats_f32", "xrs_focal_stats_f32_ex"):
         if name.endswith("_ex"):
             a = a[:11] + a[12:14] + a[15:]           # (workspace size, accuracy flags: the oracle is exact either way)

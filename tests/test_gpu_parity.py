@@ -1355,9 +1355,11 @@ def test_fuse_scope(backend):
     assert xs.fused.current() is None
 
 
-def test_overlapped_halo_split_equals_monolithic():
+@pytest.mark.parametrize("folded", [False, True])
+def test_overlapped_halo_split_equals_monolithic(folded):
     """distributed.OverlappedHalo: interior rows launched while the (here: stand-in) exchange runs on its own
-    stream, edge rows after it -- three shards of one raster reproduce the monolithic pass, step after step."""
+    stream, edge rows after it -- three shards of one raster reproduce the monolithic pass, step after step.
+    folded: both edges in one launch (xrs_raster_pass_edges_f32), as bench.py's N > 1 step does."""
     from xrspatial_amd import _lib
     from xrspatial_amd.distributed import OverlappedHalo, shard_rows
     import ctypes
@@ -1390,11 +1392,16 @@ def test_overlapped_halo_split_equals_monolithic():
                       outs['focal_mean'].ptr + off, k5.ctypes.data, 5, 5, None, n, cols, cols, cols, 1.0, 1.0,
                       225.0, 25.0, top, bot, main)
 
+        def launch_edges(edge, top, bot):
+            _lib.call("xrs_raster_pass_edges_f32", own, outs['slope'].ptr, None, None, outs['hillshade'].ptr,
+                      outs['focal_mean'].ptr, k5.ctypes.data, 5, 5, None, rows, cols, cols, cols, 1.0, 1.0,
+                      225.0, 25.0, top, bot, edge, main)
+
         ov = OverlappedHalo(rows, H, edge=16, main_stream=main)
         plan = ov.plan(ht, hb)
         assert sum(p[1] for p in plan) == rows and [p[4] for p in plan] == [False, True, True]
         for _ in range(3):
-            ov.step(exchange, launch, ht, hb)
+            ov.step(exchange, launch, ht, hb, launch_edges=launch_edges if folded else None)
         _lib.call("xrs_stream_sync", main)
         assert 0.0 <= ov.last_exchange_ms() < 50.0
         ov.close()
@@ -1403,6 +1410,54 @@ def test_overlapped_halo_split_equals_monolithic():
     # a shard shorter than two edges is launched whole, after the exchange
     assert OverlappedHalo(20, 2, edge=16, main_stream=main).plan(2, 0) == [(0, 20, 2, 0, True)]
     _lib.call("xrs_stream_destroy", main)
+
+
+@pytest.mark.parametrize("rows,edge", [(160, 16), (150, 16), (75, 20), (40, 16), (30, 16), (64, 0)])
+@pytest.mark.parametrize("products", ["hill+focal5", "slope+aspect+focal3", "aspect+focal7"])
+def test_raster_pass_edges_entry(rows, edge, products):
+    """xrs_raster_pass_edges_f32: the first and last `edge` rows of a shard (halo rows above and below it) get exactly what
+    the whole-shard pass gives them -- in one launch over two tile-row segments where the fused kernel takes the request
+    (5x5 / 3x3 masks), as two sub-range calls otherwise (7x7: the focal mean falls back to xrs_focal_stats_f32) -- and the
+    rows between the edges are left alone, except fewer than 16 rows above the last edge, which may get their own values."""
+    from xrspatial_amd import _lib
+    H, cols = 3, 700
+    z = synth.smooth_dem((rows + 2 * H, cols), nan_frac=0.003)
+    kk = {"hill+focal5": circle_kernel(1, 1, 2), "slope+aspect+focal3": np.ones((3, 3)), "aspect+focal7": circle_kernel(1, 1, 3)}
+    k = np.ascontiguousarray(kk[products], dtype=np.float64)
+    names = {"hill+focal5": ("hillshade", "focal"), "slope+aspect+focal3": ("slope", "aspect", "focal"),
+             "aspect+focal7": ("aspect", "focal")}[products]
+    buf = xs.DeviceArray.from_numpy(z)
+    own = buf.ptr + H * cols * 4
+
+    def run(edge_rows):
+        outs = {n: xs.DeviceArray.from_numpy(np.full((rows, cols), -777.0, np.float32)) for n in names}
+        p = lambda n: outs[n].ptr if n in outs else None
+        args = (own, p("slope"), p("aspect"), None, p("hillshade"), p("focal"), k.ctypes.data, k.shape[0], k.shape[1], None,
+                rows, cols, cols, cols, 2.0, 3.0, 225.0, 25.0, H, H)
+        if edge_rows is None:
+            _lib.call("xrs_raster_pass_f32", *args, None)
+        else:
+            _lib.call("xrs_raster_pass_edges_f32", *args, edge_rows, None)
+        _lib.call("xrs_stream_sync", None)
+        return {n: a.get() for n, a in outs.items()}
+
+    whole, edges = run(None), run(edge)
+    for n in names:
+        w, e = whole[n], edges[n]
+        # (the 7x7 mean is a large-window walker's: its last bit depends on where a tile starts, like any row split of it)
+        same = np.testing.assert_array_equal if (n != "focal" or k.shape[0] <= 5) else \
+            (lambda a, b, err_msg: np.testing.assert_allclose(a, b, rtol=1e-6, equal_nan=True, err_msg=err_msg))
+        if 2 * edge >= rows:
+            same(e, w, err_msg=n)
+            continue
+        same(e[:edge], w[:edge], err_msg=n)
+        same(e[rows - edge:], w[rows - edge:], err_msg=n)
+        mid = e[edge:rows - edge]
+        assert ((mid == -777.0) | (mid == w[edge:rows - edge]) | (np.isnan(mid) & np.isnan(w[edge:rows - edge]))).all(), n
+        untouched = rows - edge - 15 - edge
+        if untouched > 0:
+            top_rows = (edge + 15) // 16 * 16             # (the first segment is whole tile rows too)
+            assert (e[top_rows:rows - edge - 15] == -777.0).all(), n
 
 
 def test_device_side_cast_matches_numpy_astype():

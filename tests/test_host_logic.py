@@ -392,6 +392,48 @@ def test_every_device_entry_point_refuses_to_run_without_the_gpu():
             call()
 
 
+@pytest.mark.parametrize("folded", [False, True])
+def test_overlapped_halo_step_order_and_folded_edges(monkeypatch, folded):
+    """OverlappedHalo.step on the host side (C ABI: tests/fake_hip.py): interior rows before the wait for the exchange, the
+    edges after it -- as two launches or, with `launch_edges`, as ONE call of xrs_raster_pass_edges_f32 -- and either way the
+    shard's result is the monolithic pass."""
+    import ctypes
+    from tests import fake_hip
+    from xrspatial_amd import _lib
+    from xrspatial_amd.distributed import OverlappedHalo
+    fake_hip.install(monkeypatch)
+    H, rows, cols = 2, 44, 24
+    z = np.random.default_rng(5).normal(100, 5, (rows + 2 * H, cols)).astype(np.float32)
+    k = np.ascontiguousarray([[0, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=np.float64)
+    out_h, out_f = np.full((rows, cols), -1, np.float32), np.full((rows, cols), -1, np.float32)
+    own = z.ctypes.data + H * cols * 4
+    log = []
+
+    def launch(first, n, top, bot):
+        log.append(("rows", first, n, top, bot))
+        off = first * cols * 4
+        _lib.call("xrs_raster_pass_f32", own + off, None, None, None, out_h.ctypes.data + off, out_f.ctypes.data + off,
+                  k.ctypes.data, 3, 3, None, n, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, None)
+
+    def launch_edges(edge, top, bot):
+        log.append(("edges", edge, top, bot))
+        _lib.call("xrs_raster_pass_edges_f32", own, None, None, None, out_h.ctypes.data, out_f.ctypes.data, k.ctypes.data, 3, 3,
+                  None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, edge, None)
+
+    ov = OverlappedHalo(rows, H, edge=16)
+    ov.step(lambda stream: log.append(("exchange",)), launch, H, H, launch_edges=launch_edges if folded else None)
+    ov.close()
+    if folded:
+        assert log == [("exchange",), ("rows", 16, 12, 2, 2), ("edges", 16, 2, 2)]
+    else:
+        assert log == [("exchange",), ("rows", 16, 12, 2, 2), ("rows", 0, 16, 2, 2), ("rows", 28, 16, 2, 2)]
+    ref_h, ref_f = np.empty_like(out_h), np.empty_like(out_f)
+    _lib.call("xrs_raster_pass_f32", own, None, None, None, ref_h.ctypes.data, ref_f.ctypes.data, k.ctypes.data, 3, 3, None,
+              rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, H, H, None)
+    np.testing.assert_array_equal(out_h, ref_h)
+    np.testing.assert_array_equal(out_f, ref_f)
+
+
 def test_sharded_array_bookkeeping(monkeypatch):
     """ShardedArray without neighbours (world 1) and with a recording transport: when rows are exchanged, how deep,
     what halo_top / halo_bot each rank passes on, and which calls refuse a sharded raster.  (C ABI: tests/fake_hip.py.)"""

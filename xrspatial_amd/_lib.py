@@ -74,6 +74,9 @@ _PROTOTYPES = {
     "xrs_raster_pass_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                             c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_double, c_double, c_double,
                             c_int, c_int, c_void_p],
+    "xrs_raster_pass_edges_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_double, c_double, c_double,
+                                  c_int, c_int, c_int64, c_void_p],
     "xrs_geodesic_workspace_bytes": [c_int64, c_int64],
     "xrs_geodesic_f32": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_int64,
                          c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int, c_int, c_void_p],

@@ -35,6 +35,9 @@ struct PassArgs {
     unsigned mask_rows[5];    // bit kx of entry ky: tap (ky, kx) selected
     double inv_ntaps;
     long tiles_x, n_tiles;
+    // xrs_raster_pass_edges_f32: the launch covers tile rows [0, seg_tiles_y) and, after a gap of seg_skip tile rows, the rest
+    // (0 / 0: every tile row, in order)
+    long seg_tiles_y, seg_skip;
 };
 
 // A lane's 4 results.  NT (compile-time: every output row 16-byte aligned): one non-temporal 16-byte store -- results
@@ -287,7 +290,8 @@ template <int OPS, int KH, int KW, int RB, bool NT, unsigned CMASK = 0u>
 __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? XRS_LB_PASS_HORN : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
-    const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const long tyl = t / a.tiles_x, tx = t - tyl * a.tiles_x;
+    const long ty = tyl >= a.seg_tiles_y ? tyl + a.seg_skip : tyl;          // (two row segments in one launch: see PassArgs)
     const int lane = threadIdx.x & 63;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long x_tile = tx * 256;
@@ -311,6 +315,7 @@ int launch_pass(PassArgs &a, hipStream_t s) {
     constexpr int RB = XRS_PASS_RB;
     a.tiles_x = (a.cols + 255) / 256;
     a.n_tiles = a.tiles_x * ((a.rows + 4 * RB - 1) / (4 * RB));
+    if (a.seg_skip > 0) a.n_tiles -= a.tiles_x * a.seg_skip;               // (the caller made the segments whole tile rows)
     const long grid = xcd_grid(a.n_tiles, a.tiles_x);
     if (grid > 0x7fffffffL) return fail("raster pass: raster too large for one launch");
     // circle_kernel(1, 1, 2): rows 00100 / 01110 / 11111 / 01110 / 00100
@@ -386,11 +391,13 @@ bool pass_has_compile_time_mask(const double *kernel, int krows, int kcols) {
 }
 }  // namespace xrs
 
-extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
-                                   float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
-                                   int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in,
-                                   int64_t ld_out, double cellsize_x, double cellsize_y, double azimuth,
-                                   double angle_altitude, int halo_top, int halo_bot, void *stream) {
+// edge_rows < 0: the whole raster.  edge_rows >= 0 (xrs_raster_pass_edges_f32): only its first and last edge_rows rows --
+// in ONE launch over two segments of tile rows when the fused kernel takes the request, as two calls otherwise.
+static int raster_pass(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                       float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                       int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                       int64_t ld_out, double cellsize_x, double cellsize_y, double azimuth,
+                       double angle_altitude, int halo_top, int halo_bot, int64_t edge_rows, void *stream) {
     if (!in_dev) return fail("xrs_raster_pass_f32: null input");
     if (focal_mean_dev && (!kernel || krows <= 0 || kcols <= 0 || !(krows & 1) || !(kcols & 1)))
         return fail("xrs_raster_pass_f32: a focal mean needs an odd-shaped kernel");
@@ -422,6 +429,29 @@ extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float 
     }
     // products that stay with the stand-alone terrain kernel: all of them without the fused kernel, aspect with it
     const int rest = fast ? (ops & ~FUSABLE) : ops;
+    // the two segments as whole rows of tiles (16 raster rows each): [0, seg_a) and [seg_b, end); the rows of the second one above the edge
+    // proper are interior rows computed a second time with the same result (the same kernel on the same cells)
+    constexpr long TILE_ROWS = 4 * XRS_PASS_RB;
+    const long seg_a = edge_rows >= 0 ? (edge_rows + TILE_ROWS - 1) / TILE_ROWS : 0, seg_b = edge_rows >= 0 ? (rows - edge_rows) / TILE_ROWS : 0;
+    if (edge_rows == 0) return 0;
+    if (edge_rows > 0 && (rest || !fast || seg_b <= seg_a)) {
+        if (2 * edge_rows >= rows)
+            return raster_pass(in_dev, slope_dev, aspect_dev, curvature_dev, hillshade_dev, focal_mean_dev, kernel, krows, kcols,
+                               work_dev, rows, cols, ld_in, ld_out, cellsize_x, cellsize_y, azimuth, angle_altitude, halo_top,
+                               halo_bot, -1, stream);
+        // two calls: the rows between the edges are the halo of either (as many of them as a window can reach)
+        const int64_t between = rows - 2 * edge_rows, off = rows - edge_rows;
+        const int inner = (int)(between + edge_rows < 4096 ? between + edge_rows : 4096);
+        auto at = [](float *p, int64_t o) { return p ? p + o : nullptr; };
+        int rc = raster_pass(in_dev, slope_dev, aspect_dev, curvature_dev, hillshade_dev, focal_mean_dev, kernel, krows, kcols,
+                             work_dev, edge_rows, cols, ld_in, ld_out, cellsize_x, cellsize_y, azimuth, angle_altitude, halo_top,
+                             inner, -1, stream);
+        if (rc) return rc;
+        return raster_pass(in_dev + off * ld_in, at(slope_dev, off * ld_out), at(aspect_dev, off * ld_out),
+                           at(curvature_dev, off * ld_out), at(hillshade_dev, off * ld_out), at(focal_mean_dev, off * ld_out),
+                           kernel, krows, kcols, work_dev, edge_rows, cols, ld_in, ld_out, cellsize_x, cellsize_y, azimuth,
+                           angle_altitude, inner, halo_bot, -1, stream);
+    }
     if (rest) {
         const int rc = xrs_terrain_fused_f32(in_dev, (rest & OP_SLOPE) ? slope_dev : nullptr,
                                              (rest & OP_ASPECT) ? aspect_dev : nullptr,
@@ -455,5 +485,28 @@ extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float 
         for (int kx = 0; kx < kcols; ++kx)
             if (kernel[ky * kcols + kx] == 1.0) a.mask_rows[ky] |= 1u << kx;
     a.inv_ntaps = 1.0 / ntaps;
+    if (edge_rows >= 0) { a.seg_tiles_y = seg_a; a.seg_skip = seg_b - seg_a; }
     return krows == 3 ? launch_pass_ops<3>(a, fused_ops, as_stream(stream)) : launch_pass_ops<5>(a, fused_ops, as_stream(stream));
+}
+
+extern "C" int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                                   float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                                   int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                                   int64_t ld_out, double cellsize_x, double cellsize_y, double azimuth,
+                                   double angle_altitude, int halo_top, int halo_bot, void *stream) {
+    return raster_pass(in_dev, slope_dev, aspect_dev, curvature_dev, hillshade_dev, focal_mean_dev, kernel, krows, kcols,
+                       work_dev, rows, cols, ld_in, ld_out, cellsize_x, cellsize_y, azimuth, angle_altitude, halo_top,
+                       halo_bot, -1, stream);
+}
+
+extern "C" int xrs_raster_pass_edges_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
+                                         float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
+                                         int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in,
+                                         int64_t ld_out, double cellsize_x, double cellsize_y, double azimuth,
+                                         double angle_altitude, int halo_top, int halo_bot, int64_t edge_rows,
+                                         void *stream) {
+    if (edge_rows < 0) return fail("xrs_raster_pass_edges_f32: edge_rows must not be negative");
+    return raster_pass(in_dev, slope_dev, aspect_dev, curvature_dev, hillshade_dev, focal_mean_dev, kernel, krows, kcols,
+                       work_dev, rows, cols, ld_in, ld_out, cellsize_x, cellsize_y, azimuth, angle_altitude, halo_top,
+                       halo_bot, edge_rows, stream);
 }

@@ -268,8 +268,9 @@ class OverlappedHalo:
     Only the `edge` rows at the top and bottom of a shard depend on the neighbours' rows, so one step is
         comm stream:  [wait: previous step's edge launches]  halo exchange  -> event
         main stream:  interior rows (halo rows = the shard's own rows)  [wait: event]  top edge, bottom edge
-    The interior launch (all but 2*edge rows) runs while the exchange is in flight over xGMI; the two edge
-    launches are a few dozen workgroups each.  The C ABI needs nothing special for this: every stencil entry
+    The interior launch (all but 2*edge rows) runs while the exchange is in flight over xGMI; the two edges
+    are a few dozen workgroups each -- one launch for both where the entry point has an `_edges` form
+    (`launch_edges` of step()), two otherwise.  The C ABI needs nothing special for this: every stencil entry
     point takes a pointer to the first owned row, a row count and halo_top / halo_bot, so a sub-range of a
     shard is just another call.
 
@@ -295,17 +296,23 @@ class OverlappedHalo:
     def plan(self, halo_top: int, halo_bot: int):
         return halo_plan(self.rows, self.halo, self.edge, halo_top, halo_bot)
 
-    def step(self, exchange, launch, halo_top: int, halo_bot: int):
+    def step(self, exchange, launch, halo_top: int, halo_bot: int, launch_edges=None):
+        """`launch_edges(edge, halo_top, halo_bot)`, if given, computes the first and last `edge` rows of the whole shard in
+        ONE launch (xrs_raster_pass_edges_f32) instead of `launch` being called once per edge."""
         # the exchange overwrites halo rows the previous step's edge launches may still be reading
         _lib.call("xrs_stream_wait_event", self.comm_stream, self.ev_done)
         _lib.call("xrs_event_record", self.ev_x0, self.comm_stream)
         exchange(self.comm_stream)
         _lib.call("xrs_event_record", self.ev_halo, self.comm_stream)
         waited = False
-        for first, n, ht, hb, needs in self.plan(halo_top, halo_bot):
+        plan = self.plan(halo_top, halo_bot)
+        for first, n, ht, hb, needs in plan:
             if needs and not waited:
                 _lib.call("xrs_stream_wait_event", self.main, self.ev_halo)
                 waited = True
+                if launch_edges is not None and len(plan) == 3:
+                    launch_edges(self.edge, halo_top, halo_bot)
+                    break
             launch(first, n, ht, hb)
         _lib.call("xrs_event_record", self.ev_done, self.main)
 

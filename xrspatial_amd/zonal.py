@@ -214,9 +214,12 @@ def zonal_partials(zone_idx, values, n_zones, nodata_values=None, comm=None, tab
 
 
 # (zones x distinct values) counters of the counting path: the regime in which xrs_crosstab_counts keeps the whole table
-# in per-workgroup LDS counters (zonal_index.hip).  Above it the kernel issues one 64-bit device atomic per cell -- its
-# own comments measured that 40x slower, and it has never been timed against the two radix sorts -- so larger tables
-# (an integer DEM with thousands of distinct values) keep the sorting path.
+# in per-workgroup LDS counters (zonal_index.hip): there counting takes 4.7 - 5.5 ms against the 19 ms of the two radix
+# sorts (16384^2, 1000 zones) whatever the data.  Above it the kernel issues one 64-bit device atomic per cell, and
+# which path wins depends on the DATA (tools/majority_table_probe.py, profiles/r04/majority_table_probe.log): classes
+# drawn uniformly, 64 000 .. 4 M counters, 12.9 - 17.3 ms -- faster than sorting -- but a raster on which 90 % of a zone's
+# cells carry one class (land cover) piles its atomics onto 1000 addresses: 29 - 60 ms.  The sort's 19 ms do not depend on
+# the data, so larger tables keep the sorting path.
 _MAJORITY_TABLE_LIMIT = 36864
 
 

@@ -243,6 +243,22 @@ class Ctx:
         self.L("xrs_event_sync", e1)
         return self.elapsed_ms(e0, e1) / reps
 
+    def timed_median(self, fn, reps=9, warm=2):
+        """Median device time of one call of `fn` (every call bracketed by its own event pair; `warm` untimed calls first).
+        For the informational per-kernel figures: a kernel that follows a different one starts on whatever clocks and
+        caches that one left, and a mean over 2-3 launches carried that into the figure (25x25 seven statistics:
+        2.43 ms as the mean of two launches, 2.24 as the median of ten in the same process, profiles/r04/r04w_*)."""
+        for _ in range(warm):
+            fn()
+        self.L("xrs_stream_sync", self.stream)
+        pairs = [(self.event(), self.event()) for _ in range(reps)]
+        for e0, e1 in pairs:
+            self.L("xrs_event_record", e0, self.stream)
+            fn()
+            self.L("xrs_event_record", e1, self.stream)
+        self.L("xrs_event_sync", pairs[-1][1])
+        return float(np.median([self.elapsed_ms(e0, e1) for e0, e1 in pairs]))
+
     def preheat(self, src_ptr, dst_ptr, cells, n=40):
         # Leave the idle clocks before the contract's W warm-up steps: the MI355X ramps its clocks over the first few dozen
         # launches after idling through input staging (profiles/r01: ~0.71 ms/step over launches 5..25 against 0.635 once
@@ -464,7 +480,8 @@ def run_headline(ctx):
     # quote the PCIe-inclusive rate of the drop-in path.
     extra = {}
     if world == 1 and not args.no_extras:
-        timed = ctx.timed
+        def timed(fn, reps=9):            # (per-kernel figures: the median of `reps` individually timed launches)
+            return ctx.timed_median(fn, reps=max(reps, 9))
         if not args.unfused:
             # the same step as two stand-alone launches (what two eager reference-style calls run)
             u_h, u_f = timed(launch_hillshade, reps=10), timed(launch_focal, reps=10)

@@ -65,6 +65,20 @@ def main(outdir):
     table = zonal.stats(shard(zones_full), dem, stats_funcs=['mean', 'max', 'min', 'sum', 'std', 'var', 'count'])
     for col in table.columns:
         out['zonal_' + col] = np.asarray(table[col])
+    # return_type='xarray.DataArray': every rank back-projects the agreed table onto its own rows (planes are shards again)
+    back = zonal.stats(shard(zones_full), dem, zone_ids=[1, 4, 7, 99], stats_funcs=['mean', 'count', 'max'],
+                       return_type='xarray.DataArray')
+    assert back.dims == ('stats', 'y', 'x') and back.shape == (3, y1 - y0, W) and [str(v) for v in np.asarray(back.coords['stats'])] == ['mean', 'count', 'max']
+    out['zonal_back'] = back.data.get()
+    # focal.apply with a user callable: windows are gathered across the shard boundary (halo rows), the callable runs here
+
+    def second_largest(w):
+        v = np.sort(w[np.isfinite(w)])
+        return v[-2] if v.size > 1 else np.nan
+
+    called = focal.apply(dem, k5, func=second_largest)
+    assert isinstance(called.data, ShardedArray) and called.data.dtype == np.float32
+    out['call5'] = called.data.get()
     # crosstab: every rank counts its rows, the (zones x categories) tables are added, every rank holds the whole frame
     cats_full = ((np.arange(H)[:, None] * 7 + np.arange(W)[None, :] * 3) % 5 + 10).astype(np.int32)
     ct = zonal.crosstab(shard(zones_full), shard(cats_full), nodata_values=12)
@@ -74,6 +88,8 @@ def main(outdir):
                                          agg='percentage').to_numpy(dtype=np.float64)
     # what a sharded raster cannot do fails loudly
     for bad in (lambda: zonal.stats(shard(zones_full), dem), lambda: focal.apply(shard(full, halo_cap=2), k7),
+                lambda: focal.apply(shard(full, halo_cap=2), k7, func=second_largest),
+                lambda: zonal.stats(shard(zones_full), dem, stats_funcs={'n': len}),
                 lambda: zonal.crosstab(shard(zones_full), dem),
                 lambda: xs.slope(xs.DataArray(dem.data, dims=['lat', 'lon'], coords={'lat': np.linspace(1, 2, y1 - y0),
                                                                                    'lon': np.linspace(1, 2, W)}), method='geodesic')):

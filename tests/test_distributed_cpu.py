@@ -111,6 +111,17 @@ def test_sharded_api_host_logic(tmp_path, world):
         np.testing.assert_array_equal(p['zonal_zone'], table['zone'])
         for col in names:
             np.testing.assert_allclose(p['zonal_' + col], table[col], rtol=1e-9, err_msg=col)
+    # back-projection of the sharded table == the monolithic one (zonal.py:313-332); zone 99 does not exist
+    want_back = orc.zonal_stats(zones, full.astype(np.float64), zone_ids=[1, 4, 7, 99], stats_funcs=['mean', 'count', 'max'],
+                                return_type='array')
+    got_back = np.concatenate([p['zonal_back'] for p in parts], axis=1)
+    assert got_back.dtype == np.float64 and np.isnan(got_back[:, ~np.isin(zones, [1, 4, 7])]).all()
+    np.testing.assert_allclose(got_back, want_back, rtol=1e-9, equal_nan=True)
+    # focal.apply(func=callable): the second largest valid cell under the 5x5 circle, windows crossing shard boundaries
+    srt = np.sort(np.stack(orc._window_stack(full, k5)), axis=0)            # NaN last
+    n_valid = np.isfinite(srt).sum(axis=0)
+    want_call = np.where(n_valid > 1, np.take_along_axis(srt, np.maximum(n_valid - 2, 0)[None], axis=0)[0], np.nan)
+    np.testing.assert_array_equal(np.concatenate([p['call5'] for p in parts]), want_call.astype(np.float32))
     # sharded crosstab == the monolithic table (reference semantics: zonal.py:699-800; nodata category dropped)
     ct, pct = _crosstab_reference(zones, H, W)
     for p in parts:

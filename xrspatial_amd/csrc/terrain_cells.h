@@ -170,7 +170,12 @@ __device__ __forceinline__ float aspect_from_horn(const Horn &g) {
     // y = -fx < 0: 360 - r.  A hair west of north the reference's float64 arc tangent IS pi/2 (the double nearest pi/2 lies
     // 6.12e-17 below it, half an ulp is 1.11e-16: directions less than 4.98e-17 rad = 2.85e-15 degrees off round to it), its
     // `ang > 90` is false and it answers 90 - 90 = 0, not 360 (aspect.py:80-86; the differential fuzzer found such a cell)
-    r = fx > 0.0f ? (r < 2.85e-15f ? 0.0f : 360.0f - r) : r;
+    // Written as its own test on (fx, fy) -- less than 4.98e-17 rad west of north <=> 0 < fx < -4.98e-17 fy -- whose verdict
+    // waits in scalar registers: nesting `r < 2.85e-15f` into the select below cost the fused aspect instantiations
+    // 33 .. 58 VGPRs and their third wave per SIMD (tools/spill_scan.py: 149 -> 206 for aspect + 5x5 mean).
+    const bool hair_west = fx > 0.0f && fx < fy * -4.98e-17f;
+    r = fx > 0.0f ? 360.0f - r : r;
+    r = hair_west ? 0.0f : r;
     r = __builtin_isunordered(fx, fy) ? nan_f32() : r;       // (fmax / fmin skip a NaN operand)
     return (fx == 0.0f && fy == 0.0f) ? -1.0f : r;
 }

@@ -246,19 +246,28 @@ def _apply_callable(data, kernel, func):
     array _apply_numpy fills); `func` runs on the host on each window.  float32 result, a numpy array."""
     _lib.require_device()
     stream = get_stream()
-    src = to_device_f32(data)
-    rows, cols = src.shape
     k = _kernel_f64(kernel)
     kr, kc = k.shape
+    ht = hb = 0
+    if isinstance(data, ShardedArray):
+        # the dask slot of the reference (focal.py:329-340: map_overlap(depth=k//2, boundary=nan) around _apply_numpy):
+        # the gather reads the neighbours' rows in the shard's halo, so a window is cut only at the raster's true edge
+        src = sharded_f32(data)
+        ht, hb = src.halos(kr // 2, stream)
+    else:
+        src = to_device_f32(data)
+    rows, cols = src.shape
     out = np.zeros((rows, cols), np.float32)
     if rows == 0 or cols == 0:
         return out
+    first = src.ptr - ht * cols * 4                           # the plane the gather sees: halo rows + owned rows
+    seen = rows + ht + hb
     per_row = cols * kr * kc * 4
     band = int(max(1, min(rows, _WINDOW_BAND_BYTES // per_row)))
     wdev = DeviceArray((band, cols, kr, kc), np.float32)
     for y0 in range(0, rows, band):
         nb = min(band, rows - y0)
-        _lib.call("xrs_focal_windows_f32", src.ptr, wdev.ptr, rows, cols, cols, y0, nb, k.ctypes.data, kr, kc, stream)
+        _lib.call("xrs_focal_windows_f32", first, wdev.ptr, seen, cols, cols, y0 + ht, nb, k.ctypes.data, kr, kc, stream)
         win = wdev.get(stream)[:nb]
         for y in range(nb):
             row_w, row_o = win[y], out[y0 + y]
@@ -284,10 +293,9 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
         return scope.defer('focal_mean', raster, name, {'kernel': _kernel_f64(kernel)})
 
     if stat is None:
-        if isinstance(raster.data, ShardedArray):
-            raise NotImplementedError("focal.apply with a user callable is not available for row-sharded rasters; "
-                                      "use one of the built-in reducers")
         out = _apply_callable(raster.data, kernel, func)
+        if isinstance(raster.data, ShardedArray):             # the result is a shard again, like every other operator's
+            out = ShardedArray.from_numpy(out, raster.data.comm, raster.data.halo_cap)
         return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
 
     def run(data, kernel, stat):

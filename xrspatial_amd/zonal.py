@@ -17,7 +17,7 @@ from . import _lib
 from ._launch import get_stream
 from ._xr import DataArray, Dataset
 from .device import DTYPE_CODE, DeviceArray
-from .sharded import ShardedArray, same_layout
+from .sharded import ShardedArray, ShardedStack, same_layout
 from .utils import validate_arrays
 
 _DEVICE_STATS = ('mean', 'max', 'min', 'sum', 'std', 'var', 'count')
@@ -422,8 +422,6 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
     path (zonal.py:181-277) with a collective in place of the task graph.  The set of zone ids is agreed on first
     (global id range, then the union of the ranks' presence maps)."""
     same_layout(zones, values)
-    if return_type != 'pandas.DataFrame':
-        raise NotImplementedError("zonal.stats of a sharded raster returns the DataFrame (return_type='pandas.DataFrame')")
     if 'majority' in stat_names:
         raise NotImplementedError("'majority' needs a global sort and is not available for sharded rasters; "
                                   "pass stats_funcs without it")
@@ -455,14 +453,28 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
     unique_zones = (np.flatnonzero(mask).astype(np.float64) + lo).astype(np.int32)
     nz = len(unique_zones)
     vloc = values.local if values.dtype in (np.float32, np.float64) else values.local.astype(np.float64)
+    lut_dev = DeviceArray.from_numpy(lut)                     # (named: read by the kernels below until their sync)
     count, s1, s2, mn, mx, shift = zonal_partials(zloc, vloc, nz, nodata_values, comm if zones.world > 1 else None,
-                                           table=(lo, rng, DeviceArray.from_numpy(lut)))
+                                           table=(lo, rng, lut_dev))
     cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None, shift)
     keep = np.arange(nz) if zone_ids is None else np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
-    frame = {'zone': unique_zones[keep]}
-    for name in stat_names:
-        frame[name] = cols[name][keep]
-    return pd.DataFrame(frame)
+    if return_type == 'pandas.DataFrame':
+        frame = {'zone': unique_zones[keep]}
+        for name in stat_names:
+            frame[name] = cols[name][keep]
+        return pd.DataFrame(frame)
+    # back-projection (zonal.py:313-332) of the agreed table onto this rank's rows: every plane is a shard again
+    table = np.full((len(stat_names), nz), np.nan)
+    for i, name in enumerate(stat_names):
+        table[i, keep] = cols[name][keep]
+    tdev = DeviceArray.from_numpy(table)
+    idx = DeviceArray(zloc.shape, np.int32)
+    _lib.call("xrs_zonal_index", zloc.ptr, _ZONE_DTYPE_CODE[zloc.dtype], zloc.size, float(lo), rng, lut_dev.ptr, idx.ptr, stream)
+    planes = [values.like(np.float64) for _ in stat_names]
+    for i, plane in enumerate(planes):
+        _lib.call("xrs_zonal_backproject_f64", idx.ptr, idx.size, tdev.ptr + i * nz * 8, 1, nz, plane.ptr, stream)
+    _lib.call("xrs_stream_sync", stream)                      # idx / tdev / lut_dev are released on return
+    return ShardedStack(planes)
 
 
 def stats(
@@ -530,7 +542,12 @@ def stats(
     if return_type not in ('pandas.DataFrame', 'xarray.DataArray'):
         raise ValueError(f"unknown return_type {return_type!r}")
     if isinstance(values.data, ShardedArray):
-        return _stats_sharded(zones.data, values.data, zone_ids, names, nodata_values, return_type)
+        result = _stats_sharded(zones.data, values.data, zone_ids, names, nodata_values, return_type)
+        if return_type == 'xarray.DataArray':
+            coords = dict(values.coords.items())
+            coords['stats'] = names
+            return DataArray(result, coords=coords, dims=('stats',) + tuple(values.dims), attrs=values.attrs)
+        return result
     if not isinstance(values.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(values)))
     result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type, custom=custom)

@@ -805,6 +805,65 @@ def test_exact_moments_option_and_guard_on_adversarial_rasters(radius, monkeypat
         focal_stats(raster(cases['smooth dem']), k, stats_funcs=['mean'])
 
 
+@pytest.mark.parametrize("radius,inner", [(4, 1), (7, 4), (10, 6), (11, 3), (12, 4), (12, 11)])
+def test_annulus_mean_and_convolution_wide_walker(radius, inner):
+    """annulus_kernel(1, 1, R, RI) on the wide row walker (kxk_wide_ann*.hip: a row with a hole is the difference of two centred
+    runs of the lane's prefix sums): focal.apply's mean and convolve_2d with the normalised ring (what focal.hotspots is
+    fed) on rasters of several tiles -- clean interior tiles, rim tiles, tiles that see a NaN / inf cell (redone by the
+    NaN-aware and exact walkers), values straddling zero -- against the oracle."""
+    K = 2 * radius + 1
+    mask = annulus_kernel(1, 1, radius, inner)
+    assert mask.shape == (K, K) and mask[radius, radius] == 0 and mask[radius, radius + inner + 1] == 1
+    z = synth.smooth_dem((560, 1330), seed=60 + radius)
+    with np.errstate(all='ignore'):
+        want = corc.focal_apply(z, mask, 'mean', nthreads=8)
+    got = apply(raster(z), mask).data
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True, err_msg="clean DEM")
+    parity_log.record('560x1330', f'wide annulus {radius}/{inner} mean', got, want)
+    holes = z.copy()
+    rng = np.random.default_rng(radius * 16 + inner)
+    for _ in range(4):
+        holes[rng.integers(0, 560), rng.integers(0, 1330)] = np.nan
+    holes[150:150 + 2 * K + 3, 500:500 + 2 * K + 5] = np.nan          # windows without a valid cell
+    holes[300, 700] = np.inf
+    with np.errstate(all='ignore'):
+        want_h = corc.focal_apply(holes, mask, 'mean', nthreads=8)
+    got_h = apply(raster(holes), mask).data
+    np.testing.assert_allclose(got_h, want_h, rtol=1e-5, atol=0, equal_nan=True, err_msg="NaN / inf cells")
+    assert np.array_equal(np.isnan(got_h), np.isnan(want_h))
+    zero = (z[:300, :1100] - 2000.0).astype(np.float32)               # the guard hands such tiles to the float64 walker
+    np.testing.assert_allclose(apply(raster(zero), mask).data, corc.focal_apply(zero, mask, 'mean', nthreads=8), rtol=1e-5,
+                               atol=1e-4, equal_nan=True, err_msg="values straddling zero")
+    # row shards with halo rows: interior tiles reach into the halos
+    kk = np.ascontiguousarray(mask, dtype=np.float64)
+    full = xs.DeviceArray.from_numpy(z)
+    import ctypes
+    from xrspatial_amd import _lib
+    for first, n, ht, hb in ((100, 400, radius, radius), (0, 300, 0, radius), (260, 300, radius, 0)):
+        o_mean = xs.DeviceArray((n, 1330), np.float32)
+        ptrs = (ctypes.c_void_p * 7)()
+        ptrs[0] = o_mean.ptr
+        _lib.call("xrs_focal_stats_f32", full.ptr + first * 1330 * 4, ptrs, 1, n, 1330, 1330, 1330, kk.ctypes.data, K, K, None,
+                  ht, hb, None)
+        _lib.call("xrs_stream_sync", None)
+        np.testing.assert_allclose(o_mean.get(), want[first:first + n], rtol=1e-6, err_msg=f"shard {first}+{n}")
+    # convolve_2d with one weight on the ring
+    k = mask / mask.sum()
+    zc = z[:400].copy()
+    for _ in range(3):
+        zc[rng.integers(0, 400), rng.integers(0, 1330)] = np.nan
+    zc[200, 900] = -np.inf
+    zc[128 - radius, 512 - radius] = np.nan                          # through a zero-weight corner of a neighbouring tile's window
+    zc[260, 260] = np.nan                                            # ... and one that only windows' HOLES see
+    with np.errstate(all='ignore'):
+        want_c = corc.convolve_2d(zc, k, nthreads=8)
+    got_c = convolve_2d(zc, k)
+    np.testing.assert_allclose(got_c, want_c, rtol=2e-6, atol=0, equal_nan=True)
+    assert np.array_equal(np.isnan(got_c), np.isnan(want_c))
+    parity_log.record('400x1330', f'convolve_2d uniform annulus {radius}/{inner}', got_c, want_c)
+    np.testing.assert_allclose(convolve_2d(zero, k), corc.convolve_2d(zero, k, nthreads=8), rtol=1e-5, atol=1e-4, equal_nan=True)
+
+
 @pytest.mark.parametrize("shape_kind", ["circle", "box"])
 @pytest.mark.parametrize("radius", [3, 6, 12])
 def test_uniform_weight_convolution_wide_walker(radius, shape_kind):

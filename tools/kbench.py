@@ -123,6 +123,7 @@ def main():
     wb25 = np.ascontiguousarray(kb25 / kb25.sum())
     ka21 = np.ascontiguousarray(annulus_kernel(1, 1, 10, 6))       # 21x21 ring, inner radius 6
     ka25 = np.ascontiguousarray(annulus_kernel(1, 1, 12, 4))       # 25x25 ring, inner radius 4
+    wa21, wa25 = np.ascontiguousarray(ka21 / ka21.sum()), np.ascontiguousarray(ka25 / ka25.sum())
 
     def fstats(k, ptrs, mask):
         K = k.shape[0]
@@ -240,6 +241,8 @@ def main():
         "box25_minmaxrange": (fstats(kb25, ptr7, 0b1110), 16),
         "box25_stats7": (fstats(kb25, ptr7, 127), 32),
         "convolve25_box": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, wb25.ctypes.data, 25, 25, work.ptr, 0, 0, S), 8),
+        "convolve21_annulus": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, wa21.ctypes.data, 21, 21, work.ptr, 0, 0, S), 8),
+        "convolve25_annulus": (lambda: L("xrs_convolve2d_f32", dem.ptr, outs[0].ptr, n, n, n, n, wa25.ctypes.data, 25, 25, work.ptr, 0, 0, S), 8),
         "annulus21_mean": (fstats(ka21, ptr1, 1), 8),
         "annulus21_stats7": (fstats(ka21, ptr7, 127), 32),
         "annulus25_mean": (fstats(ka25, ptr1, 1), 8),
@@ -284,7 +287,7 @@ def main():
     for name_, (fn, bpc) in cases.items():
         if only and name_ not in only:
             continue
-        reps = 3 if name_.startswith(("focal25", "annulus")) else args.reps
+        reps = args.reps
         med, mn = timer.time(fn, reps, warmup=2)
         gbs = cells * bpc / (med * 1e-3) / 1e9
         results[name_] = {"ms_median": med, "ms_min": mn, "mcells_s": cells / (med * 1e-3) / 1e6, "gb_s": gbs,

@@ -600,6 +600,28 @@ struct WalkConv {
         const double shift = (double)cf;
         double S = 0.0;
         int nbad = 0;
+        if constexpr (shape_has_hole<Shape>(R)) {
+            // annuli: centred partial sums P[h] of |dx| <= h; a row at offset dy takes P[hw] - P[hwi]
+            double P[R + 1];
+#pragma unroll
+            for (int h = 0; h <= R; ++h) {
+#pragma unroll
+                for (int side = 0; side < (h == 0 ? 1 : 2); ++side) {
+                    const float val = v[side == 0 ? R - h : R + h];
+                    const bool ok = isfinite(val);
+                    S += ok ? (double)val - shift : 0.0;
+                    nbad += ok ? 0 : 1;
+                }
+                P[h] = S;
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int dy = j < R ? R - j : j - R, h1 = Shape::hw(R, dy), h0 = Shape::hwi(R, dy);
+                sd[j] += h0 >= 0 ? P[h1] - P[h0] : P[h1];
+            }
+            bad_total += nbad;
+            return;
+        }
 #pragma unroll
         for (int h = 0; h <= R; ++h) {
 #pragma unroll
@@ -684,13 +706,13 @@ __device__ __forceinline__ void walk_conv_tile(const WalkGeom &g, float *out, do
 template <int R, typename Shape>
 inline bool is_uniform_shape(const double *kernel, double *weight) {
     constexpr int K = 2 * R + 1;
-    const double w = kernel[R * K + R];
+    const double w = kernel[R * K + R + Shape::hw(R, 0)];     // (the rim cell of the centre row: an annulus has no centre cell)
     if (!(w != 0.0) || !std::isfinite(w)) return false;
     for (int ky = 0; ky < K; ++ky) {
-        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy);
+        const int dy = ky < R ? R - ky : ky - R, h = Shape::hw(R, dy), hi = Shape::hwi(R, dy);
         for (int kx = 0; kx < K; ++kx) {
             const int dx = kx < R ? R - kx : kx - R;
-            if (kernel[ky * K + kx] != (dx <= h ? w : 0.0)) return false;
+            if (kernel[ky * K + kx] != (dx <= h && dx > hi ? w : 0.0)) return false;
         }
     }
     *weight = w;

@@ -1067,6 +1067,18 @@ int launch_mom_annulus(const float *in, float *o_sum, float *o_mean, float *o_va
     }
 }
 
+// the mean or the uniform-weight convolution over annulus_kernel(1, 1, R, RI): the wide walker's translation unit for the outer radius
+int launch_wide_annulus(const float *in, float *o_mean, float *o_conv, long rows, long cols, long ld_in, long ld_out,
+                        const double *kernel, const double *weights_dev, int krows, int kcols, int ht, int hb, hipStream_t s) {
+    if (krows != kcols) return -1;
+    switch (krows / 2) {
+#define XRS_ANN(RR) case RR: return try_launch_wide_annulus##RR(in, o_mean, o_conv, rows, cols, ld_in, ld_out, kernel, weights_dev, krows, kcols, ht, hb, s);
+        XRS_ANN(4) XRS_ANN(5) XRS_ANN(6) XRS_ANN(7) XRS_ANN(8) XRS_ANN(9) XRS_ANN(10) XRS_ANN(11) XRS_ANN(12)
+#undef XRS_ANN
+        default: return -1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1120,6 +1132,8 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
         rc = try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc < 0)
             rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
+        if (rc < 0)             // a normalised annulus_kernel (focal.hotspots' other documented mask)
+            rc = launch_wide_annulus(in_dev, nullptr, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc >= 0) return rc;
     }
     a.tiles_x = (cols + TW - 1) / TW;
@@ -1194,8 +1208,11 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
         if (rc < 0)
             rc = try_launch_focal_wide_box(in_dev, a.out[XRS_STAT_MEAN], a.out[XRS_STAT_SUM], rows, cols, ld_in, ld_out,
                                            kernel, krows, kcols, halo_top, halo_bot, s);
-        // annulus_kernel(1, 1, R, RI): the moments walker with only the mean / sum planes (its level differences are the
-        // wide walker's; there is no second family of 66 instantiations for them)
+        // annulus_kernel(1, 1, R, RI), the mean alone: the wide walker's annulus instantiations (a row with a hole = two runs)
+        if (rc < 0 && stat_mask == m_mean)
+            rc = launch_wide_annulus(in_dev, a.out[XRS_STAT_MEAN], nullptr, rows, cols, ld_in, ld_out, kernel, nullptr, krows, kcols,
+                                     halo_top, halo_bot, s);
+        // ... with the sum: the moments walker with only the mean / sum planes
         if (rc < 0 && krows >= 9)
             rc = launch_mom_annulus(in_dev, a.out[XRS_STAT_SUM], a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,
                                     krows, kcols, halo_top, halo_bot, s);

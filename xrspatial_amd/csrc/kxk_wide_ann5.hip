@@ -1,0 +1,5 @@
+// Focal mean and uniform-weight convolve_2d over annulus_kernel(1, 1, 5, RI), RI = 1 .. 4: the wide row walker
+// (a row with a hole is the difference of two centred runs of the lane's prefix sums).
+#define XRS_WIDE_ANNULUS_R 5
+#define XRS_WIDE_ENTRY try_launch_wide_annulus5
+#include "wide_impl.h"

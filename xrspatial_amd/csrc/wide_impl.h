@@ -122,9 +122,13 @@ __device__ __forceinline__ int clipped_count(long yo, long x, long y_lo, long y_
     for (int dy = -R; dy <= R; ++dy) {
         const long yr = yo + dy;
         if (yr < y_lo || yr >= y_hi) continue;
-        const int h = Shape::hw(R, dy < 0 ? -dy : dy);
+        const int h = Shape::hw(R, dy < 0 ? -dy : dy), h0 = Shape::hwi(R, dy < 0 ? -dy : dy);
         const long a = x - h < 0 ? 0 : x - h, b = x + h > cols - 1 ? cols - 1 : x + h;
         n += (int)(b - a + 1);
+        if (h0 >= 0) {                                       // annuli: the hole's cells inside the raster
+            const long a0 = x - h0 < 0 ? 0 : x - h0, b0 = x + h0 > cols - 1 ? cols - 1 : x + h0;
+            n -= b0 >= a0 ? (int)(b0 - a0 + 1) : 0;
+        }
     }
     return n;
 }
@@ -323,9 +327,36 @@ struct WideWalk {
                     vsum[o] += acc[SLOT][o];
                 }
             }
+            if constexpr (shape_has_hole<Shape>(R)) {
+                // ---- annuli: every distinct ROW PATTERN once -- the centred run of half-width hw minus the one of half-width
+                // hwi -- through compile-time tables (ShapeRows), as in mom_impl.h
+                constexpr ShapeRows<R, Shape> T{};
+                auto run = [&](int h, int o) -> float {      // the centred run of half-width h under owned column o (static h, o)
+                    const int hi = HL + o + h, lo = HL + o - h - 1;
+                    return lo >= 0 ? w[hi] - w[lo] : w[hi];
+                };
+#pragma unroll
+                for (int d = 0; d <= R; ++d) {
+                    if (T.pat[d] != d) continue;
+                    float S[NC];
+#pragma unroll
+                    for (int o = 0; o < NC; ++o) {
+                        S[o] = run(T.hw[d], o);
+                        if (T.hwi[d] >= 0) S[o] -= run(T.hwi[d] >= 0 ? T.hwi[d] : 0, o);
+                    }
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int dy = j - R;
+                        if (T.pat[dy < 0 ? -dy : dy] != d) continue;
+                        const int idx = ((PHASE - dy) % K + K) % K;
+#pragma unroll
+                        for (int o = 0; o < NC; ++o) acc[idx][o] += S[o];
+                    }
+                }
+            }
             // ---- every distinct half-width once, into the ring slots of the output rows that see this row with it
 #pragma unroll
-            for (int h = 0; h <= R && !C::SLIDE; ++h) {
+            for (int h = 0; h <= R && !C::SLIDE && !shape_has_hole<Shape>(R); ++h) {
                 if (!C::level_used(h)) continue;
                 float S[NC];
 #pragma unroll
@@ -453,8 +484,10 @@ struct WideWalk {
         }
         constexpr float UNIT = 5.9604645e-8f;
         // SLIDE: 2R+1 row sums with 2 NV^2 u A each, the re-summation tree (5 u |V|) and 2 KR roundings of |V| <= NTAPS A
+        // (annuli: a row with a hole is the difference of two runs -- four prefix values instead of two)
+        constexpr int PV = shape_has_hole<Shape>(R) ? 4 : 2;
         constexpr float COEF = UNIT * (float)(C::SLIDE ? K * 2 * NV * NV + (5 + 2 * C::KR) * C::NTAPS
-                                                       : K * (2 * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
+                                                       : K * (PV * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
         return !__any(bad) && (COEF * a <= 0.9e-5f * mm);
     }
 };
@@ -544,10 +577,12 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
         hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_MEAN>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
-    if (out_sum) {
-        a.out = out_sum;
-        hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_SUM>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        XRS_LAUNCH_CHECK();
+    if constexpr (!shape_has_hole<Shape>(R)) {                 // (annuli: the mean and the convolution only -- the entry refuses a sum)
+        if (out_sum) {
+            a.out = out_sum;
+            hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_SUM>), dim3((unsigned)grid), dim3(256), 0, s, a);
+            XRS_LAUNCH_CHECK();
+        }
     }
     return 0;
 }
@@ -575,6 +610,7 @@ int launch_wide_conv(WideArgs &a, float *out, const double *kernel, const double
     return 0;
 }
 
+#ifndef XRS_WIDE_ANNULUS_R
 int dispatch_wide_conv(WideArgs &a, float *out, const double *kernel, const double *weights_dev, int r, hipStream_t s) {
     switch (r) {
 #define XRS_WIDE_CASE(RR) case RR: return launch_wide_conv<RR, XRS_WIDE_SHAPE>(a, out, kernel, weights_dev, s);
@@ -600,11 +636,42 @@ int dispatch_wide(WideArgs &a, float *out_mean, float *out_sum, const double *ke
         default: return -1;
     }
 }
+#else
+// annulus_kernel(1, 1, XRS_WIDE_ANNULUS_R, RI), 1 <= RI < R: one instantiation pair (mean, convolution) per inner radius, one
+// translation unit per outer radius (as kxk_mom_ann*.hip)
+template <int RI>
+int wide_annulus_pair(WideArgs &a, float *out_mean, float *out_conv, const double *kernel, const double *weights_dev, int ri, hipStream_t s) {
+    if constexpr (RI >= XRS_WIDE_ANNULUS_R) return -1;
+    else {
+        if (ri != RI) return wide_annulus_pair<RI + 1>(a, out_mean, out_conv, kernel, weights_dev, ri, s);
+        if (out_conv) return launch_wide_conv<XRS_WIDE_ANNULUS_R, AnnulusShape<RI>>(a, out_conv, kernel, weights_dev, s);
+        return is_shape<XRS_WIDE_ANNULUS_R, AnnulusShape<RI>>(kernel) ? launch_wide<XRS_WIDE_ANNULUS_R, AnnulusShape<RI>>(a, out_mean, nullptr, s) : -1;
+    }
+}
+#endif
 
 }  // namespace
 
 namespace xrs {
 
+#ifdef XRS_WIDE_ANNULUS_R
+// Exactly one of out_mean / out_conv.  0 = launched, -1 = not annulus_kernel(1, 1, XRS_WIDE_ANNULUS_R, RI) (for out_conv: times
+// one weight value), > 0 = error.  `weights_dev`: the kernel as float64 in device memory (convolution only).
+int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_conv, long rows, long cols, long ld_in, long ld_out,
+                   const double *kernel, const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s) {
+    if (krows != kcols || krows / 2 != XRS_WIDE_ANNULUS_R || !(krows & 1) || (!out_mean == !out_conv)) return -1;
+    // (the inner radius as the mask draws it: the first selected cell of the centre row, whatever its weight)
+    const int R = XRS_WIDE_ANNULUS_R;
+    int ri = -1;
+    while (ri + 1 <= R && kernel[R * krows + R + ri + 1] == 0.0) ++ri;
+    if (ri < 1 || ri >= R) return -1;
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.in = in; a.g.rows = rows; a.g.cols = cols; a.g.ld_in = ld_in; a.g.ld_out = ld_out;
+    a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
+    return wide_annulus_pair<1>(a, out_mean, out_conv, kernel, weights_dev, ri, s);
+}
+#else
 // 0 = launched, -1 = not this shape with a radius of 3..12 cells (caller takes another kernel), > 0 = error.
 // (mean and sum together: two launches)
 int XRS_WIDE_ENTRY(const float *in, float *out_mean, float *out_sum, long rows, long cols, long ld_in, long ld_out,
@@ -629,5 +696,6 @@ int XRS_WIDE_CONV_ENTRY(const float *in, float *out, long rows, long cols, long 
     a.g.halo_top = halo_top; a.g.halo_bot = halo_bot;
     return dispatch_wide_conv(a, out, kernel, weights_dev, krows / 2, s);
 }
+#endif
 
 }  // namespace xrs

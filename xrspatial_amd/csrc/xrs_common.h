@@ -327,6 +327,15 @@ int try_launch_focal_ext_annulus_c(const float *in, float *out_max, float *out_m
 XRS_DECL_MOM_ANNULUS(4) XRS_DECL_MOM_ANNULUS(5) XRS_DECL_MOM_ANNULUS(6) XRS_DECL_MOM_ANNULUS(7) XRS_DECL_MOM_ANNULUS(8)
 XRS_DECL_MOM_ANNULUS(9) XRS_DECL_MOM_ANNULUS(10) XRS_DECL_MOM_ANNULUS(11) XRS_DECL_MOM_ANNULUS(12)
 #undef XRS_DECL_MOM_ANNULUS
+// kxk_wide_ann4.hip .. kxk_wide_ann12.hip (wide_impl.h): the mean (out_mean) or the uniform-weight convolution (out_conv; exactly
+// one of the two) over annulus_kernel(1, 1, RR, RI).  0 = launched, -1 = not such a mask, > 0 = error.
+#define XRS_DECL_WIDE_ANNULUS(RR)                                                                                             \
+    int try_launch_wide_annulus##RR(const float *in, float *out_mean, float *out_conv, long rows, long cols, long ld_in,      \
+                                    long ld_out, const double *kernel, const double *weights_dev, int krows, int kcols,       \
+                                    int halo_top, int halo_bot, hipStream_t s);
+XRS_DECL_WIDE_ANNULUS(4) XRS_DECL_WIDE_ANNULUS(5) XRS_DECL_WIDE_ANNULUS(6) XRS_DECL_WIDE_ANNULUS(7) XRS_DECL_WIDE_ANNULUS(8)
+XRS_DECL_WIDE_ANNULUS(9) XRS_DECL_WIDE_ANNULUS(10) XRS_DECL_WIDE_ANNULUS(11) XRS_DECL_WIDE_ANNULUS(12)
+#undef XRS_DECL_WIDE_ANNULUS
 // kxk_sw_circle.hip / kxk_sw_box.hip (sw_impl.h): any of the seven statistics over circles / boxes of radius 2, 3 cells from one
 // pass of the strip walker (outs: XRS_STAT_* order, NULL = not wanted).  0 = launched, -1 = not such a mask, > 0 = error.
 int try_launch_focal_sw_circle(const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,

@@ -524,6 +524,13 @@ def run_headline(ctx):
         ok["focal_mean_var_std_25x25_box"] = stats_ex(np.ones((25, 25)), ptr7, 0b110001)
         ok["focal_stats7_21x21_annulus_10_6"] = stats_ex(annulus_kernel(1, 1, 10, 6), ptr7, 127)
         ok["focal_stats7_7x7_circle"] = stats_ex(circle_kernel(1, 1, 3), ptr7, 127)
+        ok["focal_mean_21x21_annulus_10_6"] = stats_ex(annulus_kernel(1, 1, 10, 6), ptr7, 1)
+        # BASELINE configs[1] verbatim: hillshade + aspect + curvature of one DEM, as ONE pass (12 B written per cell)
+        ok["hillshade_aspect_curvature_one_pass"] = round(timed(lambda: L(
+            "xrs_terrain_fused_f32", dem_ptr, None, outs7[0].ptr, outs7[1].ptr, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0,
+            225.0, 25.0, 0, 0, stream)), 4)
+        ok["hillshade_aspect_curvature_frac_of_hbm_peak"] = round(
+            16.0 * rows * cols / (ok["hillshade_aspect_curvature_one_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         del fwork
         ok["slope_frac_of_hbm_peak"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         ok["slope_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / copy_gbs, 3)

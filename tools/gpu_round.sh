@@ -46,7 +46,8 @@ for s in $STEPS; do
       timeout 600 python bench.py --workload zonal32k --steps 10 --warmup 3 --write-n1 $OUT/n1_strong.json > $OUT/bench_zonal32k.json 2> $OUT/bench_zonal32k.err; cat $OUT/bench_zonal32k.json | head -c 400; echo
       cat $OUT/n1_strong.json ;;
     fuzz)
-      for seed in 51 52; do timeout 600 python tests/fuzz_parity.py --seed $seed --cases 500 > $OUT/fuzz_s$seed.log 2>&1; tail -3 $OUT/fuzz_s$seed.log; done ;;
+      for seed in 51 52; do timeout 600 python tests/fuzz_parity.py --seed $seed --cases 1500 > $OUT/fuzz_s$seed.log 2>&1; tail -3 $OUT/fuzz_s$seed.log; done
+      timeout 600 python tests/fuzz_parity.py --seed 53 --cases 40 --big > $OUT/fuzz_big.log 2>&1; tail -3 $OUT/fuzz_big.log ;;
     s64bench)
       timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
     *) echo "unknown step $s" ;;

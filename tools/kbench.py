@@ -201,6 +201,8 @@ def main():
         "curvature": (lambda: L("xrs_curvature_f32", dem.ptr, outs[0].ptr, n, n, n, n, 1.0, 0, 0, S), 8),
         "terrain_fused4": (lambda: L("xrs_terrain_fused_f32", dem.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr,
                                      outs[3].ptr, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 20),
+        "terrain_hill_aspect_curv": (lambda: L("xrs_terrain_fused_f32", dem.ptr, None, outs[1].ptr, outs[2].ptr,
+                                               outs[3].ptr, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 16),
         "pass_hill_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, None, None, None, outs[3].ptr, outs[4].ptr,
                                        k5.ctypes.data, 5, 5, None, n, n, n, n, 1.0, 1.0, 225.0, 25.0, 0, 0, S), 12),
         "pass_hill_slope_focal5": (lambda: L("xrs_raster_pass_f32", dem.ptr, outs[0].ptr, None, None, outs[3].ptr,

@@ -1227,7 +1227,9 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
         const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
         const bool gen2 = gen && gen[0] == '2';
         if (!gen2) {
-            hipStream_t s_mm = s;          // (the two launches on two streams measured no faster than back to back: 2.39 vs 2.43 ms)
+            hipStream_t s_mm = s;          // (the two launches on two streams, forked / joined by events, measured no faster than back to back:
+                                           //  2.39 vs 2.43 ms in round 3; 2.14 - 2.23 vs 2.19 in round 4, also with the extrema kernel at 2 waves per SIMD:
+                                           //  profiles/r04/ab_two_streams.log)
             int rc = 0;
             if (want_mm) {
                 rc = try_launch_focal_ext_circle(in_dev, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], rows,

@@ -49,10 +49,10 @@ def _stats_call(in_ptr, ptrs, mask, rows, cols, ld_in, ld_out, k, work, ht, hb, 
 class _BuiltinReducer:
     """Stands in for the reference's `@ngjit _calc_*` functions (focal.py:268-302).
 
-    `apply(raster, kernel, func=_calc_sum)` upstream takes a Numba-compiled callable; a GPU
-    backend can only run the built-in reducers, so they are exported under the same names
-    as tokens that `apply` recognises.  Any other callable raises NotImplementedError
-    (the reference's own cupy slot does the same, focal.py:461-465)."""
+    `apply(raster, kernel, func=_calc_sum)` upstream takes a Numba-compiled callable; the built-in
+    reducers are exported under the same names as tokens that `apply` recognises and runs entirely
+    on the MI355X.  Any other callable runs on the host on windows the device gathers
+    (`_apply_callable`; also for row-sharded rasters, whose windows reach into the halo rows)."""
 
     def __init__(self, stat):
         self.stat = stat
@@ -281,7 +281,9 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
 
     Same signature as `xrspatial.focal.apply`; window clipped at the raster edge, NaN
     cells skipped, float32 result.  The built-in reducers run entirely on the MI355X; any other callable gets the
-    kernel-shaped float32 window of each cell (gathered on the device, `_apply_callable`) and runs on the host."""
+    kernel-shaped float32 window of each cell (gathered on the device, `_apply_callable`) and runs on the host.
+    Row-sharded rasters (`ShardedArray`) take both forms: the reference's dask slot, map_overlap(depth = k // 2,
+    boundary = nan) (focal.py:329-340)."""
     if not isinstance(raster, DataArray):
         raise TypeError("`raster` must be instance of DataArray")
     if raster.ndim != 2:

@@ -498,7 +498,8 @@ def stats(
 
     Same signature as `xrspatial.zonal.stats`.  All eight default statistics (mean / max / min / sum /
     std / var / count from one streaming partial-sum pass, majority from a device sort), `zone_ids`,
-    `nodata_values`, Dataset `values` and both return types run on the MI355X.  `stats_funcs` as a dict of callables
+    `nodata_values`, Dataset `values` and both return types run on the MI355X (row-sharded rasters: every statistic but
+    `majority`, both return types -- the DataArray's planes are shards again).  `stats_funcs` as a dict of callables
     (zonal.py:304-310): the cells are grouped by zone on the device and each callable runs on the host on the 1-D array
     of its zone's valid values (ascending order; the reference hands them over in argsort order)."""
     if isinstance(values, Dataset):

@@ -126,14 +126,19 @@ def one_case(rng, max_cells):
             desc += f" k={k.shape} taps={int(k.sum())}"
             if max(k.shape) // 2 >= min(shape) and op == "hotspots":
                 return desc, None
+            # extrema are bit-exact; the moments and the window sum of LARGE windows are float32 sums behind a guard (mom_impl.h:
+            # documented <= 2e-6 for mean / std / sum, <= 5e-6 for var, contract 1e-5) -- at 1e-6 for every plane, 3 000 cases
+            # found five windows between 1.0e-6 and 1.1e-6 (profiles/r04/r04z_fuzz_s5*.log)
+            def tol(stat):
+                return 1e-6 if stat in ("max", "min", "range") or k.size < 49 else 5e-6
             if op == "apply":
                 stat = str(rng.choice(orc.FOCAL_STATS))
                 fn = getattr(focal, "_calc_" + stat)
-                return desc + " " + stat, close(focal.apply(agg, k, fn).data, corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=1e-30)
+                return desc + " " + stat, close(focal.apply(agg, k, fn).data, corc.focal_apply(z, k, stat, nthreads=8), rtol=tol(stat), atol=1e-30)
             if op == "focal_stats":
                 got = host(focal.focal_stats(agg, k).data)
                 for i, stat in enumerate(orc.FOCAL_STATS):
-                    err = close(got[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=1e-30)
+                    err = close(got[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=tol(stat), atol=1e-30)
                     if err:
                         return desc + " " + stat, err
                 return desc, None

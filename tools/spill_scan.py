@@ -47,7 +47,7 @@ def main():
     for f, name, vgpr, scratch, spill in results:
         if args.all or scratch:
             n += 1
-            print(f"{f:22s} {vgpr:5d} {scratch:9d} {spill:7d}  {name[:110]}")
+            print(f"{f:22s} {vgpr:5d} {scratch:9d} {spill:7d}  {name}")
     print(f"{len(results)} kernels, {sum(1 for r in results if r[3])} with scratch memory")
     return 0
 

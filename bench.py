@@ -97,6 +97,19 @@ class Ctx:
         self.xs, self._lib, self.L = xs, _lib, _lib.call
         self.stream = ctypes.c_void_p()
         self.L("xrs_stream_create", ctypes.byref(self.stream))
+        if self.world > 1:
+            # a rank that dies leaves the others in a collective (or in ncclCommInitRank) for ever: no run outlives this
+            import threading
+            limit = float(os.environ.get("XRS_BENCH_TOTAL_TIMEOUT", "900"))
+
+            def give_up():
+                sys.stderr.write(f"[bench rank {self.rank}] still running after {limit:.0f} s (a collective some rank never "
+                                 "joined?): giving up, exit code 4\n")
+                sys.stderr.flush()
+                os._exit(4)
+            t = threading.Timer(limit, give_up)
+            t.daemon = True
+            t.start()
         self.comm = None
         self.connect_s = None
         self.host_group = None        # torch.distributed (gloo), only with --allow-host-halo after RCCL failed
@@ -568,10 +581,7 @@ def run_headline(ctx):
                                   "mcells_s_median_chunk": round(rows * cols / (float(np.median(chunks_ms)) * 1e-3) / 1e6, 1)}
     if world > 1 and not args.no_extras:
         del out_focal, out_hill, buf
-        xs.device.empty_cache()
-        extra["s64_strong"] = run_s64(ctx, steps=5, warmup=2, brief=True)
-        xs.device.empty_cache()
-        extra["zonal32k_strong"] = run_zonal32k(ctx, steps=5, warmup=2, brief=True)
+        xs.device.empty_cache()              # (the strong-scaling figures are taken further down, once the line is assembled)
     elif world == 1 and not args.no_extras:
         del out_focal, out_hill, buf
         xs.device.empty_cache()
@@ -580,6 +590,8 @@ def run_headline(ctx):
         extra["zonal32k"] = run_zonal32k(ctx, steps=10, warmup=2, brief=True)
 
     if rank != 0:
+        if world > 1 and not args.no_extras:
+            guarded_strong_scaling(ctx, None)
         return None
     cells_rank = rows * cols
     ms_per_step = elapsed / args.steps * 1e3
@@ -643,6 +655,8 @@ def run_headline(ctx):
             "algorithmic_bytes_per_cell": alg_bytes,
         },
     }
+    if world > 1 and not args.no_extras:
+        guarded_strong_scaling(ctx, result)
     if world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(cols, kernel)
         # the CPU path beside every reported configuration (north_star), not only the headline
@@ -652,6 +666,42 @@ def run_headline(ctx):
                 result["config"][key]["cpu_baseline"] = extra_base
         result["cpu_baseline"] = base
     return result
+
+
+def guarded_strong_scaling(ctx, result):
+    """N > 1, after the headline has been measured: the two strong-scaling workloads (config.s64_strong /
+    config.zonal32k_strong) under a watchdog.  They ride on collectives, and a rank that fails inside one -- out of memory, an
+    RCCL error -- leaves the others waiting in it for ever: a benchmark that has its headline number must not lose it to that.
+    If they are not done after XRS_BENCH_EXTRAS_TIMEOUT seconds (default 240; they take ~20), rank 0 prints the line it has,
+    with config.extras_error saying so, and every rank leaves with exit code 0.  `result`: rank 0's line (None elsewhere)."""
+    import threading
+    budget = float(os.environ.get("XRS_BENCH_EXTRAS_TIMEOUT", "240"))
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(budget):
+            return
+        if result is not None:
+            result["config"]["extras_error"] = (f"the strong-scaling workloads were not finished {budget:.0f} s after the headline: "
+                                                "line printed without (all of) them")
+            print(json.dumps(result), flush=True)
+        sys.stderr.write(f"[bench rank {ctx.rank}] strong-scaling extras timed out after {budget:.0f} s; leaving\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    for key, fn in (("s64_strong", run_s64), ("zonal32k_strong", run_zonal32k)):
+        try:
+            if os.environ.get("XRS_BENCH_TEST_HANG") == key and ctx.rank == ctx.world - 1:
+                time.sleep(1e6)                       # (tests: one rank never arrives)
+            body = fn(ctx, steps=5, warmup=2, brief=True)
+        except Exception as exc:                      # noqa: BLE001  (the other ranks may now be waiting in a collective: the watchdog's business)
+            body = {"error": repr(exc)[:300]}
+            sys.stderr.write(f"[bench rank {ctx.rank}] {key} failed: {body['error']}\n")
+        if result is not None:
+            result["config"][key] = body
+        ctx.xs.device.empty_cache()
+    done.set()
 
 
 # =====================================================================================================
@@ -1062,11 +1112,18 @@ def main():
                     json.dump(table, fh, indent=1, sort_keys=True)
     if ctx.rank == 0 and result is not None:
         print(json.dumps(result), flush=True)
+    if ctx.world > 1:
+        # the line is out: a rank that never reaches the closing barrier must not keep the launcher waiting
+        import threading
+        threading.Timer(float(os.environ.get("XRS_BENCH_TEARDOWN_TIMEOUT", "60")), lambda: os._exit(0)).start()
     ctx.barrier()
     if ctx.host_group is not None:
         ctx.host_group.destroy_process_group()
     if ctx.comm is not None:
         ctx.comm.destroy()
+    if ctx.world > 1:
+        sys.stdout.flush()
+        os._exit(0)                                   # (the teardown timer's thread would keep the interpreter alive)
 
 
 if __name__ == "__main__":

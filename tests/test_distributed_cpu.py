@@ -254,6 +254,39 @@ def test_bench_workloads_world2(workload, extra):
         assert res["scaling"] == "weak" and cfg["halo_check"]["ok"], cfg
 
 
+@pytest.mark.parametrize("hang", ["", "s64_strong"])
+def test_bench_headline_keeps_its_line_when_a_rank_hangs_in_the_extras(hang):
+    """The default N > 1 run measures the two strong-scaling workloads AFTER its headline (config.s64_strong /
+    config.zonal32k_strong); they ride on collectives, so a rank that never arrives would leave the others waiting for
+    ever.  Without a fault both are in the line; with rank 1 stuck before the first one, rank 0 prints the line it has
+    (config.extras_error) once the watchdog's budget is spent and both ranks leave with exit code 0."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", XRS_RDZV_TIMEOUT="5", XRS_BENCH_EXTRAS_TIMEOUT="8" if hang else "300",
+                   XRS_BENCH_TEARDOWN_TIMEOUT="20", XRS_BENCH_TEST_HANG=hang)
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--allow-host-halo", "--no-cpu-baseline", "--no-overlap", "--rows", "96", "--cols", "320", "--s64-size", "192",
+               "--zonal-size", "2048"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()[-3000:]
+        outs.append(out.decode())
+    import json
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]       # ONE line, from rank 0
+    cfg = json.loads(lines[0])["config"]
+    assert cfg["halo_check"]["ok"]
+    if hang:
+        assert "extras_error" in cfg and "s64_strong" not in cfg
+    else:
+        assert "extras_error" not in cfg
+        assert cfg["s64_strong"]["halo_check"]["ok"] and cfg["zonal32k_strong"]["counts_bit_exact_vs_host"], cfg
+
+
 def test_bench_dry_rccl_world2():
     """`bench.py --dry-rccl` (rendezvous, one halo exchange, one all-reduce, their checks) with two ranks over the host
     transport: rank r's halo rows must hold its neighbours' values, the sum of (rank + 1) must be 3, and the line must

@@ -47,3 +47,16 @@ def flush(path=None):
         json.dump({"what": "max relative error on |ref| > eps and max absolute error of the HIP path against the CPU oracle, "
                            "per op and BASELINE config, collected by the -m gpu tests", "rows": rows}, fh, indent=1)
     return path
+
+
+RTOL = 1e-5
+
+
+def assert_hillshade(got, want, err_msg=""):
+    """north_star's bar for hillshade: 1e-5 RELATIVE on every cell whose reference value is not (numerically) zero -- no absolute
+    term; only cells with |reference| <= 1e-6 (a fully shadowed facet: (shaded + 1) / 2 of float32 terms that cancel) are
+    held to 1e-6 absolute instead."""
+    got, want = np.asarray(got), np.asarray(want)
+    tiny = np.abs(want) <= 1e-6
+    np.testing.assert_allclose(np.where(tiny, want, got), want, rtol=RTOL, atol=0.0, equal_nan=True, err_msg=err_msg)
+    np.testing.assert_allclose(np.where(tiny, got, 0.0), np.where(tiny, want, 0.0), rtol=0.0, atol=1e-6, equal_nan=True, err_msg=err_msg + " (cells at zero)")

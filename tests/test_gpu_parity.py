@@ -12,12 +12,14 @@ import xrspatial_amd as xs
 from oracle import c_oracle as corc
 from oracle import xrs_oracle as orc
 from tests import parity_log, synth
+from tests.parity_log import assert_hillshade
 from xrspatial_amd.convolution import annulus_kernel, circle_kernel, convolve_2d, convolution_2d
 from xrspatial_amd.focal import apply, focal_stats, _calc_sum
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+
 
 
 def raster(data, res=(0.5, 0.5), backend='numpy'):
@@ -219,8 +221,11 @@ def test_terrain_vs_oracle(shape, backend):
         # relative bar only; hillshade alone ends in (shaded + 1) / 2 of float32 terms (absolute accuracy near 0)
         atol = 1e-6 if name == 'hillshade' else 0.0
         parity_log.record("smooth DEM 2000 + 800 sin cos + N(0, 0.05), cell 30 (float32-cancellation stress), small shapes",
-                          name, host(got.data), want, tol="rtol 1e-5" + (" + atol 1e-6" if atol else ""))
-        np.testing.assert_allclose(host(got.data), want, rtol=RTOL, atol=atol, equal_nan=True, err_msg=name)
+                          name, host(got.data), want, tol="rtol 1e-5" + (" (|ref| > 1e-6), else atol 1e-6" if atol else ""))
+        if name == 'hillshade':
+            assert_hillshade(host(got.data), want, name)
+        else:
+            np.testing.assert_allclose(host(got.data), want, rtol=RTOL, atol=atol, equal_nan=True, err_msg=name)
         check_meta(agg, got)
 
 
@@ -1377,7 +1382,7 @@ def test_raster_pass_fallbacks_and_shards():
         np.testing.assert_array_equal(got[s], r3[s])
     # against the oracle directly (not only against the stand-alone kernels)
     np.testing.assert_allclose(ref['focal_mean'], orc.focal_apply(z, k5, 'mean'), rtol=1e-6, equal_nan=True)
-    np.testing.assert_allclose(ref['hillshade'], orc.hillshade(z), rtol=RTOL, atol=1e-6, equal_nan=True)
+    assert_hillshade(ref['hillshade'], orc.hillshade(z))
 
 
 @pytest.mark.parametrize("backend", ['numpy', 'hip'])
@@ -1719,9 +1724,12 @@ def test_full_size_bands_match_oracle(dem16k):
             # reference as here; every other product is held to the relative bar alone
             atol = 1e-6 if name == 'hillshade' else 0.0
             parity_log.record("C2/C3 16384^2 (bands: top edge, interior, bottom edge)", name, got, want[name][rows],
-                              tol="rtol 1e-5" + (" + atol 1e-6" if atol else ""))
-            np.testing.assert_allclose(got, want[name][rows], rtol=RTOL, atol=atol, equal_nan=True,
-                                       err_msg=f"{name} band {y0}")
+                              tol="rtol 1e-5" + (" (|ref| > 1e-6), else atol 1e-6" if atol else ""))
+            if name == 'hillshade':
+                assert_hillshade(got, want[name][rows], f"{name} band {y0}")
+            else:
+                np.testing.assert_allclose(got, want[name][rows], rtol=RTOL, atol=atol, equal_nan=True,
+                                           err_msg=f"{name} band {y0}")
 
 
 def test_full_size_fused_pass_and_large_masks(dem16k):
@@ -1753,8 +1761,8 @@ def test_full_size_fused_pass_and_large_masks(dem16k):
         np.testing.assert_allclose(steep.data.rows(rows.start, rows.stop).get()[1:-1], wsl, rtol=RTOL, equal_nan=True)
         if not first and not last:
             whs = orc.hillshade(sub)[lo:hi]
-            parity_log.record(cfg, "fused hillshade", shade.data.rows(rows.start, rows.stop).get(), whs, tol="rtol 1e-5 + atol 1e-6")
-            np.testing.assert_allclose(shade.data.rows(rows.start, rows.stop).get(), whs, rtol=RTOL, atol=1e-6, equal_nan=True)
+            parity_log.record(cfg, "fused hillshade", shade.data.rows(rows.start, rows.stop).get(), whs, tol="rtol 1e-5 (|ref| > 1e-6), else atol 1e-6")
+            assert_hillshade(shade.data.rows(rows.start, rows.stop).get(), whs)
         got25 = apply(xs.DataArray(dev.rows(off, off + B + 2 * R)), k25).data.get()       # mean alone: the wide row walker
         w25 = corc.focal_apply(sub, k25, 'mean', nthreads=8)
         parity_log.record(cfg, "focal_mean_25x25 (mean alone)", got25[R:-R], w25[R:-R], tol="rtol 1e-6")
@@ -2160,7 +2168,9 @@ def test_row_shard_halo_contract_all_stencils():
         o64 = xs.DeviceArray((n, W), np.float64)
 
         def check(name, arr, tol=RTOL):
-            np.testing.assert_allclose(arr, want[name][y0:y1], rtol=tol, atol=1e-6 if name in ('hillshade', 'geodesic') else 0.0, equal_nan=True,
+            if name == 'hillshade':
+                return assert_hillshade(arr, want[name][y0:y1], f"{name} rows {y0}:{y1}")
+            np.testing.assert_allclose(arr, want[name][y0:y1], rtol=tol, atol=1e-6 if name == 'geodesic' else 0.0, equal_nan=True,
                                        err_msg=f"{name} rows {y0}:{y1}")
 
         L("xrs_slope_f32", shard.ptr, o32.ptr, n, W, W, W, 30.0, 30.0, h1t, h1b, None); check('slope', o32.get())
@@ -2240,7 +2250,7 @@ def test_terrain_with_infinite_cells():
         np.testing.assert_allclose(xs.slope(agg).data, orc.slope(z, 30.0, 30.0), rtol=RTOL, equal_nan=True)
         np.testing.assert_allclose(xs.aspect(agg).data, orc.aspect(z), rtol=RTOL, equal_nan=True)
         np.testing.assert_allclose(xs.curvature(agg).data, orc.curvature(z, 30.0), rtol=RTOL, equal_nan=True)
-        np.testing.assert_allclose(xs.hillshade(agg).data, orc.hillshade(z), rtol=RTOL, atol=1e-6, equal_nan=True)
+        assert_hillshade(xs.hillshade(agg).data, orc.hillshade(z))
         k = circle_kernel(1, 1, 2)
         got = focal_stats(agg, k)
         for i, stat in enumerate(orc.FOCAL_STATS):

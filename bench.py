@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 ROWS_PER_GPU = 16384
 COLS = 16384
 HALO = 2                      # 5x5 focal window; hillshade / slope need 1 of them
+NAN_DEM_FRAC = 0.001          # config.nan_dem: share of nodata cells
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 ALG_BYTES_FUSED = 12          # fused pass: 4 B read + 4 B hillshade + 4 B focal mean written per cell
 ALG_BYTES_PER_CELL = 8        # stand-alone kernels: 4 B read + 4 B written per cell
@@ -545,6 +546,40 @@ def run_headline(ctx):
         ok["hillshade_aspect_curvature_frac_of_hbm_peak"] = round(
             16.0 * rows * cols / (ok["hillshade_aspect_curvature_one_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         del fwork
+        # The same raster with nodata (0.1 % of the cells NaN, scattered, seeded): what every real DEM looks like
+        # to the NaN-ignoring focal kernels (focal.py:305-326, 44-67).  Round 4 ran strips with a NaN twice (profiles/r04/
+        # r04z_nan_probe.log: fused pass 0.61 -> 1.04 ms); the strip kernels now repair the rows that hold one in registers.
+        nan_buf = xs.DeviceArray((rows, cols), np.float32)
+        for y0 in range(0, rows, band):
+            n = min(band, rows - y0)
+            host = synth.asv_dem(n, cols, y0=y_begin + y0, total_rows=total_rows, nan_frac=NAN_DEM_FRAC)
+            L("xrs_memcpy_h2d", nan_buf.ptr + y0 * cols * 4, host.ctypes.data, host.nbytes, stream)
+            L("xrs_stream_sync", stream)
+        out_d = xs.DeviceArray((rows, cols), np.float64)
+        nd = {"what": f"the headline raster with {NAN_DEM_FRAC:.1%} of its cells NaN (scattered, seeded); clean-raster time of the "
+                      "same launch beside each figure", "nan_frac": NAN_DEM_FRAC}
+
+        def both(name, fn, reps=5):
+            nd[name + "_ms"] = round(timed(lambda: fn(nan_buf.ptr), reps=reps), 4)
+            nd[name + "_clean_ms"] = round(timed(lambda: fn(dem_ptr), reps=reps), 4)
+        both("fused", lambda p: L("xrs_raster_pass_f32", p, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data, kr, kc,
+                                   None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, 0, 0, stream), reps=10)
+        both("focal_mean_5x5", lambda p: L("xrs_focal_stats_f32", p, outs, 1, rows, cols, cols, cols, kernel.ctypes.data, kr, kc,
+                                            None, 0, 0, stream), reps=10)
+        excl = np.array([np.nan])                         # focal.mean's default `excludes`
+        both("focal_mean3x3", lambda p: L("xrs_focal_mean3x3", p, 0, out_d.ptr, rows, cols, cols, cols, excl.ctypes.data, 1, 0, 0,
+                                           stream), reps=10)
+        both("focal_mean_25x25", lambda p: L("xrs_focal_stats_f32", p, outs, 1, rows, cols, cols, cols, k25.ctypes.data, 25, 25,
+                                              None, 0, 0, stream))
+        both("focal_stats7_25x25", lambda p: L("xrs_focal_stats_f32", p, ptr7, 127, rows, cols, cols, cols, k25.ctypes.data, 25, 25,
+                                                None, 0, 0, stream))
+        both("focal_stats7_5x5", lambda p: L("xrs_focal_stats_f32", p, ptr7, 127, rows, cols, cols, cols, kernel.ctypes.data, 5, 5,
+                                              None, 0, 0, stream))
+        both("slope", lambda p: L("xrs_slope_f32", p, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0, 0, 0, stream))
+        nd["fused_frac_of_hbm_peak"] = round(ALG_BYTES_FUSED * rows * cols / (nd["fused_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+        nd["fused_mcells_s"] = round(rows * cols / (nd["fused_ms"] * 1e-3) / 1e6, 1)
+        extra["nan_dem"] = nd
+        del nan_buf, out_d
         ok["slope_frac_of_hbm_peak"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         ok["slope_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / copy_gbs, 3)
         ok["focal_mean_25x25_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["focal_mean_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)

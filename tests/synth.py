@@ -13,16 +13,27 @@ def smooth_dem(shape, seed=7, nan_frac=0.0, cellsize=30.0):
     return z
 
 
-def asv_dem(rows, cols, seed=71942, y0=0, total_rows=None):
+def asv_dem(rows, cols, seed=71942, y0=0, total_rows=None, nan_frac=0.0):
     """The reference's own benchmark raster (benchmarks/benchmarks/common.py:26-35) at any size:
-    100*exp(-x^2/5e5 - y^2/2e5) + N(0, 2); rows [y0, y0+rows) of a `total_rows`-row raster."""
+    100*exp(-x^2/5e5 - y^2/2e5) + N(0, 2); rows [y0, y0+rows) of a `total_rows`-row raster.
+    nan_frac: that share of the cells, scattered (seeded by the band's first row), is nodata (0.1 %)."""
     total_rows = total_rows or rows
     x = np.linspace(-180, 180, cols)
     y = np.linspace(-90, 90, total_rows)[y0:y0 + rows]
     x2, y2 = np.meshgrid(x, y)
     rng = np.random.default_rng(seed + y0)
-    z = 100.0 * np.exp(-x2 ** 2 / 5e5 - y2 ** 2 / 2e5) + rng.normal(0.0, 2.0, (rows, cols))
-    return z.astype(np.float32)
+    z = (100.0 * np.exp(-x2 ** 2 / 5e5 - y2 ** 2 / 2e5) + rng.normal(0.0, 2.0, (rows, cols))).astype(np.float32)
+    if nan_frac:
+        scatter_nodata(z, nan_frac, seed + 7919 + y0)
+    return z
+
+
+def scatter_nodata(z, frac, seed):
+    """NaN into round(frac * size) cells of z (in place), positions drawn with replacement from a seeded generator."""
+    n = int(round(frac * z.size))
+    if n:
+        z.reshape(-1)[np.random.default_rng(seed).integers(0, z.size, n)] = np.nan
+    return z
 
 
 def bands(shape, seed):

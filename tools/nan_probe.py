@@ -36,6 +36,10 @@ for label, frac, block in (("clean", 0.0, False), ("scattered 0.1%", 0.001, Fals
              "focal7_stats7": lambda: focal.focal_stats(A, circle_kernel(1, 1, 3)),
              "annulus21_stats7": lambda: focal.focal_stats(A, xs.convolution.annulus_kernel(1, 1, 10, 6)),
              "convolve5": lambda: xs.convolution.convolve_2d(dev, k5 / k5.sum()), "focal.mean": lambda: focal.mean(A)}
+    cases["box5_mean"] = lambda: focal.apply(A, np.ones((5, 5)))
+    only = os.environ.get("NAN_PROBE_CASES")
     for name, fn in cases.items():
+        if only and not any(name.startswith(o) for o in only.split(",")):
+            continue
         med, mn = t.time(lambda: (fn(), None)[1], 5, warmup=2)
         print(f"{label:16s} {name:18s} {med:8.3f} ms", flush=True)

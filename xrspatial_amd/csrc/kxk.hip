@@ -383,107 +383,36 @@ __global__ void __launch_bounds__(256) focal_mean_fast_kernel(const KxkArgs a) {
 // lanes' float4s), converts each value to float64 ONCE, and adds it into every output row it belongs
 // to.  All (RB+KH-1) row loads of a lane are independent and issued up front.
 // Interior waves (window entirely inside the raster: wave-uniform) load unconditionally from a scalar
-// row base; the sums are then checked for finiteness (a NaN/inf anywhere under a window poisons its
-// sum), and only waves that saw one -- or that touch a raster edge -- run the NaN-skipping, counting body.
+// row base.  The sums and the nodata handling are strip.h's strip_focal_mean: one body for clean strips, strips
+// with NaN cells and strips on the raster's edge.
 // CMASK: the mask as a compile-time constant (bit ky * KW + kx; 0 = a.mask_rows at run time) -- straight-line tap walk for
-// the common masks (circle_kernel(1, 1, 2), np.ones((3, 3)), np.ones((5, 5))), as in the fused pass.
-template <int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, unsigned CMASK = 0u>
-__device__ __forceinline__ bool focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
+// np.ones((3, 3)), as in the fused pass.
+template <int KH, int KW, int RB, bool INTERIOR, unsigned CMASK = 0u>
+__device__ __forceinline__ void focal_mean_direct_body(const KxkArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
     float v[NR][NV];
     load_strip<KH, KW, RB, INTERIOR>(a, x_tile, y0, lane, v);
 
     float *out = a.out[XRS_STAT_MEAN] + y0 * a.ld_out + x_tile;      // scalar
-    if (!CAREFUL) {
-        double acc[RB][4];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-            double d[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (bits >> kx & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
-                    }
-            }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
-        if (__any(bad)) return false;          // caller re-runs this strip through the NaN-aware body
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-            store_f4u(out + r * a.ld_out + loff, (float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
-                      (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps));
-        return true;
-    }
-    // edge / NaN body
-    {
-        // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
-        // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
-        // the sum and 0 to a float32 count (exact far beyond 25 taps).  Rows are consumed as they are walked, so this
-        // body needs no more registers than the fast one (the per-output form it replaces spilled).
-        double acc[RB][4];
-        float cnt[RB][4];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-            double z[NV];
-            float c[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const bool okv = !isnan(v[ir][i]);
-                z[i] = okv ? (double)v[ir][i] : 0.0;
-                c[i] = okv ? 1.0f : 0.0f;
-            }
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (bits >> kx & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
-                    }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (!INTERIOR && y0 + r >= a.rows) break;
-            store_cols(out + r * a.ld_out + loff, (float)(acc[r][0] * rcp_count((int)cnt[r][0])),
-                       (float)(acc[r][1] * rcp_count((int)cnt[r][1])), (float)(acc[r][2] * rcp_count((int)cnt[r][2])),
-                       (float)(acc[r][3] * rcp_count((int)cnt[r][3])),
-                       INTERIOR ? 4 : (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4));
-        }
-    }
-    return true;
+    const int nown = INTERIOR ? 4 : (int)(a.cols - (x_tile + loff) < 4 ? a.cols - (x_tile + loff) : 4);
+    strip_focal_mean<KH, KW, RB, CMASK, true, false, INTERIOR>(v, a.mask_rows, a.ntaps, a.inv_ntaps, strip_probe_rows(v), [&](int r, const float (&m)[4]) {
+        if (!INTERIOR && y0 + r >= a.rows) return;
+        store_cols(out + r * a.ld_out + loff, m[0], m[1], m[2], m[3], nown);
+    });
 }
 
 template <int KH, int KW, int RB, unsigned CMASK = 0u>
 #ifndef XRS_LB_MEAN
 #define XRS_LB_MEAN 4
 #endif
-// (3x3: the three inlined bodies need ~150 VGPRs; at 4 workgroups per CU they spilled 25 registers and ran at half speed)
-__global__ void __launch_bounds__(256, KH == 3 ? 3 : XRS_LB_MEAN) focal_mean_direct_kernel(const KxkArgs a) {
+// At most 4 waves per SIMD: the body needs 62-86 VGPRs and would run 5-7, and this streaming kernel is then 3 % slower (same-box
+// A/B, profiles/r05/ab_wave_caps.log: 3x3 mean 0.349 -> 0.339 ms, the 152-register round-4 kernel ran 3 and took 0.340).
+#ifndef XRS_MEAN_WAVES
+#define XRS_MEAN_WAVES 4
+#endif
+__attribute__((amdgpu_waves_per_eu(1, XRS_MEAN_WAVES)))
+__global__ void __launch_bounds__(256, XRS_LB_MEAN) focal_mean_direct_kernel(const KxkArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
     const long ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
@@ -493,12 +422,11 @@ __global__ void __launch_bounds__(256, KH == 3 ? 3 : XRS_LB_MEAN) focal_mean_dir
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!focal_mean_direct_body<KH, KW, RB, true, false, CMASK>(a, x_tile, y0, lane))
-            focal_mean_direct_body<KH, KW, RB, true, true, CMASK>(a, x_tile, y0, lane);    // NaN / inf under a window: NaN-aware, same loads
+        focal_mean_direct_body<KH, KW, RB, true, CMASK>(a, x_tile, y0, lane);
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    focal_mean_direct_body<KH, KW, RB, false, true, CMASK>(a, x_tile, y0, lane);
+    focal_mean_direct_body<KH, KW, RB, false, CMASK>(a, x_tile, y0, lane);
 }
 
 // All seven statistics, compile-time 3x3 / 5x5 shape, register-resident strip (same layout as the mean
@@ -703,6 +631,8 @@ struct Mean3Args {
     long rows, cols, ld_in, ld_out;
     int halo_top, halo_bot;
     int n_excl;
+    int only_nan_excl;            // every exclude value is NaN (or there is none): the strip path's condition
+    int excl_nan;                 // some exclude value is NaN: NaN cells pass through
     double excl[8];
 };
 
@@ -736,9 +666,9 @@ __global__ void __launch_bounds__(256) focal_mean3_kernel(const Mean3Args a) {
 
 // Strip version of focal.mean for 16-byte friendly rasters: a wave owns 256 columns x 4 rows, each lane
 // keeps its 6 x 6 neighbourhood in registers (float32 or float64 input), interior waves sum the nine
-// cells in float64 row-major (the reference's nanmean order) and divide by the constant 9; a strip whose
-// sums come out non-finite (a NaN/inf under some window) or that touches a raster edge is redone cell by
-// cell with the counting body.  Excluded centre values are passed through in both paths.
+// cells in float64 row-major (the reference's nanmean order) and divide by the constant 9 (by the count of non-NaN
+// cells under a window with nodata); a strip that touches a raster edge is done cell by cell with the counting
+// body.  Excluded centre values are passed through in both paths.
 template <typename InT>
 __device__ __forceinline__ void load6(const InT *p, bool has_l, bool has_r, double (&d)[6]);
 template <>
@@ -776,8 +706,11 @@ __device__ __forceinline__ double div9_exact(double s) {
     return q;
 }
 
+#ifndef XRS_LB_MEAN3
+#define XRS_LB_MEAN3 3
+#endif
 template <typename InT>
-__global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
+__global__ void __launch_bounds__(256, XRS_LB_MEAN3) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
     constexpr int RB = 4;
     const long t = xcd_tile(blockIdx.x, n_tiles, tiles_x);
     if (t < 0) return;
@@ -791,15 +724,73 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
     const unsigned loff = (unsigned)lane * 4u;
     const long x0 = x_tile + loff;
     const bool interior = x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - 1 >= y_lo && y0 + RB + 1 <= y_hi &&
-                          y0 + RB <= a.rows;
+                          y0 + RB <= a.rows && a.only_nan_excl;
     if (interior) {
         double d[RB + 2][6];
 #pragma unroll
         for (int r = 0; r < RB + 2; ++r) load6<InT>(in + (y0 - 1 + r) * a.ld_in + x_tile + loff, true, true, d[r]);
-        double res[RB][4];
-        bool bad = false;
+        // Nodata like strip.h's strip_focal_mean: a chain of fused multiply-adds over the lane's 6 cells of a row is non-finite
+        // when one of them is NaN / inf (3 instructions; float64 products of float32 or sane float64 cells do not overflow, and a
+        // row that does only takes the repair for nothing); the rows are voted on wave-wide.  A clean strip then runs straight
+        // through: nine additions and a division by 9 per cell, no test per cell (no cell is NaN, and NaN is the only exclude
+        // value this path is taken with).  Otherwise the ROWS that hold one are repaired (NaN -> 0 in the registers: adding 0.0
+        // where the reference skips the cell leaves its row-major float64 sum as it is; positions into a per-lane bit mask),
+        // and only output rows under a repaired row count their cells and divide by the count.  (Round 4 redid the whole strip
+        // cell by cell from re-loaded rows: 0.66 -> 1.00 ms at 0.1 % nodata.)
+        unsigned rows_hit = 0u;                   // wave-uniform
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB + 2; ++r) {
+            const double probe = fma(d[r][3], d[r][4], fma(d[r][0], d[r][1], d[r][2])) + d[r][5];
+            rows_hit |= __any(!isfinite(probe)) ? 1u << r : 0u;
+        }
+        // s / 9 for a finite sum of float32 cells: 0 or 2^-149 <= |s| <= 2^132, where div9_exact's corrections need no guard
+        auto ninth = [](double s) {
+            if (sizeof(InT) == 8) return div9_exact(s);
+            const double y = 0x1.c71c71c71c71cp-4;
+            double q = s * y;
+            q = fma(fma(-9.0, q, s), y, q);
+            return fma(fma(-9.0, q, s), y, q);
+        };
+        if (rows_hit == 0u) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                __builtin_amdgcn_sched_barrier(0);   // (one output row at a time: interleaved, the rows' temporaries spill)
+                double res[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) s += d[r + ky][o + kx];
+                    res[o] = ninth(s);
+                }
+                store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[0], res[1], res[2], res[3]);
+            }
+            return;
+        }
+        unsigned nanbits[2] = {0u, 0u};           // bit 8 * (r & 3) + i of entry r >> 2: cell i of loaded row r was NaN
+#pragma unroll
+        for (int r = 0; r < RB + 2; ++r) {
+            if (!(rows_hit >> r & 1u)) continue;
+            unsigned m = 0u;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool isn = isnan(d[r][i]);
+                m |= isn ? 1u << (8 * (r & 3) + i) : 0u;
+                d[r][i] = isn ? 0.0 : d[r][i];
+            }
+            nanbits[r >> 2] |= m;
+        }
+        // s / n for the n = 9 - lost cells that count, correctly rounded like the reference's division, without the division
+        // sequence: Markstein's two residual corrections (div9_exact) with y = RN(1 / n) -- checked against exact rational
+        // arithmetic for n = 1 .. 9 on 1.8e6 sums -- and y fetched from a table ACROSS the wave (lane j holds 1 / (9 - j); lane 9:
+        // 1 / 0 = inf, and 0 * inf = NaN is the reference's 0 / 0).
+        const double my_y = 1.0 / (double)(9 - (lane < 9 ? lane : 9));
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const unsigned hit = (rows_hit >> r) & 7u;
+            double res[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 double s = 0.0;
@@ -807,44 +798,25 @@ __global__ void __launch_bounds__(256) focal_mean3_strip_kernel(const Mean3Args 
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) s += d[r + ky][o + kx];
-                bad |= !isfinite(s);
-                const double c = d[r + 1][o + 1];
-                res[r][o] = is_excluded(a, c) ? c : div9_exact(s);
+                if (hit == 0u) {
+                    res[o] = ninth(s);
+                } else {
+                    int lost = 0;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+                        if (hit >> ky & 1u) lost += __popc((nanbits[(r + ky) >> 2] >> (8 * ((r + ky) & 3) + o)) & 7u);
+                    const double n = (double)(9 - lost), y = __shfl(my_y, lost);
+                    double q = s * y;
+                    q = fma(fma(-n, q, s), y, q);
+                    q = fma(fma(-n, q, s), y, q);
+                    // (an infinite or, from float64 cells, extreme sum: the true division; 0 * inf above is already the NaN of 0 / 0)
+                    const double as = fabs(s);
+                    if (__builtin_expect(!(as < 0x1p900 && (sizeof(InT) == 4 || as > 0x1p-900 || as == 0.0)) && lost < 9, 0)) q = s / n;
+                    const bool c_nan = (hit & 2u) && (nanbits[(r + 1) >> 2] >> (8 * ((r + 1) & 3) + o + 1) & 1u);
+                    res[o] = (c_nan && a.excl_nan) ? nan("") : q;
+                }
             }
-        if (!__any(bad)) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[r][0], res[r][1], res[r][2], res[r][3]);
-            }
-            return;
-        }
-        // a NaN / inf under some window of this strip: NaN-skipping, counting sums, one output row at a time from
-        // re-loaded rows (L1 hits; a rolled loop so that this path does not raise the kernel's register count -- done
-        // from the fast path's registers it doubled it).  The window is complete for an interior strip, so this is
-        // the reference's loop without its bounds tests.
-#pragma unroll 1
-        for (int r = 0; r < RB; ++r) {
-            double w[3][6];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) load6<InT>(in + (y0 - 1 + r + ky) * a.ld_in + x_tile + loff, true, true, w[ky]);
-            double m[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                double s = 0.0;
-                int n = 0;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const double x = w[ky][o + kx];
-                        const bool okv = !isnan(x);
-                        s += okv ? x : 0.0;
-                        n += okv ? 1 : 0;
-                    }
-                const double c = w[1][o + 1];
-                m[o] = is_excluded(a, c) ? c : s / (double)n;           // 0/0 -> NaN like the reference
-            }
-            store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, m[0], m[1], m[2], m[3]);
+            store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[0], res[1], res[2], res[3]);
         }
         return;
     }
@@ -1395,7 +1367,11 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
     memset(&a, 0, sizeof(a));
     a.in = in_dev; a.out = out_dev; a.rows = rows; a.cols = cols; a.ld_in = ld_in; a.ld_out = ld_out;
     a.halo_top = halo_top; a.halo_bot = halo_bot; a.n_excl = n_excludes;
-    for (int i = 0; i < n_excludes; ++i) a.excl[i] = excludes[i];
+    a.only_nan_excl = 1; a.excl_nan = 0;
+    for (int i = 0; i < n_excludes; ++i) {
+        a.excl[i] = excludes[i];
+        if (std::isnan(excludes[i])) a.excl_nan = 1; else a.only_nan_excl = 0;
+    }
     // (the strip kernel's 16-byte accesses only need dword / 8-byte alignment; its edge path is cell by cell)
     const bool vec = true;
     if (vec) {

@@ -16,6 +16,8 @@
 //
 // Any width / pitch / base address (dword-aligned 16-byte accesses, ragged last lane).  Masks larger than 5x5 run as
 // the separate launches -- same results, no fusion.
+#include <type_traits>
+
 #include "strip.h"
 #include "terrain_cells.h"
 
@@ -34,6 +36,7 @@ struct PassArgs {
     int nt_stores;            // host-side choice of the kernel variant: every output row is 16-byte aligned
     unsigned mask_rows[5];    // bit kx of entry ky: tap (ky, kx) selected
     double inv_ntaps;
+    int ntaps;
     long tiles_x, n_tiles;
     // xrs_raster_pass_edges_f32: the launch covers tile rows [0, seg_tiles_y) and, after a gap of seg_skip tile rows, the rest
     // (0 / 0: every tile row, in order)
@@ -61,56 +64,28 @@ __device__ __forceinline__ void put4(float *p, const float (&v)[4], int n = 4) {
 }
 
 // OPS: compile-time superset of the terrain products this instantiation can emit (absent ones are skipped by
-// wave-uniform null tests, like terrain.hip's fused kernel).  Returns false when the interior fast path met a
-// non-finite window sum: the caller re-runs the focal part of the strip through the careful body.
+// wave-uniform null tests, like terrain.hip's fused kernel).
 // CMASK: the window's taps as a compile-time constant (bit ky * KW + kx), 0 = read them from a.mask_rows at run time.
-// With the mask known, the tap walk is straight-line code: no scalar branch per tap row, and the register allocator
-// sees one basic block (the circular 5x5 mask of `circle_kernel(1, 1, 2)` -- the bench's -- is instantiated this way).
-// Compile-time plan for the window sums of a mask known at compile time: the mask rows in order of increasing tap count,
-// and for each the already summed row it can be built from (the largest subset).  The circular 5x5 mask has the row
-// patterns {2}, {1,2,3}, {0..4}: per input row and output column the three row sums cost 0 + 2 + 2 additions and each
-// goes into the output rows that see it with ONE addition -- 9 float64 additions per cell instead of 13 taps.  (Sums of
-// float32 cells are exact in float64 as long as the window's cells are within 2^29 of each other in magnitude, so the
-// association does not show.)
-struct RowPlan { int order[8]; int base[8]; };
-template <unsigned CMASK, int KH, int KW>
-constexpr RowPlan make_row_plan() {
-    RowPlan p = {};
-    auto bits = [](int ky) { return (CMASK >> (ky * KW)) & ((1u << KW) - 1u); };
-    auto pop = [](unsigned b) { int n = 0; for (; b; b &= b - 1) ++n; return n; };
-    int cnt = 0;
-    for (int c = 0; c <= KW; ++c)
-        for (int ky = 0; ky < KH; ++ky)
-            if (pop(bits(ky)) == c) p.order[cnt++] = ky;
-    for (int r = 0; r < KH; ++r) {
-        const unsigned b = bits(p.order[r]);
-        int best = -1, bp = 0;
-        for (int r2 = 0; r2 < r; ++r2) {
-            const unsigned c = bits(p.order[r2]);
-            if ((c & ~b) == 0u && pop(c) > bp) { best = r2; bp = pop(c); }
-        }
-        p.base[r] = best;
-    }
-    return p;
-}
-
+// With the mask known, the tap walk is straight-line code with no scalar branch per tap row (the circular 5x5 mask of
+// `circle_kernel(1, 1, 2)` -- the bench's -- is instantiated this way).
 #ifndef XRS_PASS_SHARED_ROWS
 #define XRS_PASS_SHARED_ROWS 1
 #endif
-#ifndef XRS_PASS_RH
-#define XRS_PASS_RH 0          // output rows per walk of the NaN-aware body (0: all RB)
-#endif
-template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool CAREFUL, bool TERRAIN, bool NT, unsigned CMASK = 0u>
-__device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
+template <int OPS, int KH, int KW, int RB, bool INTERIOR, bool NT, unsigned CMASK = 0u>
+__device__ __forceinline__ void pass_body(const PassArgs &a, long x_tile, long y0, int lane) {
     constexpr int RX = KW / 2, RY = KH / 2, NV = 4 + 2 * RX, NR = RB + KH - 1;
     const unsigned loff = (unsigned)lane * 4u;
     const long x0 = x_tile + lane * 4;
     float v[NR][NV];
     load_strip<KH, KW, RB, INTERIOR>(a, x_tile, y0, lane, v);
 
-    // ---- terrain products from the 3x3 centre of the registers (first: they need no accumulators, and an
-    // interior strip whose focal sums turn out non-finite keeps them -- the careful re-run skips this part)
-    if (TERRAIN) {
+    // which rows hold a NaN / inf (wave-uniform): gates the repair in strip_focal_mean, and tells the terrain products of a
+    // clean strip that their neighbourhoods are finite
+    const unsigned rows_hit = strip_probe_rows(v);
+
+    // ---- terrain products from the 3x3 centre of the registers (first: they need no accumulators)
+    auto terrain = [&](auto finite) {
+        constexpr bool FINITE = decltype(finite)::value;
         const long y_lo = -(long)a.halo_top, y_hi = a.rows + a.halo_bot;
         const float qnan = nan_f32();
         // (slope / aspect: Horn sums cell by cell here -- sharing the differences along the strip, terrain.hip's HornRoller,
@@ -137,7 +112,8 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
                 if ((OPS & OP_SLOPE) && a.out[0]) o_slope[o] = border ? qnan : slope_from_horn(hs[o], sk);
                 if ((OPS & OP_ASPECT) && a.out[1]) o_aspect[o] = border ? qnan : aspect_from_horn(hs[o]);
                 if ((OPS & OP_CURV) && a.out[2]) o_curv[o] = border ? qnan : curvature_cell(q, a.curv_scale);
-                if ((OPS & OP_HILL) && a.out[3]) o_hill[o] = border ? qnan : hillshade_cell(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
+                if ((OPS & OP_HILL) && a.out[3])
+                    o_hill[o] = border ? qnan : hillshade_cell<FINITE>(q, a.sin_alt, a.cos_alt, a.cos_az, a.sin_az);
             }
             const long off = y * a.ld_out + x_tile;
             const int nown = INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4);
@@ -146,147 +122,50 @@ __device__ __forceinline__ bool pass_body(const PassArgs &a, long x_tile, long y
             if ((OPS & OP_CURV) && a.out[2]) put4<NT>(a.out[2] + off + loff, o_curv, nown);
             if ((OPS & OP_HILL) && a.out[3]) put4<NT>(a.out[3] + off + loff, o_hill, nown);
         }
-    }
+    };
+    // (two copies only where the clean one is shorter: hillshade on interior strips)
+    if (INTERIOR && (OPS & OP_HILL) && rows_hit == 0u)
+        terrain(std::true_type{});
+    else
+        terrain(std::false_type{});
 
-    // ---- focal mean (float64 accumulation in row-major tap order == numba nanmean over the window).  (Round 2 tried
-    // float32 sums of values shifted by the lane's centre cell: half the VALU cycles, no spills -- and the same 0.57 ms,
-    // because this kernel runs at the streaming ceiling of its 1-read / 2-write traffic mix (experiments/rw_mix.hip); the
-    // float64 sums keep results independent of how a raster is cut into strips, bands or shards.)
+    // ---- focal mean: strip.h's strip_focal_mean (float64 sums == numba nanmean over the window; one body for clean strips,
+    // strips with nodata and strips on the raster's edge).  (Round 2 tried float32 sums of values shifted by the lane's
+    // centre cell: half the VALU cycles, no spills -- and the same 0.57 ms, because this kernel runs at the streaming ceiling
+    // of its 1-read / 2-write traffic mix (experiments/rw_mix.hip); the float64 sums keep results independent of how a
+    // raster is cut into strips, bands or shards.)
+    // Shared row sums (make_row_plan): same-box A/B hillshade + 5x5 mean 0.577 -> 0.570 ms, + slope 0.808 -> 0.798; NOT for the
+    // instantiations with aspect, which the row sums push from 168 to 178 VGPRs = from 3 to 2 waves per SIMD (all four
+    // products + mean: 1.19 -> 1.37 ms)
     float *fout = a.focal + y0 * a.ld_out + x_tile;
-    if (!CAREFUL) {
-        double acc[RB][4];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[r][o] = 0.0;
-#pragma unroll
-        for (int ir = 0; ir < NR; ++ir) {
-            // (the focal mean alone: without the terrain block in front, the scheduler hoists the conversions of ALL rows to
-            //  the top -- 128 registers of float64 images -- and spills 100 of them; one row at a time)
-            if (OPS == 0) __builtin_amdgcn_sched_barrier(0);
-            double d[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) d[i] = (double)v[ir][i];
-            if (CMASK != 0u && KH <= 8 && XRS_PASS_SHARED_ROWS && !(OPS & OP_ASPECT)) {
-                // shared row sums (make_row_plan): every distinct row pattern once per input row.  Same-box A/B: hillshade + 5x5
-                // mean 0.577 -> 0.570 ms, + slope 0.808 -> 0.798; NOT for the instantiation with slope AND aspect, which the row sums
-                // push from 168 to 178 VGPRs = from 3 to 2 waves per SIMD (all four products + mean: 1.19 -> 1.37 ms)
-                constexpr RowPlan plan = make_row_plan<CMASK ? CMASK : 1u, KH, KW>();
-                double rs[KH][4];
-#pragma unroll
-                for (int r = 0; r < KH; ++r) {
-                    const int ky = plan.order[r];
-                    const unsigned bits = (CMASK >> (ky * KW)) & ((1u << KW) - 1u);
-                    const unsigned have = plan.base[r] >= 0 ? (CMASK >> (plan.order[plan.base[r] >= 0 ? plan.base[r] : 0] * KW)) & ((1u << KW) - 1u) : 0u;
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        double t = 0.0;
-                        bool first = true;
-                        if (plan.base[r] >= 0 && have) { t = rs[plan.base[r] >= 0 ? plan.base[r] : 0][o]; first = false; }
-#pragma unroll
-                        for (int kx = 0; kx < KW; ++kx)
-                            if ((bits & ~have) >> kx & 1u) {
-                                t = first ? d[kx + o] : t + d[kx + o];
-                                first = false;
-                            }
-                        rs[r][o] = t;
-                    }
-                    const int orow = ir - ky;
-                    if (orow < 0 || orow >= RB || bits == 0u) continue;
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[orow][o] += rs[r][o];
-                }
-                continue;
-            }
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-                const int orow = ir - ky;
-                if (orow < 0 || orow >= RB) continue;
-                const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : a.mask_rows[ky];
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx)
-                    if (bits >> kx & 1u) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[orow][o] += d[kx + o];
-                    }
-            }
-        }
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) bad |= !isfinite(acc[r][o]);
-        if (__any(bad)) return false;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float m[4] = {(float)(acc[r][0] * a.inv_ntaps), (float)(acc[r][1] * a.inv_ntaps),
-                                (float)(acc[r][2] * a.inv_ntaps), (float)(acc[r][3] * a.inv_ntaps)};
-            put4<NT>(fout + r * a.ld_out + loff, m);
-        }
-    } else {
-        // NaN-aware: the same inverted walk (every loaded row is converted once and added into the output rows whose
-        // window covers it -- per output the taps still arrive in row-major order), with NaN cells contributing 0 to
-        // the sum and 0 to a float32 count (exact far beyond 25 taps).
-        // This COLD body (strips with a NaN / inf under a window, strips on the raster edge) is where the kernel's
-        // spilled registers live: in the ISA of the bench instantiation every scratch access lies between the fast
-        // body's `s_cbranch_vccz` over the re-run and its target; the hot path touches no scratch (tools/spill_scan.py
-        // reports per kernel, not per path).  Walking RH < RB output rows at a time (XRS_PASS_RH) trims the spill of the
-        // compile-time-mask instantiations (80 -> 52 -> 28 bytes for RH = 4, 2, 1) and quadruples it for the run-time-mask
-        // ones: left at RB.
-        constexpr int RH = XRS_PASS_RH ? XRS_PASS_RH : RB;
-#pragma unroll
-        for (int hb = 0; hb < RB; hb += RH) {
-            double acc[RH][4];
-            float cnt[RH][4];
-#pragma unroll
-            for (int r = 0; r < RH; ++r)
-#pragma unroll
-                for (int o = 0; o < 4; ++o) { acc[r][o] = 0.0; cnt[r][o] = 0.0f; }
-#pragma unroll
-            for (int ir = hb; ir < hb + RH + KH - 1; ++ir) {
-                double z[NV];
-                float c[NV];
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const bool okv = !isnan(v[ir][i]);
-                    z[i] = okv ? (double)v[ir][i] : 0.0;
-                    c[i] = okv ? 1.0f : 0.0f;
-                }
-#pragma unroll
-                for (int ky = 0; ky < KH; ++ky) {
-                    const int orow = ir - ky - hb;
-                    if (orow < 0 || orow >= RH) continue;
-                    const unsigned bits = CMASK ? ((CMASK >> (ky * KW)) & ((1u << KW) - 1u)) : (unsigned)a.mask_rows[ky];
-#pragma unroll
-                    for (int kx = 0; kx < KW; ++kx)
-                        if (bits >> kx & 1u) {
-#pragma unroll
-                            for (int o = 0; o < 4; ++o) { acc[orow][o] += z[kx + o]; cnt[orow][o] += c[kx + o]; }
-                        }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RH; ++r) {
-                if (!INTERIOR && y0 + hb + r >= a.rows) break;
-                const float m[4] = {(float)(acc[r][0] * rcp_count((int)cnt[r][0])), (float)(acc[r][1] * rcp_count((int)cnt[r][1])),
-                                    (float)(acc[r][2] * rcp_count((int)cnt[r][2])), (float)(acc[r][3] * rcp_count((int)cnt[r][3]))};
-                put4<NT>(fout + (hb + r) * a.ld_out + loff, m, INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4));
-            }
-        }
-    }
-
-    return true;
+    const int nown = INTERIOR ? 4 : (int)(a.cols - x0 < 4 ? a.cols - x0 : 4);
+    strip_focal_mean<KH, KW, RB, CMASK, XRS_PASS_SHARED_ROWS && !(OPS & OP_ASPECT), OPS == 0, INTERIOR>(
+        v, a.mask_rows, a.ntaps, a.inv_ntaps, rows_hit, [&](int r, const float (&m)[4]) {
+            if (!INTERIOR && y0 + r >= a.rows) return;
+            put4<NT>(fout + r * a.ld_out + loff, m, nown);
+        });
 }
 
 template <int OPS, int KH, int KW, int RB, bool NT, unsigned CMASK = 0u>
-// instantiations with slope / aspect: 2 (the allocator then takes 156-168 VGPRs = 3 waves per SIMD without scratch; capped at
-// 4 workgroups per CU they spill 31-45 registers in the hot path: hillshade + slope + 5x5 mean 0.81 -> 1.18 ms)
+// instantiations with slope / aspect: 3 workgroups per CU = 168 VGPRs (they take 155-167 without scratch; the all-four one would
+// take 177 = 2 waves per SIMD if allowed to, and holds 168 with 4 spilled registers; capped at 4 workgroups per CU they spill
+// 31-45 registers in the hot path: hillshade + slope + 5x5 mean 0.81 -> 1.18 ms)
 #ifndef XRS_LB_PASS_HORN
-#define XRS_LB_PASS_HORN 2
+#define XRS_LB_PASS_HORN 3
 #endif
 #ifndef XRS_LB_PASS
 #define XRS_LB_PASS 4
 #endif
+// Waves per SIMD, capped: since the nodata handling moved out of line these kernels need 59-111 (3x3) / 85-139 (5x5) VGPRs and would
+// run 4-8 waves; the streams they read and write like fewer (same-box A/B, profiles/r05/ab_wave_caps.log: hillshade + 3x3 mean
+// 0.515 -> 0.489 ms at 3; 5x5 mean alone 0.368 -> 0.363 at 4; hillshade + 5x5 mean 0.548 / 0.562 / 0.546 uncapped / 3 / 4).
+#ifndef XRS_PASS_WAVES3
+#define XRS_PASS_WAVES3 3
+#endif
+#ifndef XRS_PASS_WAVES5
+#define XRS_PASS_WAVES5 4
+#endif
+__attribute__((amdgpu_waves_per_eu(1, KH == 3 ? XRS_PASS_WAVES3 : XRS_PASS_WAVES5)))
 __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? XRS_LB_PASS_HORN : XRS_LB_PASS) raster_pass_kernel(const PassArgs a) {
     const long t = xcd_tile(blockIdx.x, a.n_tiles, a.tiles_x);
     if (t < 0) return;
@@ -298,13 +177,11 @@ __global__ void __launch_bounds__(256, (OPS & (OP_SLOPE | OP_ASPECT)) ? XRS_LB_P
     const long y0 = ty * (4 * RB) + (long)wy * RB;
     if (y0 >= a.rows) return;
     if (strip_is_interior<KH, KW, RB>(a, x_tile, y0)) {
-        if (!pass_body<OPS, KH, KW, RB, true, false, true, NT, CMASK>(a, x_tile, y0, lane))
-            pass_body<OPS, KH, KW, RB, true, true, false, NT, CMASK>(a, x_tile, y0, lane);  // NaN / inf under a window: focal part
-                                                                                     // again, NaN-aware, same loads
+        pass_body<OPS, KH, KW, RB, true, NT, CMASK>(a, x_tile, y0, lane);
         return;
     }
     if (x_tile + lane * 4 >= a.cols) return;
-    pass_body<OPS, KH, KW, RB, false, true, true, NT, CMASK>(a, x_tile, y0, lane);
+    pass_body<OPS, KH, KW, RB, false, NT, CMASK>(a, x_tile, y0, lane);
 }
 
 template <int OPS, int K>
@@ -485,6 +362,7 @@ static int raster_pass(const float *in_dev, float *slope_dev, float *aspect_dev,
         for (int kx = 0; kx < kcols; ++kx)
             if (kernel[ky * kcols + kx] == 1.0) a.mask_rows[ky] |= 1u << kx;
     a.inv_ntaps = 1.0 / ntaps;
+    a.ntaps = ntaps;
     if (edge_rows >= 0) { a.seg_tiles_y = seg_a; a.seg_skip = seg_b - seg_a; }
     return krows == 3 ? launch_pass_ops<3>(a, fused_ops, as_stream(stream)) : launch_pass_ops<5>(a, fused_ops, as_stream(stream));
 }

@@ -941,6 +941,39 @@ def run_zonal32k(ctx, steps=None, warmup=None, brief=False):
                       ("host-staged over gloo (--allow-host-halo)" if world > 1 else "none (one GPU)")),
         "counts_bit_exact_vs_host": counts_ok, "total_count": int(got.sum()),
     }
+    if world == 1 and not args.no_extras:
+        # The PUBLIC call on the same resident rasters -- xrspatial.zonal.stats' signature, DataArray in, pandas.DataFrame out
+        # (zonal.py:422-667) -- with RAW zone ids (the blocky ids + 5000): id discovery (np.unique(zones), zonal.py:290), the
+        # reduction, the five tables back over PCIe, mean / std / var and the DataFrame on the host.  Wall clock per call.
+        zraw = xs.DeviceArray((rows, cols), np.int32)
+        for r0 in range(0, rows, band_rows):
+            n = min(band_rows, rows - r0)
+            z = synth.block_zones(n, cols, n_zones=nz, block=block, y0=y0 + r0) + np.int32(5000)
+            L("xrs_memcpy_h2d", zraw.ptr + r0 * cols * 4, z.ctypes.data, z.nbytes, stream)
+            L("xrs_stream_sync", stream)
+        za, va = xs.DataArray(zraw, dims=['y', 'x']), xs.DataArray(vals, dims=['y', 'x'])
+        seven = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+
+        def wall(fn, reps):
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t) * 1e3)
+            return float(np.median(ts))
+        df = xs.zonal_stats(za, va, stats_funcs=seven)                  # (first call: allocations)
+        api7 = wall(lambda: xs.zonal_stats(za, va, stats_funcs=seven), 7)
+        api_ok = bool(len(df) == nz and (df['zone'].to_numpy() == np.arange(5000, 5000 + nz)).all()
+                      and (df['count'].to_numpy().astype(np.int64) == want).all())
+        xs.zonal_stats(za, va)
+        api_def = wall(lambda: xs.zonal_stats(za, va), 2)
+        out["api"] = {"what": "xs.zonal_stats(zones, values, stats_funcs=...) -> DataFrame on the resident rasters, raw ids 5000..5999; "
+                              "wall clock per call (id discovery + reduction + D2H + host finish)",
+                      "api_ms_7stats": round(api7, 4), "api_ms_default_with_majority": round(api_def, 4),
+                      "kernel_ms": round(dev_ms, 4), "api_over_kernel_7stats": round(api7 / dev_ms, 3),
+                      "api_mcells_s_7stats": round(cells_total / (api7 * 1e-3) / 1e6, 1),
+                      "zones_and_counts_equal_exact_host_counts": api_ok}
+        del zraw, za, va
     if args.zonal_size == 32768:
         out["traffic_rank0"], out["traffic_from"] = traffic_for(ctx, SYM_ZONAL, rows, cols, None)
         if world > 1:

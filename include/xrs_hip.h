@@ -278,6 +278,27 @@ int xrs_zonal_partials_lut_f64(const int32_t *zones_dev, int32_t zone_min, int32
                                const double *values_dev, int64_t n, int n_zones, double nodata, int has_nodata, double shift,
                                uint64_t *count_dev, double *sum_dev, double *sumsq_dev, double *min_dev, double *max_dev,
                                void *stream);
+/* ONE pass from the raw int32 zone raster WITHOUT a discovery pass in front (np.unique(zones) of zonal.py:290 folded into the
+ * reduction): the caller GUESSES a window of ids [zone_base, zone_base + window) -- xrs_zonal_sample_* below reads a strided
+ * sample of the rasters for that -- and the kernel accumulates straight into window-indexed tables (entry id - zone_base;
+ * window <= 5000 ids: the tables live in LDS), which it initialises itself (overwritten, not accumulated into).
+ * present_dev[id - zone_base] = 1 (window bytes) for ids that occur with invalid values only (count 0: the reference still
+ * lists such a zone); *overflow_dev = 1 if some cell's id lies outside the window -- the tables are then incomplete and the
+ * caller takes the two-pass route (xrs_zonal_scan_presence_i32 + xrs_zonal_partials_lut_*). */
+int xrs_zonal_partials_window_f32(const int32_t *zones_dev, int32_t zone_base, int window, const float *values_dev, int64_t n,
+                                  float nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
+                                  double *sumsq_dev, float *min_dev, float *max_dev, unsigned char *present_dev,
+                                  int32_t *overflow_dev, void *stream);
+int xrs_zonal_partials_window_f64(const int32_t *zones_dev, int32_t zone_base, int window, const double *values_dev, int64_t n,
+                                  double nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
+                                  double *sumsq_dev, double *min_dev, double *max_dev, unsigned char *present_dev,
+                                  int32_t *overflow_dev, void *stream);
+/* n_samples cells at an odd stride through both rasters -> result24_dev = { int32 zmin, zmax; double mean of the valid
+ * values; uint64 number of valid values }: the id window to guess and a shift for the moments, from one tiny launch. */
+int xrs_zonal_sample_f32(const int32_t *zones_dev, const float *values_dev, int64_t n, int64_t n_samples, float nodata,
+                         int has_nodata, void *result24_dev, void *stream);
+int xrs_zonal_sample_f64(const int32_t *zones_dev, const double *values_dev, int64_t n, int64_t n_samples, double nodata,
+                         int has_nodata, void *result24_dev, void *stream);
 /* float64 values (the reference does not cast `values`: float64 and integer rasters keep
  * their precision; integers are widened to float64 by the host layer).  min/max are float64. */
 int xrs_zonal_init_f64(uint64_t *count_dev, double *sum_dev, double *sumsq_dev,

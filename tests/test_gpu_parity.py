@@ -763,6 +763,18 @@ def test_separable_box_walk(K):
     lake = got[5][500 + R:560 - R, 600 + R:700 - R]
     assert lake.size and (lake == 0).all()
     np.testing.assert_array_equal(got[0][500 + R:560 - R, 600 + R:700 - R], np.float32(1234.567))
+    # ---- a lake AT a tile's shift below high relief in the same tile: the running column sums keep a rounding residual of
+    # the relief they crossed (~2^-53 of its squares), which is all a window inside the lake then holds -- exact 0 is the
+    # contract there too (the guard knows each column's history), and gentle terrain below a cliff keeps its tolerance
+    z3 = np.full((rows, cols), 50.0, np.float32)
+    rng3 = np.random.default_rng(K)
+    z3[:110] = (50.0 + rng3.normal(0, 300.0, (110, cols))).astype(np.float32)
+    z3[400:] = (50.0 + rng3.normal(0, 0.5, (rows - 400, cols))).astype(np.float32)
+    got3, _ = run(z3, 1 | 16 | 32)
+    flat = slice(110 + R, 400 - R)
+    assert (got3[5][flat] == 0).all() and (got3[4][flat] == 0).all(), "a lake below relief: var / std must be exactly 0"
+    np.testing.assert_array_equal(got3[0][flat], np.float32(50.0))
+    check(got3, z3, 0, rows, "relief, lake at the shift, gentle terrain", tol=2e-6)
     # ---- the same masks through the public API (workspace from the pool), convolve_2d / hotspots' normalised box included
     pub = focal_stats(raster(z2), k, stats_funcs=['mean', 'std', 'var', 'sum'])
     for j, i in enumerate((0, 4, 5, 6)):
@@ -1225,6 +1237,55 @@ def test_zonal_device_resident_zone_indexing(zdtype):
         want = orc.zonal_stats(zf, vals, stats_funcs=['count'])
         np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'])
         np.testing.assert_array_equal(got['count'].to_numpy(), want['count'])
+
+
+@pytest.mark.parametrize("vdtype", [np.float32, np.float64])
+def test_zonal_one_pass_discovery(vdtype):
+    """zonal.stats on int32 zones without a discovery pass: the reduction guesses a window of ids from a strided sample and
+    finds the ids itself (xrs_zonal_partials_window_*).  Raw ids far from 0 with gaps, negative ids, a zone whose cells are
+    all NaN / nodata (listed with count 0 like np.unique does), zone_ids -- against the oracle, counts bit-exact; and the two
+    ways the guess fails -- ONE cell with an id the sample cannot have seen (overflow flag), ids spread wider than a window
+    -- must fall back to the two-pass route with the same answers."""
+    from xrspatial_amd import zonal as zmod
+    from xrspatial_amd._launch import get_stream
+    rng = np.random.default_rng(11)
+    rows, cols = 700, 900
+    stats = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    vals = (synth.asv_dem(rows, cols) + 40).astype(vdtype)
+    vals[rng.random(vals.shape) < 0.01] = np.nan
+    blocks = ((np.arange(rows)[:, None] // 37) * 31 + np.arange(cols)[None, :] // 53) % 400
+    for name, zones in (("ids 5000+, gaps", (5000 + 3 * blocks).astype(np.int32)),
+                        ("negative ids", (blocks - 250).astype(np.int32)),
+                        ("scattered", (7000 + rng.integers(0, 300, (rows, cols))).astype(np.int32))):
+        v = vals.copy()
+        dead = zones == zones[300, 450]
+        v[dead] = np.nan                                             # a zone without one valid cell
+        v[zones == zones[10, 10]] = -9999                            # ... and one that is all nodata
+        zd, vd = xs.DeviceArray.from_numpy(zones), xs.DeviceArray.from_numpy(v)
+        one = zmod._one_pass_partials(zd, vd, -9999)
+        assert one is not None, name
+        np.testing.assert_array_equal(one[0], np.unique(zones), err_msg=name)
+        for zone_ids in (None, [int(zones[0, 0]), int(zones[300, 450]), int(zones[-1, -1]), 123456]):
+            got = xs.zonal_stats(xs.DataArray(zd), xs.DataArray(vd), zone_ids=zone_ids, stats_funcs=stats, nodata_values=-9999)
+            want = orc.zonal_stats(zones, v, zone_ids=zone_ids, stats_funcs=stats, nodata_values=-9999)
+            np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'], err_msg=name)
+            for col in ('count', 'max', 'min'):
+                np.testing.assert_array_equal(got[col].to_numpy(), want[col], err_msg=f"{name} {col}")
+            for col in ('mean', 'sum', 'std', 'var'):
+                np.testing.assert_allclose(got[col].to_numpy(), want[col], rtol=RTOL, err_msg=f"{name} {col}")
+    # ---- the guess fails: one stray id / ids spread over 40 000 values
+    zones = (5000 + 3 * blocks).astype(np.int32)
+    stray = zones.copy()
+    stray[123, 457] = 2_000_000
+    wide = (zones * 100).astype(np.int32)
+    for name, zz in (("one stray id", stray), ("wide spread", wide)):
+        zd, vd = xs.DeviceArray.from_numpy(zz), xs.DeviceArray.from_numpy(vals)
+        assert zmod._one_pass_partials(zd, vd, None) is None, name
+        got = xs.zonal_stats(xs.DataArray(zd), xs.DataArray(vd), stats_funcs=stats)
+        want = orc.zonal_stats(zz, vals, stats_funcs=stats)
+        np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'], err_msg=name)
+        np.testing.assert_array_equal(got['count'].to_numpy(), want['count'], err_msg=name)
+        np.testing.assert_allclose(got['mean'].to_numpy(), want['mean'], rtol=RTOL, err_msg=name)
 
 
 @pytest.mark.parametrize("n_zones,vdtype", [(5000, np.float32), (12000, np.float32), (9000, np.float64)])

@@ -112,6 +112,12 @@ _PROTOTYPES = {
     "xrs_zonal_partials_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p],
     "xrs_zonal_scan": [c_void_p, c_int, c_int64, c_void_p, c_void_p],
+    "xrs_zonal_partials_window_f32": [c_void_p, c_int, c_int, c_void_p, c_int64, c_float, c_int, c_double, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrs_zonal_partials_window_f64": [c_void_p, c_int, c_int, c_void_p, c_int64, c_double, c_int, c_double, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrs_zonal_sample_f32": [c_void_p, c_void_p, c_int64, c_int64, c_float, c_int, c_void_p, c_void_p],
+    "xrs_zonal_sample_f64": [c_void_p, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_void_p],
     "xrs_zonal_scan_presence_i32": [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "xrs_zonal_presence": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p],
     "xrs_zonal_index": [c_void_p, c_int, c_int64, c_double, c_int64, c_void_p, c_void_p, c_void_p],

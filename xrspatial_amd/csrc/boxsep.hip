@@ -130,6 +130,7 @@ struct BoxWalk {
     double c0;
     float c0f;
     double C1[NC], C2[NC];        // (C2 unused -- and optimised away -- without the squares)
+    double q_peak[NC];            // the largest window sum of squares each output column has seen on this tile (guard)
     unsigned long long failm;     // lanes with a result the fast walk must not stand for (wave-uniform)
 
     __device__ __forceinline__ BoxWalk(const BoxArgs &a_, unsigned char *lds, long xs_, long xo, long y0_, long ye, int lane_)
@@ -276,7 +277,14 @@ struct BoxWalk {
             const double s0 = RING ? B1[o] : fma(n, c0, B1[o]);
             if (Q) {
                 const double e = fma(-sd, sd * inv, B2[o]);              // n * variance
-                bad |= !(e >= 0x1p-24 * B2[o]);                         // (a NaN / inf anywhere fails it too)
+                // The guard knows the column's HISTORY: the add / subtract recurrence of the column sums never re-seeds, so
+                // after the window has crossed high relief every column keeps a rounding residual of ~2^-53 of its past peak
+                // -- a lake at the tile's shift then has sd = 0 and e = B2 = that residual, which passes any test against
+                // the current window alone (round 4: var ~1e-12 and std ~1e-6 where exact 0 is the contract).  An output
+                // column's windows always hold the same columns, so the running maximum of its own B2 bounds what the
+                // residual can be: below 2^-26 of it (a few hundred residuals: 2^-22 relative on e) the tile is handed on.
+                q_peak[o] = fmax(q_peak[o], B2[o]);
+                bad |= !(e >= 0x1p-24 * B2[o]) || !(e >= 0x1p-26 * q_peak[o]);     // (a NaN / inf anywhere fails it too)
                 const double var = e * inv;
                 r_var[o] = (float)var;
                 r_std[o] = __builtin_amdgcn_sqrtf((float)var);               // (v_sqrt_f32: 1 ulp; sqrtf's fix-up costs 8 instructions per cell)
@@ -317,7 +325,7 @@ struct BoxWalk {
     __device__ __forceinline__ void init() {
         failm = 0;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) { C1[j] = 0.0; C2[j] = 0.0; }
+        for (int j = 0; j < NC; ++j) { C1[j] = 0.0; C2[j] = 0.0; q_peak[j] = 0.0; }
         // the shift: the cell at the tile centre (any finite value works; a near one keeps d small)
         const long yc = y0 + (y_end - y0) / 2;
         long xc = x_out0 + a.w_out / 2;

@@ -41,6 +41,9 @@ struct ZonalArgs {
     unsigned long long *count;
     double *sum, *sumsq;
     VT *mn, *mx;
+    // one-pass discovery (xrs_zonal_partials_window_*): `zidx` holds RAW ids, [zbase, zbase + nz) is a GUESSED window of them
+    unsigned char *present;       // present[id - zbase] = 1 for ids whose cells are all invalid (count stays 0; null: not wanted)
+    int *overflow;                // set to 1 when a cell's id lies outside the window (null: cells outside are just not selected)
 };
 
 template <typename VT> struct Bits;
@@ -143,6 +146,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
     } else {
         acc.c64 = a.count; acc.s = a.sum; acc.q = a.sumsq; acc.mn = a.mn; acc.mx = a.mx;
     }
+    // window mode: ids seen with only invalid values go straight to the global flags (plain stores of 1: NaN / nodata cells are
+    // the rare ones); a cell outside the window is remembered per lane and reported once at the end
+    bool outside = false;
+    auto in_window = [&](int z) { return (unsigned)z < (unsigned)a.nz; };
 
     const long n4 = VEC ? (a.n >> 2) : 0;
     const long stride = (long)gridDim.x * NT;
@@ -179,6 +186,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) z[4 * u + k] -= a.zbase;        // (negative / >= nz: outside the window)
                 }
+                if (a.overflow) {                                       // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) outside |= !in_window(z[4 * u + k]);
+                }
                 if constexpr (sizeof(VT) == 4) {
                     const float4 vf = ldg_stream(reinterpret_cast<const float4 *>(a.vals) + i);
                     v[4 * u] = vf.x; v[4 * u + 1] = vf.y; v[4 * u + 2] = vf.z; v[4 * u + 3] = vf.w;
@@ -213,6 +224,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
             p.mn = wave_reduce<WrMin>(p.mn);
             p.mx = wave_reduce<WrMax>(p.mx);
             if ((threadIdx.x & 63) == 0 && p.c) acc.add(p);
+            if (a.present && !p.c && (threadIdx.x & 63) == 0) a.present[z0] = 1;   // (p.c: the wave's total -- a trip without one valid cell)
             continue;
         }
         Part<VT> p;
@@ -230,7 +242,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
             for (int k = 0; k < 4; ++k) {
                 const int zk = z[4 * u + k];
                 const VT vk = v[4 * u + k];
-                if (!cell_ok(a, zk, vk)) continue;
+                if (!cell_ok(a, zk, vk)) {
+                    if (a.present && in_window(zk)) a.present[zk] = 1;
+                    continue;
+                }
                 const double d = (double)vk - a.shift;
                 if (p.z >= 0 && p.z != zk) {
                     Part<VT> one; one.z = zk; one.c = 1; one.s = d; one.q = d * d; one.mn = vk; one.mx = vk;
@@ -273,12 +288,16 @@ __global__ void __launch_bounds__(NT, NT == 1024 && sizeof(VT) == 4 && SLOTS == 
     for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += stride) {
         const int z = (a.lut ? zone_of(a, a.zidx[i]) : a.zidx[i]) - a.zbase;
         const VT v = a.vals[i];
+        if (a.overflow) outside |= !in_window(z);
         if (cell_ok(a, z, v)) {
             const double d = (double)v - a.shift;
             Part<VT> p; p.z = z; p.c = 1; p.s = d; p.q = d * d; p.mn = v; p.mx = v;
             acc.add(p);
+        } else if (a.present && in_window(z)) {
+            a.present[z] = 1;
         }
     }
+    if (a.overflow && outside) *a.overflow = 1;
 
     if (LDS) {
         __syncthreads();
@@ -322,7 +341,8 @@ int zonal_init(uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_
 template <typename VT>
 int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n, int n_zones, VT nodata,
                    int has_nodata, double shift, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev,
-                   VT *max_dev, void *stream, const int32_t *lut_dev = nullptr, int zmin = 0, int rng = 0) {
+                   VT *max_dev, void *stream, const int32_t *lut_dev = nullptr, int zmin = 0, int rng = 0, int window_base = 0,
+                   unsigned char *present_dev = nullptr, int *overflow_dev = nullptr) {
     if (n < 0 || n_zones < 0) return fail("xrs_zonal_partials: negative size");
     if (n == 0 || n_zones == 0) return 0;
     if (!zone_idx_dev || !values_dev || !count_dev || !sum_dev || !sumsq_dev || !min_dev || !max_dev)
@@ -334,17 +354,19 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     a.nodata = nodata; a.has_nodata = has_nodata; a.shift = shift;
     a.count = reinterpret_cast<unsigned long long *>(count_dev);
     a.sum = sum_dev; a.sumsq = sumsq_dev; a.mn = min_dev; a.mx = max_dev;
+    a.present = present_dev; a.overflow = overflow_dev;
     const size_t lds_cap = 144 * 1024;                           // of the CU's 160 KiB (one workgroup per CU beyond 64 KiB)
     const size_t per_zone = 16 + 2 * sizeof(VT) + 4;
     // More zones than LDS holds: several launches, each accumulating one window of zone indices in LDS (cells of other
     // windows are skipped).  A 5000-zone window streams the raster in ~1.5 ms; device atomics on the full table took
     // 21 ms for the same raster.
     const int window = (int)(lds_cap / per_zone);
+    if (overflow_dev && n_zones > window) return fail("xrs_zonal_partials_window: at most %d ids per window", window);
     const bool vec = aligned16(zone_idx_dev) && aligned16(values_dev);
     hipStream_t s = as_stream(stream);
     for (int base = 0; base < n_zones; base += window) {
         const int nzw = n_zones - base < window ? n_zones - base : window;
-        a.zbase = base; a.nz = nzw;
+        a.zbase = base + window_base; a.nz = nzw;
         a.count = reinterpret_cast<unsigned long long *>(count_dev) + base;
         a.sum = sum_dev + base; a.sumsq = sumsq_dev + base; a.mn = min_dev + base; a.mx = max_dev + base;
         const size_t smem = (size_t)nzw * per_zone;
@@ -395,9 +417,95 @@ int zonal_partials(const int32_t *zone_idx_dev, const VT *values_dev, int64_t n,
     return 0;
 }
 
+
+// ---- one-pass zone discovery: a strided sample of the rasters picks the id window and the shift of the moments
+struct SampleResult { int zmin, zmax; double value_mean; unsigned long long n_valid; };
+
+template <typename VT>
+__global__ void __launch_bounds__(1024) zonal_sample_kernel(const int32_t *zones, const VT *vals, long n, long n_samples, VT nodata,
+                                                            int has_nodata, SampleResult *out) {
+    __shared__ int s_min, s_max;
+    __shared__ double s_sum;
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) { s_min = 0x7fffffff; s_max = (int)0x80000000; s_sum = 0.0; s_cnt = 0u; }
+    __syncthreads();
+    // an odd stride (co-prime to the power-of-two row pitches zone blocks align with) and a start in the middle of it
+    const long stride = ((n / n_samples) | 1L) > 0 ? ((n / n_samples) | 1L) : 1L;
+    int zlo = 0x7fffffff, zhi = (int)0x80000000;
+    double sum = 0.0;
+    unsigned cnt = 0u;
+    for (long k = threadIdx.x; k < n_samples; k += 1024) {
+        const long i = (k * stride + stride / 2) % n;
+        const int z = zones[i];
+        zlo = z < zlo ? z : zlo; zhi = z > zhi ? z : zhi;
+        const VT v = vals[i];
+        if (isfinite(v) && !(has_nodata && v == nodata)) { sum += (double)v; ++cnt; }
+    }
+    zlo = wave_reduce<WrMin>(zlo); zhi = wave_reduce<WrMax>(zhi);
+    sum = wave_reduce<WrSum>(sum); cnt = wave_reduce<WrSum>(cnt);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_min, zlo); atomicMax(&s_max, zhi);
+        atomicAdd(&s_sum, sum); atomicAdd(&s_cnt, cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->zmin = s_min; out->zmax = s_max;
+        out->value_mean = s_cnt ? s_sum / (double)s_cnt : 0.0;
+        out->n_valid = s_cnt;
+    }
+}
+
+template <typename VT>
+int zonal_sample(const int32_t *zones_dev, const VT *values_dev, int64_t n, int64_t n_samples, VT nodata, int has_nodata,
+                 void *result24_dev, void *stream) {
+    if (n <= 0 || n_samples <= 0) return fail("xrs_zonal_sample: empty raster or sample");
+    if (!zones_dev || !values_dev || !result24_dev) return fail("xrs_zonal_sample: null pointer");
+    if (n_samples > n) n_samples = n;
+    hipLaunchKernelGGL(zonal_sample_kernel<VT>, dim3(1), dim3(1024), 0, as_stream(stream), zones_dev, values_dev, (long)n,
+                       (long)n_samples, nodata, has_nodata, static_cast<SampleResult *>(result24_dev));
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename VT>
+int zonal_window(const int32_t *zones_dev, int32_t zone_base, int window, const VT *values_dev, int64_t n, VT nodata,
+                 int has_nodata, double shift, uint64_t *count_dev, double *sum_dev, double *sumsq_dev, VT *min_dev, VT *max_dev,
+                 unsigned char *present_dev, int32_t *overflow_dev, void *stream) {
+    if (window <= 0) return fail("xrs_zonal_partials_window: empty window");
+    if (!present_dev || !overflow_dev) return fail("xrs_zonal_partials_window: null pointer");
+    if (int rc = zonal_init<VT>(count_dev, sum_dev, sumsq_dev, min_dev, max_dev, window, stream)) return rc;
+    XRS_HIP(hipMemsetAsync(present_dev, 0, (size_t)window, as_stream(stream)));
+    XRS_HIP(hipMemsetAsync(overflow_dev, 0, sizeof(int32_t), as_stream(stream)));
+    return zonal_partials<VT>(zones_dev, values_dev, n, window, nodata, has_nodata, shift, count_dev, sum_dev, sumsq_dev, min_dev,
+                              max_dev, stream, nullptr, 0, 0, zone_base, present_dev, overflow_dev);
+}
+
 }  // namespace
 
 extern "C" {
+
+int xrs_zonal_sample_f32(const int32_t *zones_dev, const float *values_dev, int64_t n, int64_t n_samples, float nodata,
+                         int has_nodata, void *result24_dev, void *stream) {
+    return zonal_sample<float>(zones_dev, values_dev, n, n_samples, nodata, has_nodata, result24_dev, stream);
+}
+int xrs_zonal_sample_f64(const int32_t *zones_dev, const double *values_dev, int64_t n, int64_t n_samples, double nodata,
+                         int has_nodata, void *result24_dev, void *stream) {
+    return zonal_sample<double>(zones_dev, values_dev, n, n_samples, nodata, has_nodata, result24_dev, stream);
+}
+int xrs_zonal_partials_window_f32(const int32_t *zones_dev, int32_t zone_base, int window, const float *values_dev, int64_t n,
+                                  float nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
+                                  double *sumsq_dev, float *min_dev, float *max_dev, unsigned char *present_dev,
+                                  int32_t *overflow_dev, void *stream) {
+    return zonal_window<float>(zones_dev, zone_base, window, values_dev, n, nodata, has_nodata, shift, count_dev, sum_dev,
+                               sumsq_dev, min_dev, max_dev, present_dev, overflow_dev, stream);
+}
+int xrs_zonal_partials_window_f64(const int32_t *zones_dev, int32_t zone_base, int window, const double *values_dev, int64_t n,
+                                  double nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
+                                  double *sumsq_dev, double *min_dev, double *max_dev, unsigned char *present_dev,
+                                  int32_t *overflow_dev, void *stream) {
+    return zonal_window<double>(zones_dev, zone_base, window, values_dev, n, nodata, has_nodata, shift, count_dev, sum_dev,
+                                sumsq_dev, min_dev, max_dev, present_dev, overflow_dev, stream);
+}
 
 int xrs_zonal_init(uint64_t *c, double *s, double *q, float *mn, float *mx, int nz, void *stream) {
     return zonal_init<float>(c, s, q, mn, mx, nz, stream);

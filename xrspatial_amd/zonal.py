@@ -99,6 +99,62 @@ def _zone_table_device(zones_dev: DeviceArray):
     return uniq, zmin, rng, DeviceArray.from_numpy(lut)
 
 
+_ONE_PASS_SAMPLES = 1 << 16          # cells of the strided sample that picks the id window and the shift
+_ONE_PASS_WINDOW_MAX = 4096          # ids per guessed window (29 B of LDS each)
+
+
+def _one_pass_partials(zones_dev: DeviceArray, vdev: DeviceArray, nodata_values):
+    """zonal partials of an int32 zone raster WITHOUT a discovery pass over it: a strided sample of the rasters (one tiny
+    launch, 24 bytes back) gives the range of ids to expect and the shift; the window [base, base + W) guessed around that
+    range is then reduced in ONE pass (xrs_zonal_partials_window_*: tables indexed by id - base in LDS), which also notes
+    ids that occur with invalid values only and whether any cell fell outside the window.  One more read of the tables
+    brings everything back.  Returns (unique ids, count, sum, sumsq, min, max, shift) with one entry per id that occurs --
+    the set np.unique(zones) of zonal.py:290 -- or None when the guess did not hold (ids wider spread than a window, or a
+    cell outside it): the caller then runs discovery and reduction as two passes."""
+    stream = get_stream()
+    n = int(zones_dev.size)
+    f64 = vdev.dtype == np.float64
+    sfx, vt = ("f64", np.float64) if f64 else ("f32", np.float32)
+    has_nodata = nodata_values is not None
+    nodata = float(nodata_values) if has_nodata else 0.0
+    res = DeviceArray((3,), np.float64)
+    _lib.call("xrs_zonal_sample_" + sfx, zones_dev.ptr, vdev.ptr, n, min(n, _ONE_PASS_SAMPLES), nodata, int(has_nodata), res.ptr,
+              stream)
+    raw = res.get(stream)
+    zmin, zmax = (int(v) for v in raw[:1].view(np.int32)[:2])
+    shift = float(np.rint(raw[1])) if int(raw[2:3].view(np.uint64)[0]) else 0.0     # (an integer, like _pick_shift's)
+    rng = zmax - zmin + 1
+    window = 256
+    while window < 2 * rng:
+        window *= 2
+    window = min(window, _ONE_PASS_WINDOW_MAX)
+    if rng + rng // 4 > window:
+        return None
+    base = max(zmin - (window - rng) // 2, -(1 << 31))
+    if base + window > (1 << 31):
+        base = (1 << 31) - window
+    # one buffer for everything that comes back: count u64 | sum f64 | sumsq f64 | min | max | present u8 | overflow i32
+    vsz = np.dtype(vt).itemsize
+    off_s1, off_s2 = 8 * window, 16 * window
+    off_mn = 24 * window
+    off_mx = off_mn + vsz * window
+    off_pr = off_mx + vsz * window
+    off_ov = (off_pr + window + 7) & ~7
+    buf = DeviceArray((off_ov + 8,), np.uint8)
+    p = buf.ptr
+    _lib.call("xrs_zonal_partials_window_" + sfx, zones_dev.ptr, base, window, vdev.ptr, n, nodata, int(has_nodata), shift,
+              p, p + off_s1, p + off_s2, p + off_mn, p + off_mx, p + off_pr, p + off_ov, stream)
+    host = buf.get(stream)
+    if int(host[off_ov:off_ov + 4].view(np.int32)[0]):
+        return None
+    count = host[:off_s1].view(np.uint64)
+    seen = (count > 0) | (host[off_pr:off_pr + window] > 0)
+    keep = np.flatnonzero(seen)
+    ids = (keep + base).astype(np.int32)
+    return (ids, count[keep], host[off_s1:off_s2].view(np.float64)[keep], host[off_s2:off_mn].view(np.float64)[keep],
+            host[off_mn:off_mx].view(vt)[keep], host[off_mx:off_pr].view(vt)[keep], shift)
+
+
 def _dense_zone_index_device(zones_dev: DeviceArray, max_range=None):
     """Device-side counterpart of `_dense_zone_index` for zone rasters already in HBM: returns
     (unique ids as a host array of the zones dtype, int32 DeviceArray of dense indices), or None when
@@ -353,6 +409,17 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
         _lib.require_device()
         if isinstance(zones_data, np.ndarray):
             zones_data = DeviceArray.from_numpy(np.ascontiguousarray(zones_data, dtype=np.int32))
+        _, vdev = _stage(zones_data, values_data)
+        one = _one_pass_partials(zones_data, vdev, nodata_values) if comm is None else None
+        if one is not None:
+            # the ids were found by the reduction itself (no discovery pass: 8 B per cell in all)
+            unique_zones, count, s1, s2, mn, mx, shift = one
+            cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None, shift)
+            keep = slice(None) if zone_ids is None else np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
+            frame = {'zone': unique_zones[keep]}
+            for name in stat_names:
+                frame[name] = cols[name][keep]
+            return pd.DataFrame(frame)
         tab = _zone_table_device(zones_data)
         if tab is not None:
             unique_zones, zmin, rng, lut_dev = tab

@@ -30,6 +30,7 @@ the dominant kernel (HIP-event time on the launch stream; HBM traffic from profi
 it was collected on the very build that is loaded), `cpu_baseline` = the CPU oracle timed on this box.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -56,6 +57,23 @@ SYM_FOCAL5 = "focal_mean_direct_kernel<5, 5, 4, 0u>"
 SYM_HILL = "terrain_strip_kernel<8, float, 4>"
 SYM_S64 = "raster_pass_kernel<9, 5, 5, 4, true, 4685252u>"
 SYM_ZONAL = "zonal_kernel<float, true, true, 1024, 2>"     # (1000 zones: 2 table slots per lane)
+
+
+@contextlib.contextmanager
+def c_stdout_to_stderr():
+    """RCCL prints its version banner (NCCL_DEBUG=VERSION, exported on these boxes) to the C stdout when a communicator comes
+    up: this benchmark's stdout is ONE JSON line, so file descriptor 1 points at stderr while a communicator is created."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class Ctx:
@@ -131,7 +149,8 @@ class Ctx:
         err = ""
         t0 = time.perf_counter()
         try:
-            self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
+            with c_stdout_to_stderr():
+                self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
             self.halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
         except Exception as exc:                      # noqa: BLE001
             err = repr(exc)[:300]
@@ -149,7 +168,8 @@ class Ctx:
                 if not os.environ.get("XRS_RDZV_FILE"):
                     os.environ.pop("XRS_RDZV_FILE", None)
                 try:
-                    self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
+                    with c_stdout_to_stderr():
+                        self.comm = Comm.from_env(timeout=float(os.environ.get("XRS_RDZV_TIMEOUT", "180")))
                     self.halo_via = f"RCCL send/recv over xGMI, {HALO} rows per neighbour per step"
                     err = ""
                 except Exception as exc:              # noqa: BLE001
@@ -858,8 +878,72 @@ def run_s64(ctx, steps=None, warmup=None, brief=False):
             "fused_pass_frac_of_measured_copy": round(16 * cells_total / (tf * 1e-3) / 1e9 / copy_gbs, 4),
             "fused_pass_frac_of_8TBs": round(16 * cells_total / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         })
+    if world == 1 and not args.no_extras and not args.unfused and total_rows % 8 == 0 and total_rows // 8 > 64:
+        # the step rank 3 of 8 would run: its 1/8 of the rows (a middle shard: both neighbours exist), the interior rows on the
+        # main stream while 2 x HALO rows go out and come in over RCCL on the comm stream, then both edges in one launch
+        from xrspatial_amd.distributed import Comm, OverlappedHalo
+        try:
+            with c_stdout_to_stderr():
+                comm1 = Comm(Comm.new_id(), 1, 0)
+            srows = total_rows // 8
+            sbase = 3 * srows
+            sptr = dem_ptr + sbase * cols * 4
+            scratch = xs.DeviceArray((2 * HALO, cols), np.float32)      # where the "neighbours' rows" land (the real halo rows stay)
+            ov = OverlappedHalo(srows, HALO, edge=16, main_stream=stream)
+
+            def xchg(cs):
+                L("xrs_comm_selftest_f32", comm1.handle, sptr, scratch.ptr, HALO * cols, cs)
+                L("xrs_comm_selftest_f32", comm1.handle, sptr + (srows - HALO) * cols * 4, scratch.ptr + HALO * cols * 4, HALO * cols, cs)
+
+            def rows_launch(first, n, top, bot):
+                off = (sbase + first) * cols * 4
+                L("xrs_raster_pass_f32", dem_ptr + off, o_slope.ptr + off, None, None, o_hill.ptr + off, o_focal.ptr + off,
+                  kernel.ctypes.data, 5, 5, None, n, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, stream)
+
+            def edges_launch(edge, top, bot):
+                off = sbase * cols * 4
+                L("xrs_raster_pass_edges_f32", dem_ptr + off, o_slope.ptr + off, None, None, o_hill.ptr + off, o_focal.ptr + off,
+                  kernel.ctypes.data, 5, 5, None, srows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, top, bot, edge, stream)
+
+            out["rehearsal_n8"] = rehearse_n8(
+                ctx, f"rank 3 of 8: rows {sbase}..{sbase + srows} of the resident raster; OverlappedHalo.step with the exchange as two "
+                     f"RCCL self send/recv of {HALO} x {cols} float32 on the comm stream, interior launch + one edges launch",
+                lambda: ov.step(xchg, rows_launch, HALO, HALO, launch_edges=edges_launch), elapsed / steps * 1e3,
+                2 * 2 * HALO * cols * 4)
+            out["rehearsal_n8"]["exchange_ms_last_step"] = round(ov.last_exchange_ms(), 4)
+            ov.close()
+            comm1.destroy()
+            del scratch
+        except Exception as exc:                     # noqa: BLE001 -- the rehearsal must not cost the run its line
+            out["rehearsal_n8"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     del o_hill, o_slope, o_focal, buf
     return out
+
+
+def rehearse_n8(ctx, what, shard_step, n1_ms, exchange_bytes):
+    """ONE-GPU rehearsal of the step a rank runs at N = 8 -- a PROJECTION, not a scaling measurement (no second GPU is in this
+    process: the halo / partial exchange goes through RCCL to this rank itself, on its own stream, in the shape the real step
+    sends).  shard_step(events) enqueues one such step; timed over 20 steps wall clock with the host loop (launches, event
+    records, stream waits) in it.  projected_speedup = the one-GPU step of the whole raster / the shard step: what 8 such
+    ranks reach if the xGMI exchange stays hidden behind the interior rows as it does here."""
+    L, stream = ctx.L, ctx.stream
+    for _ in range(3):
+        shard_step()
+    L("xrs_stream_sync", stream)
+    e0, e1 = ctx.event(), ctx.event()
+    t_host = time.perf_counter()
+    L("xrs_event_record", e0, stream)
+    for _ in range(20):
+        shard_step()
+    L("xrs_event_record", e1, stream)
+    host_us = (time.perf_counter() - t_host) / 20 * 1e6          # the Python / ctypes / HIP launch path of one step, not waiting
+    L("xrs_stream_sync", stream)
+    L("xrs_device_sync")
+    shard_ms = ctx.elapsed_ms(e0, e1) / 20
+    return {"what": what, "shard_ms": round(shard_ms, 4), "n1_ms": round(n1_ms, 4),
+            "projected_speedup_at_8": round(n1_ms / shard_ms, 3), "host_us_per_step": round(host_us, 1),
+            "exchange_bytes_per_step": int(exchange_bytes),
+            "note": "projection from one GPU: rank-shaped work + RCCL self send/recv; not a measured scaling curve"}
 
 
 # =====================================================================================================
@@ -974,6 +1058,26 @@ def run_zonal32k(ctx, steps=None, warmup=None, brief=False):
                       "api_mcells_s_7stats": round(cells_total / (api7 * 1e-3) / 1e6, 1),
                       "zones_and_counts_equal_exact_host_counts": api_ok}
         del zraw, za, va
+    if world == 1 and not args.no_extras and rows % 8 == 0:
+        from xrspatial_amd.distributed import Comm
+        try:
+            with c_stdout_to_stderr():
+                comm1 = Comm(Comm.new_id(), 1, 0)
+            srows = rows // 8
+            off = 3 * srows * cols * 4
+
+            def shard_step():
+                L("xrs_zonal_init", zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, nz, stream)
+                L("xrs_zonal_partials_f32", zones.ptr + off, vals.ptr + off, srows * cols, nz, 0.0, 0, 0.0, zc.ptr, zs.ptr, zq.ptr,
+                  zmn.ptr, zmx.ptr, stream)
+                L("xrs_zonal_allreduce", comm1.handle, zc.ptr, zs.ptr, zq.ptr, zmn.ptr, zmx.ptr, 0, nz, stream)
+
+            out["rehearsal_n8"] = rehearse_n8(
+                ctx, f"rank 3 of 8: {srows} rows, reset + partial sums + the five all-reduces of {nz} entries through a 1-rank RCCL "
+                     "communicator on the launch stream", shard_step, elapsed / steps * 1e3, nz * (8 + 8 + 8 + 4 + 4))
+            comm1.destroy()
+        except Exception as exc:                     # noqa: BLE001
+            out["rehearsal_n8"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if args.zonal_size == 32768:
         out["traffic_rank0"], out["traffic_from"] = traffic_for(ctx, SYM_ZONAL, rows, cols, None)
         if world > 1:
@@ -1104,7 +1208,21 @@ def run_dry_rccl(ctx):
         return None
     expect = world * (world + 1) / 2
     ok = bad_total == 0 and total == expect and (counts is None or (counts["u64_sum"] == [int(expect), world] and counts["u8_max"][1] == 1))
+    # how many logical devices this process sees (a lease with > 1 could run the sharded tests over real RCCL) and how the
+    # GPU is partitioned
+    ndev = ctypes.c_int(0)
+    try:
+        ctx._lib.load().xrs_device_count(ctypes.byref(ndev))
+    except Exception:                                # noqa: BLE001 -- (the CPU test double of the library has no devices to count)
+        ndev.value = -1
+    partition = None
+    try:
+        import subprocess
+        partition = subprocess.run(["rocm-smi", "--showcomputepartition"], capture_output=True, text=True, timeout=20).stdout.strip()[-400:]
+    except Exception as exc:                         # noqa: BLE001
+        partition = f"rocm-smi unavailable: {type(exc).__name__}"
     return {"dry_rccl": True, "ok": bool(ok), "n_gpus": world, "transport": ctx.halo_via, "rccl": info,
+            "visible_devices": int(ndev.value), "compute_partition": partition,
             "rendezvous_and_comm_init_s": None if ctx.connect_s is None else round(ctx.connect_s, 3),
             "halo_exchange": {"rows_per_neighbour": HALO, "cols": cols, "cells_wrong_all_ranks": int(bad_total),
                               "first_call_s": round(exchange_s, 4)},

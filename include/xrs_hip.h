@@ -135,9 +135,12 @@ int xrs_raster_pass_f32(const float *in_dev, float *slope_dev, float *aspect_dev
  * arrived: the rows in between were launched earlier, while the exchange was in flight -- what a dask graph does with
  * map_overlap(depth, boundary=nan), slope.py:86-97, the scheduler does here with two streams).  ONE launch over two
  * segments of tile rows when the fused kernel takes the request (3x3 / 5x5 masks: results are those of xrs_raster_pass_f32
- * on the whole raster, bit for bit), the two sub-range calls otherwise (what any row split of that request gives).  Rows
- * between the edges are not written, except up to 15 rows
- * above the last edge, which receive the values the whole-raster pass gives them.  2 * edge_rows >= rows: the whole raster. */
+ * on the whole raster, bit for bit), the two sub-range calls otherwise (what any row split of that request gives).  The
+ * one-launch form works in whole tile rows of 16 raster rows: besides the edges it also writes up to 15 rows BELOW the first
+ * edge (rows [edge_rows, 16 * ceil(edge_rows / 16))) and up to 15 rows ABOVE the last one, with the values the whole-raster
+ * pass gives them -- harmless on the stream that also runs the launch for the rows in between (same values), a write-write
+ * race if that launch runs on another stream: keep both on one stream, or pass edge_rows % 16 == 0.  No other row between the
+ * edges is written.  2 * edge_rows >= rows: the whole raster. */
 int xrs_raster_pass_edges_f32(const float *in_dev, float *slope_dev, float *aspect_dev, float *curvature_dev,
                               float *hillshade_dev, float *focal_mean_dev, const double *kernel, int krows,
                               int kcols, void *work_dev, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
@@ -218,7 +221,9 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
  * (xrs_kxk_workspace_bytes) plus one byte per tile for the separable box kernel -- np.ones((k, k)) masks, the ones the
  * reference's benchmark suite runs, get their variance / standard deviation (and the mean and sum beside them) from an
  * O(1)-per-cell walk that hands the tiles it cannot stand for (NaN / inf cells, flat windows) to the general kernel
- * through that map.  With a smaller workspace (or none) the general kernel runs everywhere: same results, more time. */
+ * through that map.  With a smaller workspace (or none) the general kernel runs everywhere: more time, and results that agree
+ * with the separable walk's within the documented tolerance (float32 walker vs float64 column sums: ~2e-6 relative on var / std),
+ * not bit for bit. */
 size_t xrs_focal_workspace_bytes(int64_t rows, int64_t cols, int krows, int kcols);
 
 /* focal.apply with a user callable (func other than the built-in reducers): the kernel-shaped float32 arrays that

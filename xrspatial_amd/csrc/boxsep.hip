@@ -34,6 +34,7 @@
 // cells outside contribute d = 0; plain predicated loads of the entering and the leaving row, no ring).
 #include "circle_walk.h"
 #include "lds_dma.h"
+#include "wave_reduce.h"
 
 using namespace xrs;
 
@@ -79,39 +80,6 @@ struct BoxGeo {
 // rows in flight by LDS-DMA (pairs of rows: one DMA instruction each).  The ring is what limits residency: with the
 // squares' two extra prefix arrays 4 rows ahead keep two workgroups on a CU at 25x25, without them 8 do
 constexpr int box_ahead(bool with_squares) { return with_squares ? XRS_BOX_D : 2 * XRS_BOX_D; }
-
-// ---- wave-wide inclusive scan of one float64 per lane: Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8 with
-// bound_ctrl: a lane without a source reads 0), then the row totals across (row_bcast 15 into rows 1 and 3, row_bcast 31
-// into rows 2 and 3; the rows that are not written keep 0).  N independent values at once, step by step: one scan is a chain
-// of 6 dependent (2 DPP moves + 1 float64 add), and the compiler keeps chains in source order -- interleaved here, the N
-// chains hide one another's latency.
-template <int CTRL>
-__device__ __forceinline__ double dpp_shr_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_bcast_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int N>
-__device__ __forceinline__ void wave_scan_f64(double (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x111>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x112>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x114>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_shr_f64<0x118>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_bcast_f64<0x142, 0xa>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_bcast_f64<0x143, 0xc>(v[i]);
-}
 
 // RING = true: a full tile whose whole input window lies inside the raster: rows arrive in the wave's LDS ring by LDS-DMA
 // and are read from it twice (entering, leaving); RING = false: tiles at the raster / shard edge and the last tile column:

@@ -13,7 +13,7 @@
 
 #include <cmath>
 #include <cstdlib>
-#include <rocprim/warp/warp_reduce.hpp>
+#include "wave_reduce.h"
 #include <type_traits>
 
 namespace xrs {
@@ -420,17 +420,14 @@ __device__ __forceinline__ void walk_exact_window(const WalkGeom &g, long yo, lo
         const bool ok = idx < NT && dx <= Shape::hw(R, dy) && dx > Shape::hwi(R, dy) && yr >= y_lo && yr < y_hi && xr >= 0 && xr < g.cols;
         return ok ? g.in[yr * g.ld_in + xr] : nan_f32();
     };
-    rocprim::warp_reduce<double, 64>::storage_type st;
     double s = 0.0, m = 0.0;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const float v = tap(i);
         if (!isnan(v)) { s += (double)v; m += 1.0; }
     }
-    rocprim::warp_reduce<double, 64>().reduce(s, s, st);
-    rocprim::warp_reduce<double, 64>().reduce(m, m, st);
-    s = __shfl(s, 0);
-    m = __shfl(m, 0);
+    s = wave_reduce<WrSum>(s);                             // (wave_reduce.h: DPP, wave-uniform results)
+    m = wave_reduce<WrSum>(m);
     mean = m > 0.0 ? s / m : nan("");                      // true division: a flat window must give its value exactly
     double dev = 0.0;
 #pragma unroll
@@ -438,8 +435,7 @@ __device__ __forceinline__ void walk_exact_window(const WalkGeom &g, long yo, lo
         const float v = tap(i);
         if (!isnan(v)) { const double d = (double)v - mean; dev = fma(d, d, dev); }
     }
-    rocprim::warp_reduce<double, 64>().reduce(dev, dev, st);
-    dev = __shfl(dev, 0);
+    dev = wave_reduce<WrSum>(dev);
     var = m > 0.0 ? dev / m : nan("");
 }
 

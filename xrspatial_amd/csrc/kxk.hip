@@ -1091,16 +1091,8 @@ int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_
     a.weights = static_cast<const double *>(work_dev);
     if (krows >= 7 && !ab_env("XRS_CONV_TAPS")) {
         // one weight value on a circle / box (normalised circle_kernel, np.ones / k^2): the wide row walker (wide_impl.h,
-        // float32 on shifted values, guarded).  (`make AB=1` + XRS_CONV_GEN=1: round 1's float64 column walker.)
+        // float32 on shifted values, guarded).  (Round 1's float64 column walker: experiments/superseded/.)
         int rc = -1;
-#ifdef XRS_AB
-        const char *gen = ab_env("XRS_CONV_GEN");
-        if (gen && gen[0] == '1') {
-            rc = try_launch_conv_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
-            if (rc < 0) rc = try_launch_conv_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
-            if (rc >= 0) return rc;
-        }
-#endif
         rc = try_launch_conv_wide_circle(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
         if (rc < 0)
             rc = try_launch_conv_wide_box(in_dev, out_dev, rows, cols, ld_in, ld_out, kernel, a.weights, krows, kcols, halo_top, halo_bot, s);
@@ -1166,8 +1158,8 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
     // Large circles / boxes: the float32 walkers of wide_impl.h / ext_impl.h / mom_impl.h.  XRS_FOCAL_EXACT_MOMENTS keeps
     // the float64 column walkers (mean / var / std within ~1 ulp of the reference's float64 accumulators, ~2x the time);
     // XRS_FOCAL_SEQUENTIAL_SUM keeps `sum` on the kernel that adds the taps in the reference's order in float32 (bit-exact
-    // with numba's nansum) instead of rounding the exact sum once.  (`make AB=1`: XRS_FOCAL_GEN=1 / 2 select the first /
-    // second generation for A/B runs.)
+    // with numba's nansum) instead of rounding the exact sum once.  (`make AB=1`: XRS_FOCAL_GEN=1 selects the first generation
+    // for A/B runs; the second lives in experiments/superseded/.)
     if (flags & ~(unsigned)(XRS_FOCAL_EXACT_MOMENTS | XRS_FOCAL_SEQUENTIAL_SUM)) return fail("xrs_focal_stats_f32_ex: unknown flag bits 0x%x", flags);
     const char *gen = ab_env("XRS_FOCAL_GEN");
     const bool gen1 = (flags & XRS_FOCAL_EXACT_MOMENTS) || (gen && gen[0] == '1');
@@ -1193,12 +1185,10 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
     if (!gen1 && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
         // several statistics on a circle / box: the extrema walker (ext_impl.h: max / min / range) and the moments walker
         // (mom_impl.h: mean / var / std / sum), each one pass; a sequential `sum` comes from its own kernel.
-        // XRS_FOCAL_GEN=2: round 2's one-pass float64 column walker (walk2_impl.h) for A/B runs.
         float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
         const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
         const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
-        const bool gen2 = gen && gen[0] == '2';
-        if (!gen2) {
+        {
             hipStream_t s_mm = s;          // (the two launches on two streams, forked / joined by events, measured no faster than back to back:
                                            //  2.39 vs 2.43 ms in round 3; 2.14 - 2.23 vs 2.19 in round 4, also with the extrema kernel at 2 waves per SIMD:
                                            //  profiles/r04/ab_two_streams.log)
@@ -1238,38 +1228,6 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
             // (rc < 0: neither a circle nor a box of radius 4..12 -- the kernels below)
         }
     }
-#ifdef XRS_AB
-    if (gen && gen[0] == '2' && krows == kcols && krows >= 9 && (stat_mask & ~(m_mean | m_sum))) {
-        float *o_sum = seq_sum ? nullptr : a.out[XRS_STAT_SUM];
-        const bool want_mm = a.out[XRS_STAT_MAX] || a.out[XRS_STAT_MIN] || a.out[XRS_STAT_RANGE];
-        const bool want_mom = o_sum || a.out[XRS_STAT_MEAN] || a.out[XRS_STAT_VAR] || a.out[XRS_STAT_STD];
-        typedef int (*Walk2Fn)(const float *, float *, float *, float *, float *, float *, float *, float *, long, long, long,
-                               long, const double *, int, int, int, int, hipStream_t);
-        const Walk2Fn circle = want_mm && want_mom ? try_launch_focal_circle2
-                               : want_mm ? try_launch_focal_circle2_mm : try_launch_focal_circle2_mom;
-        const Walk2Fn box = want_mm && want_mom ? try_launch_focal_box2 : want_mm ? try_launch_focal_box2_mm : try_launch_focal_box2_mom;
-        int rc = 0;
-        if (want_mm || want_mom) {
-            rc = circle(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN],
-                        a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
-                        halo_bot, s);
-            if (rc < 0)
-                rc = box(in_dev, o_sum, a.out[XRS_STAT_MAX], a.out[XRS_STAT_MIN], a.out[XRS_STAT_RANGE], a.out[XRS_STAT_MEAN],
-                         a.out[XRS_STAT_VAR], a.out[XRS_STAT_STD], rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
-                         halo_bot, s);
-        }
-        if (rc > 0) return rc;
-        if (rc == 0) {
-            if (!(seq_sum && a.out[XRS_STAT_SUM])) return 0;
-            float *only_sum[XRS_NUM_STATS] = {nullptr};
-            only_sum[XRS_STAT_SUM] = a.out[XRS_STAT_SUM];
-            const int rc2 = try_walk_f32(in_dev, only_sum, false, rows, cols, ld_in, ld_out, kernel, krows, kcols, halo_top,
-                                         halo_bot, s);
-            if (rc2 >= 0) return rc2;
-            return fail("xrs_focal_stats_f32: no sequential-sum kernel for this mask");
-        }
-    }
-#endif
     if (stat_mask == (1u << XRS_STAT_MEAN) && krows * kcols >= 49 && !ab_env("XRS_FOCAL_MEAN_RUNS")) {
         // circles and boxes, 7x7 .. 25x25: column walker (running float64 sums over centred runs)
         const int rc = try_walk_f64(in_dev, a.out[XRS_STAT_MEAN], nullptr, nullptr, rows, cols, ld_in, ld_out, kernel,

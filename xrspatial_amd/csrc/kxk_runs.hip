@@ -19,7 +19,7 @@
 
 #include <cmath>
 
-#include <rocprim/warp/warp_scan.hpp>
+#include "wave_reduce.h"
 
 using namespace xrs;
 
@@ -102,12 +102,10 @@ __global__ void __launch_bounds__(1024, 8) focal_mean_runs_kernel(const RunArgs 
             }
             const double l1 = m[0] + m[1], l2 = l1 + m[2];
             const int c1 = cn[0] + cn[1], c2 = c1 + cn[2];
-            double tot;                                                // inclusive wave64 scans of the lane totals
-            int ctot;                                                  // (DPP cross-lane moves: no LDS traffic)
-            rocprim::warp_scan<double, 64>::storage_type st_d;
-            rocprim::warp_scan<int, 64>::storage_type st_i;
-            rocprim::warp_scan<double, 64>().inclusive_scan(l2, tot, st_d);
-            rocprim::warp_scan<int, 64>().inclusive_scan(c2, ctot, st_i);
+            double sc[1] = {l2};                                       // inclusive wave64 scans of the lane totals
+            wave_scan_f64<1>(sc);                                      // (wave_reduce.h: DPP cross-lane moves, no LDS traffic)
+            const double tot = sc[0];
+            const int ctot = wave_scan_i32(c2);
             const double base = tot - l2;                              // exclusive prefix of this lane
             const int cbase = ctot - c2;
             double *prow = P + (size_t)r * a.pp;
@@ -247,13 +245,10 @@ __global__ void __launch_bounds__(1024, 4) focal_meanvar_runs_kernel(const RunAr
             const double l1 = m[0] + m[1], l2 = l1 + m[2];
             const double q1 = q[0] + q[1], q2 = q1 + q[2];
             const int c1 = cn[0] + cn[1], c2 = c1 + cn[2];
-            double tot, qtot;
-            int ctot;
-            rocprim::warp_scan<double, 64>::storage_type st_d;
-            rocprim::warp_scan<int, 64>::storage_type st_i;
-            rocprim::warp_scan<double, 64>().inclusive_scan(l2, tot, st_d);
-            rocprim::warp_scan<double, 64>().inclusive_scan(q2, qtot, st_d);
-            rocprim::warp_scan<int, 64>().inclusive_scan(c2, ctot, st_i);
+            double sc[2] = {l2, q2};
+            wave_scan_f64<2>(sc);
+            const double tot = sc[0], qtot = sc[1];
+            const int ctot = wave_scan_i32(c2);
             const double base = tot - l2, qbase = qtot - q2;
             const int cbase = ctot - c2;
             double *prow = P + (size_t)r * a.pp, *qrow = P2 + (size_t)r * a.pp;

@@ -5,7 +5,7 @@
 #include "circle_walk.h"
 #include "lds_dma.h"
 
-#include <rocprim/warp/warp_reduce.hpp>
+#include "wave_reduce.h"
 
 #include <utility>
 
@@ -288,12 +288,9 @@ struct MomWalkN {
         const bool own = snapN >= 16.0f;
         float est = c + (snapN > 0.0f ? snapS / snapN : 0.0f);
         {
-            rocprim::warp_reduce<float, 64>::storage_type st;
             float se = own ? est : 0.0f, sn = own ? 1.0f : 0.0f;
-            rocprim::warp_reduce<float, 64>().reduce(se, se, st);
-            rocprim::warp_reduce<float, 64>().reduce(sn, sn, st);
-            se = __shfl(se, 0);
-            sn = __shfl(sn, 0);
+            se = wave_reduce<WrSum>(se);                       // (wave_reduce.h: DPP, wave-uniform results)
+            sn = wave_reduce<WrSum>(sn);
             if (!own) est = sn > 0.0f ? se / sn : est;
         }
         float d = est - c;
@@ -337,14 +334,8 @@ struct MomWalkN {
             // rounding of a window's S: <= ~K (2 K^2 + K) u A in its rows' prefix sums and their differences + K ntaps u A in
             // the ring, per valid cell no more than that over n -- (a few 10^4 u) A / ntaps for the mean, x 2 for the lanes'
             // different, moving shifts; accepted up to 0.9e-5 of the smallest |mean| (wide_impl.h's bound and contract)
-            rocprim::warp_reduce<float, 64>::storage_type st;
-            float A, lo, hi, M;
-            rocprim::warp_reduce<float, 64>().reduce(a_max, A, st, rocprim::maximum<float>());
-            rocprim::warp_reduce<float, 64>().reduce(c_hi, hi, st, rocprim::maximum<float>());
-            rocprim::warp_reduce<float, 64>().reduce(c_lo, lo, st, rocprim::minimum<float>());
-            rocprim::warp_reduce<float, 64>().reduce(m_min, M, st, rocprim::minimum<float>());
-            A = __shfl(A, 0) + (__shfl(hi, 0) - __shfl(lo, 0));
-            M = __shfl(M, 0);
+            const float A = wave_reduce<WrMax>(a_max) + (wave_reduce<WrMax>(c_hi) - wave_reduce<WrMin>(c_lo));
+            const float M = wave_reduce<WrMin>(m_min);
             constexpr float COEF = 2.0f * 5.9604645e-8f * (float)(K * (2 * K * K + K) + K * C::NTAPS) / (float)C::NTAPS;
             if (!(COEF * A <= 0.9e-5f * M)) return false;
         }

@@ -1,6 +1,6 @@
 // Runtime entry points: devices, memory, streams, events.  (include/xrs_hip.h "runtime")
 #include "xrs_common.h"
-#include "_build/build_id.h"
+#include "build_id.h"                // generated into the build directory of the flavour being built (Makefile: -I$(BUILD))
 
 using namespace xrs;
 

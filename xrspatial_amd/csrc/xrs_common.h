@@ -67,7 +67,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // pattern of the 3x3 kernels; groups of 2 / 4 / 8+ tile rows: 0.332 / 0.340 / 0.35).  unit = 1: launch order.
 // Returns -1 for the surplus blocks of the padded grid.
 // unit = 0: the round-1 order, one contiguous band of tiles per XCD -- kept for the column walkers (circle_walk.h,
-// walk2_impl.h, wide_impl.h: tall tiles, 100+ rows each; same-box A/B 3-6 % faster in bands) and, unmeasured, the
+// wide_impl.h: tall tiles, 100+ rows each; same-box A/B 3-6 % faster in bands) and, unmeasured, the
 // LDS-tile kernels.
 __device__ __forceinline__ long xcd_tile(long block, long n_tiles, long unit) {
     if (unit == 0) {
@@ -239,11 +239,6 @@ int try_launch_focal_box_f32(const float *in, float *out_sum, float *out_max, fl
                              float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in,
                              long ld_out, const double *kernel, int krows, int kcols, int halo_top, int halo_bot,
                              hipStream_t s);      // kxk_box.hip: the same for np.ones((k, k)) masks
-// kxk_circle_conv.hip / kxk_box_conv.hip: convolve_2d with one weight value on a circle / box of radius 3..12 cells
-int try_launch_conv_circle(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
-                           const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-int try_launch_conv_box(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
-                        const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 // kxk_circle64.hip / kxk_box64.hip: mean / var / std for the same shapes (float64 moments of shifted values, guarded).
 int try_launch_focal_box_f64(const float *in, float *out_mean, float *out_var, float *out_std, long rows, long cols,
                              long ld_in, long ld_out, const double *kernel, int krows, int kcols, int halo_top,
@@ -265,28 +260,6 @@ int try_launch_conv_wide_circle(const float *in, float *out, long rows, long col
                                 const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
 int try_launch_conv_wide_box(const float *in, float *out, long rows, long cols, long ld_in, long ld_out, const double *kernel,
                              const double *weights_dev, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-// kxk_circle2.hip / kxk_box2.hip: all seven statistics in one pass, radius 4..12 cells (walk2_impl.h).
-int try_launch_focal_circle2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-int try_launch_focal_box2(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-// kxk_*2_mm.hip / kxk_*2_mom.hip: the same walker with only the extrema pass (max / min / range) or only the moments pass
-// (mean / var / std / sum); the other outputs must be NULL
-int try_launch_focal_circle2_mm(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-int try_launch_focal_box2_mm(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-int try_launch_focal_circle2_mom(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                             float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                             const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-int try_launch_focal_box2_mom(const float *in, float *out_sum, float *out_max, float *out_min, float *out_range,
-                          float *out_mean, float *out_var, float *out_std, long rows, long cols, long ld_in, long ld_out,
-                          const double *kernel, int krows, int kcols, int halo_top, int halo_bot, hipStream_t s);
-
 // kxk_big.hip: focal statistics / convolve_2d for windows beyond the tiled kernels' 63 x 63 (one thread per cell, window from
 // global memory, mask / weights from a device copy of the kernel in `work_dev`)
 int launch_window_any_size(bool conv, const float *in, float *const *outs, long rows, long cols, long ld_in, long ld_out,

@@ -25,15 +25,16 @@ _STAT_INDEX = {'mean': 0, 'max': 1, 'min': 2, 'range': 3, 'std': 4, 'var': 5, 's
 # (a per-output guard sends ill-conditioned tiles to the exact kernels).  Set
 #   options['moments'] = 'exact'      (or XRS_FOCAL_MOMENTS=exact)      float64 running sums for mean / var / std: ~1 ulp;
 #   options['sum'] = 'sequential'     (or XRS_FOCAL_SUM=sequential)     `sum` bit-identical to numba's float32 nansum
-# to keep whole launches on the exact kernels (about 2x the time).
-options = {'moments': 'fast', 'sum': 'rounded'}
+# to keep whole launches on the exact kernels (about 2x the time).  A value set in `options` wins over the environment;
+# None (the initial state) = the environment variable if set, else 'fast' / 'rounded'.
+options = {'moments': None, 'sum': None}
 _FLAG_EXACT_MOMENTS, _FLAG_SEQUENTIAL_SUM = 1, 2
 
 
 def _focal_flags():
     import os
-    moments = os.environ.get('XRS_FOCAL_MOMENTS', options['moments'])
-    sums = os.environ.get('XRS_FOCAL_SUM', options['sum'])
+    moments = options.get('moments') or os.environ.get('XRS_FOCAL_MOMENTS') or 'fast'
+    sums = options.get('sum') or os.environ.get('XRS_FOCAL_SUM') or 'rounded'
     if moments not in ('fast', 'exact'):
         raise ValueError(f"focal moments option must be 'fast' or 'exact', got {moments!r}")
     if sums not in ('rounded', 'sequential'):
@@ -111,10 +112,12 @@ def _focal_stats_banded(host, kernel, stats):
         ptrs = (ctypes.c_void_p * 7)()
         for s, ptr in zip(stats, out_ptrs):
             ptrs[_STAT_INDEX[s]] = ptr
+        # one workspace per band launch (the bands run on several streams: no shared tile map) -- np.ones boxes then take the
+        # separable walk here as they do for device-resident rasters, so both backends give the same var / std; the block goes
+        # back to the pool behind the launch, fenced on `stream` (device.py)
+        work = _window_workspace(k, n_rows, cols)
         _stats_call(in_ptr, ptrs, mask, n_rows, cols, cols, cols, k, work, ht, hb, stream)
 
-    work = None if max(k.shape) <= 63 else _window_workspace(k)      # (alive until pipelined_rows has drained its streams;
-                                                                      #  the bands run on several streams: no shared tile map)
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
 
 

@@ -506,7 +506,16 @@ def _stats_sharded(zones, values, zone_ids, stat_names, nodata_values, return_ty
         lo, neg_hi = (float(v) for v in comm.allreduce(np.array([lo, -hi]), 'min'))      # one small all-reduce
         hi = -neg_hi
     if not np.isfinite(lo):                                   # no rank holds a zone cell
-        return pd.DataFrame({'zone': np.empty(0, np.int32), **{name: np.empty(0) for name in stat_names}})
+        if return_type == 'pandas.DataFrame':
+            return pd.DataFrame({'zone': np.empty(0, np.int32), **{name: np.empty(0) for name in stat_names}})
+        # back-projection of an empty table: every plane is NaN everywhere, sharded like the input
+        planes = [values.like(np.float64) for _ in stat_names]
+        blank = np.full(zloc.shape, np.nan)
+        for plane in planes:
+            if blank.size:
+                _lib.call("xrs_memcpy_h2d", plane.ptr, blank.ctypes.data, blank.nbytes, stream)
+        _lib.call("xrs_stream_sync", stream)
+        return ShardedStack(planes)
     rng = int(hi - lo) + 1
     if rng > _SHARDED_RANGE_LIMIT:
         raise NotImplementedError(f"zone ids span {rng} values; sharded zonal.stats handles up to {_SHARDED_RANGE_LIMIT}")

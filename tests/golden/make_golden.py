@@ -115,6 +115,10 @@ WANTED = [
     ("test_zonal.py", "result_custom_stats", (), "zonal_custom"),
     ("test_zonal.py", "result_custom_stats_dataarray", (), "zonal_custom_da"),
     ("test_zonal.py", "qgis_zonal_stats", (), "zonal_qgis"),
+    ("test_zonal.py", "result_count_crosstab_2d", (), "crosstab_2d_count"),
+    ("test_zonal.py", "result_percentage_crosstab_2d", (), "crosstab_2d_percentage"),
+    ("test_zonal.py", "result_crosstab_3d", (), "crosstab_3d"),
+    ("test_zonal.py", "result_nodata_values_crosstab_3d", (), "crosstab_3d_nodata"),
 ]
 
 
@@ -122,8 +126,11 @@ def _store(prefix, value, arrays, tables):
     """Flatten a fixture's return value into npz arrays / json tables."""
     if isinstance(value, np.ndarray):
         arrays[prefix] = value
+    elif isinstance(value, dict) and all(isinstance(v, dict) for v in value.values()):
+        for k, v in value.items():                       # (a table per aggregation: result_crosstab_3d)
+            _store(f"{prefix}__{k}", v, arrays, tables)
     elif isinstance(value, dict):
-        tables[prefix] = {k: [float(x) for x in v] for k, v in value.items()}
+        tables[prefix] = {str(k): [float(x) for x in v] for k, v in value.items()}
     elif isinstance(value, (tuple, list)) and not all(
             isinstance(x, (int, float)) for x in value):
         for i, item in enumerate(value):

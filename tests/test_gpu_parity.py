@@ -2082,6 +2082,28 @@ def test_geodesic_closed_form(backend):
             parity_log.record("f3 geodesic: closed-form surfaces on WGS84 (analytic pin)", "slope", got_s, slope, tol="rtol 2e-3 (float32 elevations at 1 arc-second)")
 
 
+def test_geodesic_against_independent_40_digit_fit():
+    """The HIP geodesic kernels (float64 arithmetic, float32 out) on curved surfaces against the independent 40-digit
+    evaluation of the 3x3 fit (tests/test_oracle_golden.py::_geodesic_fit_mp: ECEF, ENU, curvature-correction term and the
+    plane fit each contribute) -- float64 elevations in, 2-D lat / lon coordinates, centre cell of every patch."""
+    from tests.test_oracle_golden import _curved_geodesic_case, _geodesic_fit_mp
+    for lat0 in (0.0, 37.0, -58.0, 75.0):
+        for cell_deg in (1.0 / 3600.0, 30.0 / 3600.0, 0.25):
+            for seed in range(2):
+                elev, LAT, LON = _curved_geodesic_case(lat0, cell_deg, seed)
+                want_s, want_a = _geodesic_fit_mp(elev, LAT, LON)
+                agg = xs.DataArray(xs.DeviceArray.from_numpy(elev), dims=['y', 'x'],
+                                   coords={'lat': xs.DataArray(LAT, dims=['y', 'x']), 'lon': xs.DataArray(LON, dims=['y', 'x'])})
+                got_s = float(host(xs.slope(agg, method='geodesic').data)[1, 1])
+                got_a = float(host(xs.aspect(agg, method='geodesic').data)[1, 1])
+                cell_m = np.deg2rad(cell_deg) * 6.371e6
+                tol = max(2e-7, 40 * 2.2e-16 * 6.4e6 / cell_m)             # float32 store; float64 cancellation over one cell
+                np.testing.assert_allclose(got_s, want_s, rtol=tol, err_msg=f"lat {lat0} cell {cell_deg} seed {seed}")
+                assert abs((got_a - want_a + 180.0) % 360.0 - 180.0) < max(4e-5, 100 * tol), (lat0, cell_deg, got_a, want_a)
+                parity_log.record("f3 geodesic: curved surfaces vs an independent 40-digit evaluation", "slope", got_s, want_s,
+                                  tol="rtol 2e-7 (float32 store) + float64 cancellation over one cell")
+
+
 def test_geodesic_properties_and_validation():
     flat = np.full((6, 8), 500.0)
     for lat_c in (0.0, 30.0, 60.0, -45.0):
@@ -2110,15 +2132,23 @@ def test_geodesic_properties_and_validation():
                  method='geodesic')
 
 
-def test_zonal_crosstab(golden):
-    """zonal.crosstab: reference goldens (test_zonal.py:240-264, 786-822) + seeded rasters vs the oracle."""
+def test_zonal_crosstab(golden, golden_tables):
+    """zonal.crosstab: the reference's own expectations (test_zonal.py:240-336, 786-880, lifted by tests/golden/make_golden.py)
+    + seeded rasters vs the oracle."""
     from xrspatial_amd.zonal import crosstab
+    T = golden_tables
     zones, values = raster(golden["zonal_zones"]), raster(golden["zonal_values"])
-    df = crosstab(zones, values, zone_ids=[1, 2, 3], cat_ids=[0, 1, 2])
-    assert list(df.columns) == ['zone', 0, 1, 2] and df['zone'].tolist() == [1, 2, 3]
-    assert df[0].tolist() == [0, 0, 1] and df[1].tolist() == [6, 0, 0] and df[2].tolist() == [0, 4, 0]
-    df = crosstab(zones, values, zone_ids=[1, 2], cat_ids=[1, 2], nodata_values=3, agg='percentage')
-    assert df[1].tolist() == [100, 0] and df[2].tolist() == [0, 100]
+
+    def same(df, table):
+        assert [str(c) for c in df.columns] == [k for k in ['zone'] + sorted(k for k in table if k != 'zone')]
+        for col in df.columns:
+            np.testing.assert_allclose(df[col].to_numpy().astype(float), table[str(col)], err_msg=str(col))
+    # result_count_crosstab_2d -> (zone_ids, cat_ids, table); result_percentage_crosstab_2d -> (nodata, zone_ids, cat_ids, table)
+    same(crosstab(zones, values, zone_ids=[int(z) for z in T["crosstab_2d_count__0"]], cat_ids=[int(c) for c in T["crosstab_2d_count__1"]]),
+         T["crosstab_2d_count__2"])
+    same(crosstab(zones, values, zone_ids=[int(z) for z in T["crosstab_2d_percentage__1"]],
+                  cat_ids=[int(c) for c in T["crosstab_2d_percentage__2"]], nodata_values=T["crosstab_2d_percentage__0"],
+                  agg='percentage'), T["crosstab_2d_percentage__3"])
     rng = np.random.default_rng(8)
     zz = rng.integers(0, 9, size=(150, 260)).astype(np.float64)
     zz[rng.random(zz.shape) < 0.02] = np.nan
@@ -2140,16 +2170,16 @@ def test_zonal_crosstab(golden):
         assert list(got.columns) == list(want)
         for col in want:
             np.testing.assert_array_equal(got[col].to_numpy(), want[col], err_msg=f"{nzz}x{ncc} {col}")
-    # 3-D values: a layer per category (test_zonal.py:50-59, 266-336, 825-880)
+    # 3-D values: a layer per category (data_values_3d, test_zonal.py:50-59): result_crosstab_3d -> (layer, zone_ids, {agg: table}),
+    # every aggregation the reference checks (test_crosstab_3d_agg_method, :843-855); result_nodata_values_crosstab_3d ->
+    # (nodata, layer, zone_ids, table) through the default agg='count' (:859-880)
     data3 = np.ones((3, 8, 4))
     v3 = xs.DataArray(data3, dims=['lat', 'lon', 'race'], coords={'race': np.array(['cat1', 'cat2', 'cat3', 'cat4'], dtype=object)})
-    for agg, exp in (('count', [6, 5, 6]), ('sum', [6., 5., 6.]), ('mean', [1., 1., 1.]), ('std', [0., 0., 0.])):
-        df = crosstab(zones, v3, zone_ids=[1, 2, 3], layer=-1, agg=agg)
-        assert list(df.columns) == ['zone', 'cat1', 'cat2', 'cat3', 'cat4']
-        for c in ('cat1', 'cat4'):
-            np.testing.assert_allclose(df[c].to_numpy(), exp)
-    with pytest.raises(ValueError):
-        crosstab(zones, values, agg='mean')
+    layer, zone_ids = int(T["crosstab_3d__0"]), [int(z) for z in T["crosstab_3d__1"]]
+    for agg in ('min', 'max', 'mean', 'sum', 'std', 'var', 'count'):
+        same(crosstab(zones, v3, zone_ids=zone_ids, layer=layer, agg=agg), T[f"crosstab_3d__2__{agg}"])
+    same(crosstab(zones, v3, zone_ids=[int(z) for z in T["crosstab_3d_nodata__2"]], layer=int(T["crosstab_3d_nodata__1"]),
+                  nodata_values=T["crosstab_3d_nodata__0"]), T["crosstab_3d_nodata__3"])
 
 
 def test_large_mask_stats_conditioning():

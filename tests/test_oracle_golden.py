@@ -351,3 +351,136 @@ def test_geodesic_oracle_level_surface_is_flat():
     elev, LAT, LON, _, _ = _analytic_geodesic_case(37.0, 0.0, 0.0, h0=1200.0, cell_arcsec=3.0)
     s = orc.geodesic_slope(elev, LAT, LON)[1:-1, 1:-1]
     assert np.all(s < 2e-3)                       # degrees; the WGS84 / mean-sphere mismatch of the correction is what is left
+
+
+# ---------------------------------------------------------------- geodesic: an independent 40-digit evaluation of the 3x3 fit
+def _geodesic_fit_mp(elev3, lat3, lon3, z_factor=1.0, correction=True):
+    """(slope_deg, aspect_deg) at the centre of a 3x3 neighbourhood, evaluated INDEPENDENTLY of oracle/xrs_oracle.py in 40-digit
+    arithmetic (mpmath): WGS84 geodetic -> ECEF, the East / North / Up frame of the centre cell as a rotation applied to the
+    difference vectors, the sphere-flattening term u += (e^2 + n^2) / 2R of xrspatial/geodesic.py:96-97, and the plane
+    u = A e + B n + C as a three-parameter least-squares problem solved by mpmath (not the centred normal equations the
+    reference and the oracle spell out)."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    a, b = mp.mpf('6378137.0'), mp.mpf('6356752.314245')
+    R = mp.mpf('6370994.884953014')
+    d2r = mp.pi / 180
+
+    def ecef(lat, lon, h):
+        cl, sl = mp.cos(lat), mp.sin(lat)
+        N = a * a / mp.sqrt(a * a * cl * cl + b * b * sl * sl)
+        return mp.matrix([(N + h) * cl * mp.cos(lon), (N + h) * cl * mp.sin(lon), (b * b / (a * a) * N + h) * sl])
+
+    latc, lonc = mp.mpf(float(lat3[1, 1])) * d2r, mp.mpf(float(lon3[1, 1])) * d2r
+    pc = ecef(latc, lonc, mp.mpf(float(elev3[1, 1])) * z_factor)
+    rot = mp.matrix([[-mp.sin(lonc), mp.cos(lonc), 0],
+                     [-mp.sin(latc) * mp.cos(lonc), -mp.sin(latc) * mp.sin(lonc), mp.cos(latc)],
+                     [mp.cos(latc) * mp.cos(lonc), mp.cos(latc) * mp.sin(lonc), mp.sin(latc)]])
+    rows, rhs = [], []
+    for i in range(3):
+        for j in range(3):
+            p = ecef(mp.mpf(float(lat3[i, j])) * d2r, mp.mpf(float(lon3[i, j])) * d2r, mp.mpf(float(elev3[i, j])) * z_factor)
+            e, n, u = rot * (p - pc)
+            if correction:
+                u += (e * e + n * n) / (2 * R)
+            rows.append([e, n, 1])
+            rhs.append(u)
+    A, B, _ = mp.lu_solve(mp.matrix(rows), mp.matrix(rhs))          # (overdetermined: the least-squares solution)
+    slope = mp.degrees(mp.atan(mp.sqrt(A * A + B * B)))
+    aspect = mp.degrees(mp.atan2(-A, -B)) % 360
+    return float(slope), float(aspect)
+
+
+def _curved_geodesic_case(lat0_deg, cell_deg, seed):
+    """A 3x3 patch of a CURVED surface (quadratic in northing / easting, random coefficients, 3-30 % grades) on the
+    reference's grid geometry: descending latitudes, ascending longitudes."""
+    rng = np.random.default_rng(seed)
+    lat = lat0_deg - (np.arange(3) - 1) * cell_deg
+    lon = 10.0 + (np.arange(3) - 1) * cell_deg
+    LAT, LON = np.meshgrid(lat, lon, indexing='ij')
+    north = np.deg2rad(LAT - lat0_deg) * 6371000.0
+    east = np.deg2rad(LON - 10.0) * 6371000.0 * np.cos(np.deg2rad(lat0_deg))
+    span = north.max() - north.min()
+    g = rng.uniform(-0.3, 0.3, 2)
+    q = rng.uniform(-0.3, 0.3, 3) / span                          # curvature: the gradient changes by ~0.3 across the patch
+    elev = 800.0 + g[0] * north + g[1] * east + q[0] * north ** 2 + q[1] * north * east + q[2] * east ** 2
+    return elev, LAT, LON
+
+
+@pytest.mark.parametrize("lat0", [0.0, 37.0, -58.0, 75.0])
+@pytest.mark.parametrize("cell_deg", [1.0 / 3600.0, 30.0 / 3600.0, 0.25])
+def test_geodesic_oracle_matches_independent_40_digit_fit(lat0, cell_deg):
+    """The geodesic oracle (float64 restatement of xrspatial/geodesic.py:40-229; the reference holds no vectors for it) on
+    curved surfaces against the independent 40-digit evaluation above: the ECEF conversion, the ENU projection, the
+    curvature-correction term and the plane fit each contribute to these numbers -- at 0.25-degree cells and 75 N the
+    correction term alone moves the slope by far more than the tolerance, which the test checks -- and must agree to 1e-7
+    relative (float64 rounding of ~6e6 m coordinates differenced over a cell) in slope and 1e-6 degrees in aspect."""
+    for seed in range(4):
+        elev, LAT, LON = _curved_geodesic_case(lat0, cell_deg, seed)
+        want_s, want_a = _geodesic_fit_mp(elev, LAT, LON)
+        got_s = float(orc._geodesic_plane_fit(elev, LAT, LON, 1.0)[0][0, 0])      # A, B in float64 (before the float32 store)
+        A, B, valid = orc._geodesic_plane_fit(elev, LAT, LON, 1.0)
+        assert bool(valid[0, 0])
+        got_s = float(np.degrees(np.arctan(np.hypot(A[0, 0], B[0, 0]))))
+        got_a = float(np.degrees(np.arctan2(-A[0, 0], -B[0, 0])) % 360.0)
+        # float64 cancellation: ECEF coordinates of ~6.4e6 m differenced over one cell, i.e. ~1e-16 * 6.4e6 / cell relative
+        cell_m = np.deg2rad(cell_deg) * 6.371e6
+        tol = max(1e-9, 20 * 2.2e-16 * 6.4e6 / cell_m)
+        np.testing.assert_allclose(got_s, want_s, rtol=tol, err_msg=f"slope lat {lat0} cell {cell_deg} seed {seed}")
+        assert abs((got_a - want_a + 180.0) % 360.0 - 180.0) < max(1e-6, 100 * tol), (got_a, want_a)
+        # the float32 result the public functions return
+        np.testing.assert_allclose(orc.geodesic_slope(elev, LAT, LON)[1, 1], np.float32(want_s), rtol=max(2e-7, tol))
+    # the correction term is exercised: without it the large-cell fit is a different number -- 1e-5 relative at 0.25-degree
+    # cells and 75 N, four orders of magnitude above the tolerance the oracle is held to there
+    elev, LAT, LON = _curved_geodesic_case(75.0, 0.25, 0)
+    with_c, _ = _geodesic_fit_mp(elev, LAT, LON)
+    without_c, _ = _geodesic_fit_mp(elev, LAT, LON, correction=False)
+    assert abs(with_c - without_c) > 5e-6 * with_c
+
+
+def test_geodesic_fit_approaches_the_analytic_gradient():
+    """On a small stencil the fitted plane of a curved surface is its tangent plane at the centre: slope -> atan |grad h|,
+    aspect -> bearing of -grad h, to O(cell / curvature radius) -- the closed form behind the geometry (1 arc-second cells)."""
+    for lat0 in (12.0, 51.0):
+        rng = np.random.default_rng(int(lat0))
+        cell = 1.0 / 3600.0
+        lat = lat0 - (np.arange(3) - 1) * cell
+        lon = 10.0 + (np.arange(3) - 1) * cell
+        LAT, LON = np.meshgrid(lat, lon, indexing='ij')
+        a, b = 6378137.0, 6356752.314245
+        phi0 = np.deg2rad(lat0)
+        w = np.sqrt(a * a * np.cos(phi0) ** 2 + b * b * np.sin(phi0) ** 2)
+        N, M = a * a / w, a * a * b * b / w ** 3
+        north = np.deg2rad(LAT - lat0) * (M + 800.0)
+        east = np.deg2rad(LON - 10.0) * (N + 800.0) * np.cos(phi0)
+        gn, ge = rng.uniform(-0.3, 0.3, 2)
+        elev = 800.0 + gn * north + ge * east + 2e-4 * north ** 2 - 1e-4 * north * east + 3e-4 * east ** 2
+        s = float(orc.geodesic_slope(elev, LAT, LON)[1, 1])
+        asp = float(orc.geodesic_aspect(elev, LAT, LON)[1, 1])
+        np.testing.assert_allclose(s, np.degrees(np.arctan(np.hypot(gn, ge))), rtol=2e-4)
+        assert abs((asp - np.degrees(np.arctan2(-ge, -gn)) + 180.0) % 360.0 - 180.0) < 0.02
+
+
+def test_crosstab_oracle_matches_reference_tables(golden, golden_tables):
+    """orc.crosstab_2d / the per-layer zonal statistics behind the 3-D crosstab against the reference's own expectations
+    (xrspatial/tests/test_zonal.py:240-336, lifted by make_golden.py)."""
+    T = golden_tables
+    zones, values = golden["zonal_zones"], golden["zonal_values"]
+    got = orc.crosstab_2d(zones, values, zone_ids=[int(z) for z in T["crosstab_2d_count__0"]],
+                          cat_ids=[int(c) for c in T["crosstab_2d_count__1"]])
+    for col, want in T["crosstab_2d_count__2"].items():
+        key = 'zone' if col == 'zone' else int(col)
+        np.testing.assert_allclose(np.asarray(got[key], dtype=float), want, err_msg=col)
+    got = orc.crosstab_2d(zones, values, zone_ids=[int(z) for z in T["crosstab_2d_percentage__1"]],
+                          cat_ids=[int(c) for c in T["crosstab_2d_percentage__2"]], nodata_values=T["crosstab_2d_percentage__0"],
+                          agg='percentage')
+    for col, want in T["crosstab_2d_percentage__3"].items():
+        key = 'zone' if col == 'zone' else int(col)
+        np.testing.assert_allclose(np.asarray(got[key], dtype=float), want, err_msg=col)
+    # 3-D values (a layer per category, all ones: data_values_3d): every aggregation is zonal.stats of a layer
+    layer_vals = np.ones(zones.shape)
+    zone_ids = [int(z) for z in T["crosstab_3d__1"]]
+    for agg in ('min', 'max', 'mean', 'sum', 'std', 'var', 'count'):
+        st = orc.zonal_stats(zones, layer_vals, zone_ids=zone_ids, stats_funcs=[agg])
+        for cat in ('cat1', 'cat2', 'cat3', 'cat4'):
+            np.testing.assert_allclose(st[agg], T[f"crosstab_3d__2__{agg}"][cat], err_msg=f"{agg} {cat}")

@@ -21,7 +21,7 @@ for s in $STEPS; do
     bench)
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
     pmc)
-      timeout 900 python tools/pmc_profile.py copy_kernel,pass_hill_focal5,pass_hill_slope_focal5,focal5_mean,hillshade,slope,aspect,focal25_mean,focal25_stats7,focal25_meanvarstd,focal25_minmaxrange,focal5_stats7,focal7_stats7,box25_stats7,box25_meanvarstd,box25_mean,annulus21_stats7,annulus21_mean,annulus25_mean,convolve21_annulus,terrain_hill_aspect_curv,zonal_1000,zonal_1000_scattered,zonal_5000 \
+      timeout 900 python tools/pmc_profile.py copy_kernel,geodesic_slope,geodesic_aspect,pass_hill_focal5,pass_hill_slope_focal5,focal5_mean,hillshade,slope,aspect,focal25_mean,focal25_stats7,focal25_meanvarstd,focal25_minmaxrange,focal5_stats7,focal7_stats7,box25_stats7,box25_meanvarstd,box25_mean,annulus21_stats7,annulus21_mean,annulus25_mean,convolve21_annulus,terrain_hill_aspect_curv,zonal_1000,zonal_1000_scattered,zonal_5000 \
         --out $OUT/pmc.json --traffic $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"; tail -3 $OUT/pmc.log ;;
     stats)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$TAG -o s -- \

@@ -177,6 +177,9 @@ struct ExtWalk {
         const long off = out_off;                             // (wave-uniform row address + 4 * lane)
         out_off += g.ld_out;
         if (EDGE && (x >= g.cols || yo >= y_end)) return;
+#ifdef XRS_FLOOR_NO_STORES                                     // (tools/floor_probe.sh: the walk without its output streams)
+        if (g.rows >= 0) return;
+#endif
         if (a.out_max) st_row_nt(uniform_ptr(a.out_max + off), 4u * (unsigned)lane, hi);
         if (a.out_min) st_row_nt(uniform_ptr(a.out_min + off), 4u * (unsigned)lane, lo);
         if (a.out_range) st_row_nt(uniform_ptr(a.out_range + off), 4u * (unsigned)lane, hi - lo);
@@ -214,8 +217,15 @@ struct ExtWalk {
             slot_out = slot_out + 1 == C::RB ? 0 : slot_out + 1;
         }
         float lo1[R + 1], hi1[R + 1], lo2[R + 1], hi2[R + 1];
+#ifdef XRS_FLOOR_NO_ARITH                                      // (tools/floor_probe.sh: the DMA ring and the stores, no reads / extrema)
+#pragma unroll
+        for (int h = 0; h <= R; ++h) { lo1[h] = hi1[h] = lo2[h] = hi2[h] = 0.0f; }
+        if (g.rows < 0)
+#endif
+        {
         row_levels(row1, lo1, hi1);
         row_levels(row2, lo2, hi2);
+        }
         if (EDGE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -177,6 +177,9 @@ struct MomWalk {
     // NC results per lane to the wave-uniform row address `p` (streaming store, scalar base + 32-bit lane offset: the
     // compiler otherwise keeps a 64-bit lane address per output plane alive across the walk)
     __device__ __forceinline__ void store_row(float *p, stNC v) const {
+#ifdef XRS_FLOOR_NO_STORES                                     // (tools/floor_probe.sh: the walk without its output streams)
+        if (g.rows >= 0) return;
+#endif
         const unsigned lane_b = (unsigned)(NC * 4) * (unsigned)lane;
         if (NC == 2) { lds_dma_v2f q; q[0] = v[0]; q[1] = v[NC - 1]; st_row_nt(uniform_ptr(p), lane_b, q); }
         else if (NC == 1) st_row_nt(uniform_ptr(p), lane_b, v[0]);
@@ -296,11 +299,17 @@ struct MomWalk {
         // memory barrier between the passes -- XRS_MOM_SPLIT_READS -- should need 26 registers less; this compiler then
         // spills 53 instead.)
         asm volatile("" : "+v"(row));                         // (one base register + immediate offsets for the reads)
+#ifdef XRS_FLOOR_NO_ARITH                                      // (tools/floor_probe.sh: the DMA ring and the stores, no reads / sums)
+        if (g.rows < 0)
+#endif
         moment_pass<PHASE, false>(row);
 #ifdef XRS_MOM_SPLIT_READS
         asm volatile("" ::: "memory");
 #endif
 #ifndef XRS_MOM_T_NOQ
+#ifdef XRS_FLOOR_NO_ARITH
+        if (g.rows < 0)
+#endif
         moment_pass<PHASE, true>(row);
 #endif
 

@@ -23,6 +23,24 @@
 //     mode (nodata regions, scattered NaN cells), and from there -- +-inf, rasters whose values straddle zero -- to the
 //     float64 column walker of circle_walk.h (NaN-skipping, counting, exact).  Typical errors are ~1e-8 relative
 //     (tests: 1e-6 on both DEMs).
+//   * nodata (round 5).  A NaN under some window used to end the tile's walk (one non-finite sum) and send the whole tile to the
+//     NaN-aware walker below -- with 0.1 % of the cells NaN that is every tile, at ~0.34 ms of a wave's time each, and the 25x25
+//     mean took 1.72 ms instead of 0.55.  Interior tiles of the mean / sum (circles and boxes) now carry NaN cells themselves.
+//     At the head of a step every lane looks at the cells of the row it stages for the wave (its NC, the first lanes also the
+//     halo cells: two LDS reads) and the wave votes; a row that holds NaN (rare) has those cells OVERWRITTEN in the ring with
+//     the shift -- a cell equal to the shift adds nothing to any sum, so the reads, prefix sums, rings and the sliding box sum
+//     behind it never know -- and their positions noted in a 152-bit bitmap.  Every lane then takes the bits of its own NV
+//     cells from the bitmap and, for each of the 2R+1 output rows this input row lies under, adds the number of them inside
+//     that row's run (one popcount per distinct half-width and column) to a LOST RING in LDS: one byte per owned column, slot
+//     = the step that completes that output row, mod 2R+1 (3.2 KiB per wave at 25x25; atomic adds on the word two lanes
+//     share).  An output row completed while a NaN row is among its 2R+1 input rows (a scalar shift register remembers)
+//     reads its lane's entry, clears it and divides by n - lost.  No count ring in registers (they are not there: 160 of 168),
+//     nothing on clean rows but the vote and one scalar test.  +-inf, windows that lost more than half their cells and tiles
+//     whose rows have shown one lane more than 255 NaN cells in all still hand the tile on; so do edge tiles and the annuli.
+//     (Forms that did not survive: the vote on the prefix total behind the read -- free, but the row then has to be read
+//     again, and a second copy of the read spilled 37 registers into the round loop, whose scratch traffic sat in the vmcnt
+//     bookkeeping of the DMA ring: 0.59 -> 2.2 ms on a CLEAN raster; a two-trip loop around one copy; counting the lost cells at
+//     every output row from a ring of bitmap rows: a scalar loop of dependent LDS reads, 1.6 ms at 0.1 % NaN.)
 //   * raster edges (clipped windows): out-of-raster cells enter as d = 0 and the divisor is the geometric count of
 //     in-raster cells, so edge tiles stay on the fast path (a second, predicated instantiation of the same walk).
 //   * memory latency: the interior walk prefetches its rows D = 8 ahead by LDS-DMA (global_load_lds_dwordx4: global ->
@@ -41,6 +59,7 @@
 #include "circle_walk.h"
 #include "lds_dma.h"
 #include "mom_nan_walk.h"
+#include "wave_reduce.h"
 
 #include <type_traits>
 #include <utility>
@@ -51,6 +70,9 @@ namespace {
 
 #ifndef XRS_WIDE_NO_FALLBACK
 #define XRS_WIDE_NO_FALLBACK 0
+#endif
+#ifndef XRS_WIDE_CARRY
+#define XRS_WIDE_CARRY 1          // NaN tiles: the carrying walk (below) before the NaN-aware walker of mom_nan_walk.h
 #endif
 struct WideArgs {
     WalkGeom g;                   // in, rows, cols, ld_in, ld_out, halo_top, halo_bot (tiles_x / n_tiles: wave tiles)
@@ -139,11 +161,16 @@ __device__ __forceinline__ int clipped_count(long yo, long x, long y_lo, long y_
 // w * sum over the full window, NaN within R cells of the raster edge, and NaN whenever the SQUARE window holds a
 // non-finite cell, zero weights included: any non-finite cell among those the tile reads sends the tile to the exact walker).
 enum : int { WIDE_MEAN = 0, WIDE_SUM = 1, WIDE_CONV = 2 };
-template <int R, typename Shape, bool EDGE, int MODE>
+template <int R, typename Shape, bool EDGE, int MODE, bool CARRY = false>
 struct WideWalk {
     static constexpr bool SUM = MODE == WIDE_SUM, CONV = MODE == WIDE_CONV;
     using C = WideCfg<R, Shape>;
     static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW;
+    // CARRY: nodata carried by the walk itself (header) -- the second walk of a tile whose first, plain walk met a NaN
+    // (not the annuli: four of the radius-10 rings spill 1-4 registers into the round loop with it; their NaN tiles go the old way)
+    static constexpr bool NANOK = CARRY && !CONV && !shape_has_hole<Shape>(R) && NC <= 2 && NV <= 32 && TW + 2 * HL <= 160 &&
+                                  32 % NC == 0;
+    static constexpr int NMW = 6;  // words of the bitmap (TW + 2 HL <= 160 bits, + one the last lane's read may touch)
 
     // ---- state
     float acc[C::KR][NC];          // ring: partial window sums of the 2R+1 output rows in flight (SLIDE: the last KR row sums H)
@@ -157,6 +184,13 @@ struct WideWalk {
     float *out_row;                // interior: (wave-uniform) first cell of the next output row of this wave tile
     float amax, mmin;
     bool bad;
+    unsigned inflight;             // (wave-uniform) bit b: input row t - b holds NaN cells (they were zeroed; positions in nanmap)
+    bool saw_nan;                  // (wave-uniform) some row of the tile did
+    unsigned *nanmap;              // LDS: NMW words, the NaN bitmap of the row being marked: bit s = staged cell s is NaN
+    unsigned short *lostring;      // LDS: [K][64] -- slot (step mod K), lane: NaN cells under the windows of the output row that step
+                                   // completes, one byte per owned column
+    int lost_slot;                 // (wave-uniform) t mod K of the current step
+    int span_total;                // (wave-uniform) NaN cells the rows of this tile have shown their worst lane, summed
     int t;                         // input row counter: row y_first + t
     // ---- constants of the tile
     const WalkGeom &g;
@@ -201,13 +235,30 @@ struct WideWalk {
         amax = 0.0f;
         mmin = INFINITY;
         bad = false;
+        inflight = 0u;
+        saw_nan = false;
+        lost_slot = K - 1;
+        span_total = 0;
         t = 0;
         y_first = y0 - R;
         n_in = (int)(y_end - y0) + 2 * R;                // (interior tiles: a whole number of rounds)
         // shift: the cell at the tile centre (any finite value works; a nearby one keeps |v - c| small)
         const long yc = y0 + (y_end - y0) / 2, xc = (x_tile + TW / 2 < g.cols ? x_tile + TW / 2 : g.cols - 1);
-        const float c0 = g.in[yc * g.ld_in + xc];
-        c = isfinite(c0) ? c0 : 0.0f;
+        float c0 = g.in[yc * g.ld_in + xc];
+        if (!isfinite(c0)) {
+            // the centre cell is nodata: the first finite cell of the 64 to its left on that row instead (shift 0 on a raster of
+            // values around 1000 fails the rounding bound below: at 0.1 % nodata that was 8 tiles of 16 128 handed to the NaN-aware
+            // walker -- and whichever of them ran last, ~0.3 ms of a lone wave at the end of the launch)
+            const long xl = xc - lane >= 0 ? xc - lane : 0;
+            const float cand = g.in[yc * g.ld_in + xl];
+            const unsigned long long fin = __ballot(isfinite(cand));
+            c0 = fin ? __shfl(cand, __builtin_ctzll(fin)) : 0.0f;
+        }
+        c = c0;
+        if constexpr (NANOK) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) lostring[j * 64 + lane] = 0;
+        }
         if (EDGE) {
 #pragma unroll
             for (int o = 0; o < NC; ++o)
@@ -259,20 +310,129 @@ struct WideWalk {
         }
     }
 
+    // (NANOK) the input row of this step holds NaN: every lane overwrites the NaN among ITS cells of the row in the ring (staged
+    // cells NC l .. NC l + NC - 1; the first 2 HL / NC lanes also the halo cells TW + NC l ..) with the shift -- a cell equal to
+    // the shift adds nothing to any sum -- and notes their positions in the bitmap (bit s = staged cell s).  Then every lane
+    // takes the bits of its own NV cells from it and adds, for each of the 2R+1 output rows this input row lies under, the
+    // number of them inside that row's run to the lost ring: slot (step that completes the output row) mod K.  The runs are
+    // compile-time masks; ~100 instructions and 2R+1 read-modify-writes of LDS on the rare row, one read at every output.
+    __device__ __forceinline__ void mark_row(float *row, int i) {
+        typedef float ldsNC __attribute__((ext_vector_type(NC)));
+        unsigned *bm = nanmap;
+        if (lane < NMW) bm[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (LDS serves one wave's instructions in order)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if (part && lane >= 2 * HL / NC) break;
+            const int s0 = (part ? TW : 0) + NC * lane;
+            ldsNC *p = reinterpret_cast<ldsNC *>(row + s0);
+            ldsNC v = *p;
+            unsigned mine = 0u;
+#pragma unroll
+            for (int e = 0; e < NC; ++e)
+                if (isnan(v[e])) { v[e] = c; mine |= 1u << e; }
+            if (mine) {
+                *p = v;
+                atomicOr(&bm[s0 >> 5], mine << (s0 & 31));     // (NC cells at a multiple of NC: never across two words)
+            }
+        }
+        spread_lost(i);
+    }
+
+    // (NANOK) the bitmap of the current row is complete: every lane takes the bits of its own NV cells and adds, for each of the
+    // 2R+1 output rows this input row lies under, the number of them inside that row's run to the lost ring
+    __device__ __forceinline__ void spread_lost(int i) {
+        unsigned *bm = nanmap;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (LDS serves one wave's instructions in order)
+        const int s0 = NC * lane;
+        const unsigned long long two = ((unsigned long long)bm[(s0 >> 5) + 1] << 32) | bm[s0 >> 5];
+        const unsigned span = (unsigned)(two >> (s0 & 31));    // bit k: the lane's cell w[k] of this row is NaN
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (the next marked row clears the bitmap)
+        // lost counts are bytes: once the rows of this tile have shown a lane more than 255 NaN cells in all (the sum of the
+        // rows' worst lanes: a scalar) the tile is handed on (dense nodata -- the NaN-aware walker is the faster one there
+        // anyway); below that no byte of the ring can overflow
+        span_total += wave_reduce<WrMax>(__popc(span & ((1u << NV) - 1u)));
+        bad |= span_total > 255;
+        // every distinct half-width once (both owned columns packed: byte o), then one LDS add per output row in flight; the ring
+        // holds one 16-bit entry per lane, two lanes to a word: an atomic add of the entry shifted to the lane's half
+        constexpr ShapeRows<R, Shape> T{};
+        unsigned lvl[R + 1];
+#pragma unroll
+        for (int h = 0; h <= R; ++h) {
+            lvl[h] = 0u;
+            if (!C::level_used(h)) continue;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) lvl[h] |= (unsigned)__popc((span >> (HL + o - h)) & ((2u << (2 * h)) - 1u)) << (8 * o);
+            lvl[h] <<= 16 * (lane & 1);
+        }
+        unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (lane >> 1);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
+            if (i + j < 2 * R) continue;                       // (the run-in: steps that complete no output row never read their slot)
+            const int slot = lost_slot + j < K ? lost_slot + j : lost_slot + j - K;
+            __hip_atomic_fetch_add(ring32 + slot * 32, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+
+    // (NANOK) NaN cells under the windows of the output row this step completes: the lane's entry of the lost ring, cleared
+    // for the step that will use the slot next
+    __device__ __forceinline__ void lost_cells(int (&lost)[NC]) const {
+        unsigned short *p = lostring + lost_slot * 64 + lane;
+        const unsigned v = *p;
+        *p = 0;
+#pragma unroll
+        for (int o = 0; o < NC; ++o) lost[o] = (int)((v >> (8 * o)) & 255u);
+    }
+
     template <int PHASE, int BASE>   // BASE: SLIDE's ring slot of the round's first row (0 otherwise)
     __device__ __forceinline__ void process(const float (&q)[NC], float hq, int i) {
         constexpr int SLOT = (BASE + PHASE) % C::KR;
         const long yy = y_first + i;
         const bool row_in = !EDGE || (yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot);  // wave-uniform
+        if constexpr (NANOK) {
+            inflight = (inflight << 1) & ((1u << K) - 1u);
+            lost_slot = lost_slot + 1 == K ? 0 : lost_slot + 1;          // == i mod K (init: K - 1)
+        }
         if (row_in) {
             typedef float ldsNC __attribute__((ext_vector_type(NC)));
             float w[NV];
             if (EDGE) {
                 // ---- shifted row -> LDS, each lane reads back the NV cells under its NC windows
                 float d[NC];
-                const float dh = hq - c;
+                float dh = hq - c;
 #pragma unroll
                 for (int e = 0; e < NC; ++e) d[e] = q[e] - c;
+                if constexpr (NANOK) {
+                    // (the interior walk's vote, on the cells in registers: NaN -> d = 0, positions into the bitmap)
+                    bool nn = !isfinite(dh);
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) nn |= !isfinite(d[e]);
+                    if (__builtin_expect(__any(nn) != 0, 0)) {
+                        bad |= isinf(dh);
+#pragma unroll
+                        for (int e = 0; e < NC; ++e) bad |= isinf(d[e]);
+                        unsigned *bm = nanmap;
+                        if (lane < NMW) bm[lane] = 0u;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        unsigned mine = 0u;
+#pragma unroll
+                        for (int e = 0; e < NC; ++e)
+                            if (isnan(d[e])) { d[e] = 0.0f; mine |= 1u << e; }
+                        if (mine) atomicOr(&bm[(NC * lane) >> 5], mine << ((NC * lane) & 31));
+                        if (isnan(dh)) {
+                            dh = 0.0f;
+                            if (lane < 2 * HL) atomicOr(&bm[(TW + lane) >> 5], 1u << ((TW + lane) & 31));
+                        }
+                        spread_lost(i);
+                        inflight |= 1u;
+                        saw_nan = true;
+                        if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e + 1 < NC; e += 2) amax = amax3(amax, d[e], d[e + 1]);
                 amax = amax3(amax, dh, 0.0f);
@@ -295,8 +455,29 @@ struct WideWalk {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             } else {
-                // ---- the row landed in the ring (raw cells): read the NV cells under the lane's windows, shift them
-                const float *row = lds + slot_out * C::RBF;
+                // ---- the row landed in the ring (raw cells).  (NANOK) First a look at the lane's OWN cells of it (the NC it stages
+                // for the wave, the first lanes also the halo cells): a wave-wide vote, and a row that holds NaN has them
+                // overwritten with the shift in the ring and noted in the bitmap (mark_row) BEFORE anybody reads the row.  The vote
+                // stands at the head of the step, where the instruction stream is cut anyway; voting on the prefix total behind
+                // the read (free, but the row then has to be read again: a second copy of the read spilled 37 registers into the
+                // round loop, a two-trip loop around one copy cut the step in the middle of its dependent chains: 25x25 mean
+                // 0.59 -> 2.2 / 0.80 ms on a clean raster).
+                float *row = lds + slot_out * C::RBF;
+                if constexpr (NANOK) {
+                    const int s1 = lane < 2 * HL / NC ? TW + NC * lane : NC * lane;     // (the other lanes look at their own cells twice)
+                    const ldsNC a0 = *reinterpret_cast<const ldsNC *>(row + NC * lane), a1 = *reinterpret_cast<const ldsNC *>(row + s1);
+                    bool nn = false;
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) nn |= !isfinite(a0[e]) || !isfinite(a1[e]);
+                    if (__builtin_expect(__any(nn) != 0, 0)) {        // rare, wave-uniform
+#pragma unroll
+                        for (int e = 0; e < NC; ++e) bad |= isinf(a0[e]) || isinf(a1[e]);      // +-inf: the tile is handed on
+                        mark_row(row, i);
+                        inflight |= 1u;
+                        saw_nan = true;
+                        if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < NQ; ++b) {
                     const ldsNC v4 = *reinterpret_cast<const ldsNC *>(row + NC * lane + NC * b);
@@ -315,7 +496,10 @@ struct WideWalk {
             // ---- lane-local prefix sums: P[k] = w[0] + .. + w[k]; cell o's centre is w[HL + o]
 #pragma unroll
             for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
-            if (CONV) bad |= !isfinite(w[NV - 1]);            // the lanes' totals cover every cell the tile read in this row
+            // the lanes' totals cover every cell the tile read in this row: the convolution must not meet a non-finite cell at all, and
+            // the plain walk of the mean / sum gives up at the first row that holds one (not 2R rows later, when the first poisoned
+            // window sum comes out): the carrying walk behind it then starts all the sooner
+            if (CONV || !NANOK) bad |= !isfinite(w[NV - 1]);
             if (C::SLIDE) {
                 // input row i lives in slot i mod KR; the row that leaves the window, i - (2R+1), K slots behind
                 constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;
@@ -388,6 +572,8 @@ struct WideWalk {
             const long yo = y0 + (i - 2 * R);
             const long xo = x_tile + NC * lane;
             float res[NC];
+            int lost_o[NC];
+            if (NANOK && __builtin_expect(inflight != 0u, 0)) lost_cells(lost_o);
 #pragma unroll
             for (int o = 0; o < NC; ++o) {
                 float n = (float)C::NTAPS;
@@ -397,6 +583,17 @@ struct WideWalk {
                                 : (float)clipped_count<R, Shape>(yo, xo + o, -(long)g.halo_top, g.rows + g.halo_bot, g.cols);
                 }
                 const float s = C::SLIDE ? vsum[o] : acc[DONE][o];
+                if (NANOK && __builtin_expect(inflight != 0u, 0)) {   // (wave-uniform) NaN rows under this output row's windows
+                    const int lost = lost_o[o];
+                    const float nf = n - (float)lost;                  // (n: the window's cells inside the raster)
+                    // (a window without a valid cell: mean NaN, sum 0 -- numba nanmean / nansum of an empty window)
+                    const float m = lost ? (nf > 0.0f ? fmaf(s, __builtin_amdgcn_rcpf(nf), c) : nan_f32())
+                                         : (EDGE ? c + s / n : fmaf(s, 1.0f / (float)C::NTAPS, c));
+                    res[o] = SUM ? fmaf(nf, c, s) : m;
+                    bad |= !isfinite(s) || 2.0f * (float)lost > n;
+                    if (!EDGE || xo + o < g.cols) mmin = fminf(mmin, fabsf(m));
+                    continue;
+                }
                 if (CONV) {
                     // full windows only: NaN within R cells of the raster (or shard halo) edge
                     const bool full = !EDGE || (yo - R >= -(long)g.halo_top && yo + R < g.rows + g.halo_bot &&
@@ -488,7 +685,8 @@ struct WideWalk {
         constexpr int PV = shape_has_hole<Shape>(R) ? 4 : 2;
         constexpr float COEF = UNIT * (float)(C::SLIDE ? K * 2 * NV * NV + (5 + 2 * C::KR) * C::NTAPS
                                                        : K * (PV * NV * NV + K) + K * C::NTAPS) / (float)C::NTAPS * (EDGE ? 4.0f : 1.0f);
-        return !__any(bad) && (COEF * a <= 0.9e-5f * mm);
+        // (windows that lost cells to nodata -- at most half of them -- divide the same rounding by a smaller count)
+        return !__any(bad) && (COEF * (saw_nan ? 2.0f : 1.0f) * a <= 0.9e-5f * mm);
     }
 };
 
@@ -499,6 +697,8 @@ template <int R, typename Shape, int MODE>
 __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const WideArgs a) {
     using C = WideCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float lds_rows[4][C::LDS_WAVE];
+    __shared__ unsigned nan_row[4][8];                         // per wave: the NaN bitmap of the row being marked (interior tiles)
+    __shared__ unsigned short lost_ring[4][(MODE != WIDE_CONV && !shape_has_hole<Shape>(R)) ? C::K * 64 : 1];   // per wave: NaN cells under the windows in flight
     long ty, gx;                   // (rim tiles first: circle_walk.h)
     if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     const int lane = threadIdx.x & 63;
@@ -528,6 +728,25 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
         if (C::TW == 128 && x_tile + 128 <= g.cols) fill_tile128_nt(a.out, g.ld_out, x_tile, y0, y_end, lane, SUM ? 0.0f : nan_f32());
         else walk_fill_no_data(g, planes, 1, SUM ? a.out : nullptr, 0.0f, x_tile, x_tile + C::TW, y0, y_end, lane);
         return;
+    }
+    // NaN cells under a window (scattered nodata, a nodata region's rim): the SAME walk again, this time carrying them (CARRY:
+    // vote on the staged cells, in-ring repair, lost ring in LDS -- ~1.3x a plain walk).  The plain walk in front of it stopped
+    // at the first round that met a NaN, so a clean raster never pays for any of this.  +-inf, dense nodata, windows with fewer
+    // than half their cells and ill-conditioned sums still fail here and go on to the walkers below.
+    if constexpr (MODE != WIDE_CONV && !shape_has_hole<Shape>(R) && XRS_WIDE_CARRY) {
+        bool ok2;
+        if (interior) {
+            WideWalk<R, Shape, false, MODE, true> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+            w.nanmap = nan_row[wv];
+            w.lostring = lost_ring[wv];
+            ok2 = w.run();
+        } else {
+            WideWalk<R, Shape, true, MODE, true> w(g, a.out, lds_rows[wv], x_tile, y0, y_end, lane);
+            w.nanmap = nan_row[wv];
+            w.lostring = lost_ring[wv];
+            ok2 = w.run();
+        }
+        if (ok2) return;
     }
     if (MODE == WIDE_CONV) {
         // a non-finite cell in reach, or sums too ill-conditioned for float32: the float64 conv walker (tap by tap, in the

@@ -167,3 +167,44 @@ def test_fuzz_smoke():
         if err:
             fails.append(f"[{i}] {desc}: {err}")
     assert not fails, "\n".join(fails[:10])
+
+
+@pytest.mark.parametrize("kind,radius", [("circle", 12), ("circle", 6), ("circle", 3), ("box", 12), ("box", 5)])
+def test_large_window_mean_sum_carry_nodata(kind, radius):
+    """The large-window mean / sum on rasters with nodata (wide_impl.h: a tile whose plain walk meets a NaN is walked again by
+    the same row walker CARRYING the NaN cells -- vote on staged cells, in-ring repair, lost ring in LDS): scattered NaN at
+    0.1 % and 2 %, NaN exactly at the centre cells of wave tiles (the cell the shift is taken from), NaN along the raster's
+    edges (edge tiles carry too), a dense patch (the walk hands such tiles on), an all-NaN block larger than the window, and
+    a +-inf cell -- mean and sum against the oracle, NaN patterns exactly."""
+    from xrspatial_amd.convolution import circle_kernel
+    K = 2 * radius + 1
+    k = circle_kernel(1, 1, radius) if kind == "circle" else np.ones((K, K))
+    rows, cols = 900, 1700
+    rng = np.random.default_rng(100 * radius + (kind == "box"))
+    base = (1000.0 + 40.0 * np.sin(np.arange(cols)[None, :] / 90.0) * np.cos(np.arange(rows)[:, None] / 70.0)
+            + rng.normal(0, 2.0, (rows, cols))).astype(np.float32)
+    cases = {}
+    z = base.copy(); z[rng.random(z.shape) < 1e-3] = np.nan; cases["0.1 % scattered"] = z
+    z = base.copy(); z[rng.random(z.shape) < 0.02] = np.nan; cases["2 % scattered"] = z
+    z = base.copy(); z[::13, 64::128] = np.nan; z[65::130, ::17] = np.nan; cases["tile centres and a lattice"] = z
+    z = base.copy(); z[:3, ::7] = np.nan; z[-2:, 5::11] = np.nan; z[::9, :2] = np.nan; z[4::10, -3:] = np.nan; cases["raster edges"] = z
+    z = base.copy(); z[300:420, 500:800][rng.random((120, 300)) < 0.6] = np.nan; z[600:600 + 2 * K + 5, 900:900 + 3 * K] = np.nan
+    z[100, 1200] = np.inf; z[700, 300] = -np.inf; cases["dense patch, nodata block, inf"] = z
+    for name, z in cases.items():
+        agg = xs.DataArray(xs.DeviceArray.from_numpy(z), dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+        for stat in ('mean', 'sum'):
+            got = focal_stats(agg, k, stats_funcs=[stat]).data.get()[0]
+            with np.errstate(all='ignore'):
+                want = corc.focal_apply(z, k, stat, nthreads=8)
+            assert (np.isnan(got) == np.isnan(want)).all(), f"{kind} r={radius} {name} {stat}: NaN pattern"
+            fin = np.isfinite(want)
+            assert (got[~fin & ~np.isnan(want)] == want[~fin & ~np.isnan(want)]).all(), f"{kind} r={radius} {name} {stat}: infinities"
+            if stat == 'mean':
+                np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL, atol=0, err_msg=f"{kind} r={radius} {name} mean")
+                parity_log.record("large-window mean on nodata (carrying walk), 900x1700", f"{kind} {K}x{K} {name}", got[fin], want[fin],
+                                  tol="rtol 1e-5")
+            else:
+                # `sum` is the exactly rounded window sum; the reference adds the taps in float32 one by one: its own bound
+                n = float(np.count_nonzero(k == 1))
+                np.testing.assert_allclose(got[fin], want[fin], rtol=max(RTOL, 1.01 * (n - 1) * 2.0 ** -24), atol=0,
+                                           err_msg=f"{kind} r={radius} {name} sum")

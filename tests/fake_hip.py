@@ -168,6 +168,16 @@ def call(name, *a):
         out[0], out[1] = (fin.min(), fin.max()) if fin.size else (np.inf, -np.inf)
         out[2:3].view(np.uint64)[0] = fin.size
         out[3:4].view(np.int32)[0] = int(bool((fin == np.floor(fin)).all()))
+    elif name == "xrs_zonal_scan_presence_i32":
+        z, n, res, present, window, _ = a
+        ids = _arr(z, n, np.int32)
+        out = _arr(res, 4, np.float64)
+        out[0], out[1] = (ids.min(), ids.max()) if ids.size else (np.inf, -np.inf)
+        out[2:3].view(np.uint64)[0] = ids.size
+        out[3:4].view(np.int32)[0] = 1
+        flags = _arr(present, window, np.uint8)
+        flags[...] = 0
+        flags[ids[(ids >= 0) & (ids < window)]] = 1
     elif name == "xrs_zonal_presence":
         z, code, n, zmin, rng, present, _ = a
         raw = _arr(z, n, (np.int32, np.int64, np.float32, np.float64)[code])
@@ -200,6 +210,43 @@ def call(name, *a):
         _arr(s2, nz, np.float64)[...] += np.bincount(idx[ok], weights=v64 * v64, minlength=nz)
         np.minimum.at(_arr(mn, nz, vt), idx[ok], v[ok])
         np.maximum.at(_arr(mx, nz, vt), idx[ok], v[ok])
+    elif name in ("xrs_zonal_sample_f32", "xrs_zonal_sample_f64"):
+        z, vals, n, n_samples, nodata, has_nodata, res, _ = a
+        vt = np.float64 if name.endswith("f64") else np.float32
+        n_samples = min(int(n_samples), int(n))
+        stride = max((int(n) // n_samples) | 1, 1)
+        idx = (np.arange(n_samples, dtype=np.int64) * stride + stride // 2) % int(n)
+        ids, v = _arr(z, n, np.int32)[idx], _arr(vals, n, vt)[idx]
+        ok = np.isfinite(v)
+        if has_nodata:
+            ok &= v != vt(nodata)
+        out = _arr(res, 3, np.float64)
+        out[:1].view(np.int32)[:2] = (ids.min(), ids.max())
+        out[1] = float(v[ok].astype(np.float64).mean()) if ok.any() else 0.0
+        out[2:3].view(np.uint64)[0] = int(ok.sum())
+    elif name in ("xrs_zonal_partials_window_f32", "xrs_zonal_partials_window_f64"):
+        z, base, window, vals, n, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, present, overflow, _ = a
+        vt = np.float64 if name.endswith("f64") else np.float32
+        off = _arr(z, n, np.int32).astype(np.int64) - int(base)
+        inside = (off >= 0) & (off < window)
+        v = _arr(vals, n, vt)
+        okv = np.isfinite(v)
+        if has_nodata:
+            okv &= v != vt(nodata)
+        ok = inside & okv
+        d = v[ok].astype(np.float64) - shift
+        _arr(cnt, window, np.uint64)[...] = np.bincount(off[ok], minlength=window).astype(np.uint64)
+        _arr(s1, window, np.float64)[...] = np.bincount(off[ok], weights=d, minlength=window)
+        _arr(s2, window, np.float64)[...] = np.bincount(off[ok], weights=d * d, minlength=window)
+        lo, hi = _arr(mn, window, vt), _arr(mx, window, vt)
+        lo[...] = np.inf
+        hi[...] = -np.inf
+        np.minimum.at(lo, off[ok], v[ok])
+        np.maximum.at(hi, off[ok], v[ok])
+        flags = _arr(present, window, np.uint8)
+        flags[...] = 0
+        flags[off[inside & ~okv]] = 1             # (the kernel marks ids met with invalid cells only; marking more is harmless)
+        _arr(overflow, 1, np.int32)[0] = int(not inside.all())
     elif name == "xrs_memset":
         ptr, value, nbytes, _ = a
         _arr(ptr, nbytes, np.uint8)[...] = value

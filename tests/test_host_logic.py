@@ -568,3 +568,41 @@ def test_user_callables_host_logic(monkeypatch, golden, golden_tables):
             want[y, x] = np.nansum(w) + np.isnan(w).sum()
     np.testing.assert_array_equal(got.data, want)
     assert got.data.dtype == np.float32
+
+
+def test_zonal_one_pass_window_host_logic(monkeypatch):
+    """zonal._one_pass_partials on the CPU stand-in of the C ABI: the window guessed from the strided sample, ids listed like
+    np.unique does (a zone with invalid cells only is there with count 0), the overflow flag and the too-wide range sending
+    the call to the two-pass route -- and zonal.stats giving the oracle's table either way."""
+    from tests import fake_hip
+    from oracle import xrs_oracle as orc
+    from xrspatial_amd import zonal as zmod
+    import xrspatial_amd as xs
+    fake_hip.install(monkeypatch)
+    rng = np.random.default_rng(3)
+    rows, cols = 120, 200
+    zones = (5000 + 3 * (((np.arange(rows)[:, None] // 11) * 7 + np.arange(cols)[None, :] // 23) % 60)).astype(np.int32)
+    vals = (rng.normal(100, 5, (rows, cols))).astype(np.float32)
+    vals[rng.random(vals.shape) < 0.02] = np.nan
+    vals[zones == zones[60, 100]] = np.nan                     # a zone without one valid cell
+    stats = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    zd, vd = xs.DeviceArray.from_numpy(zones), xs.DeviceArray.from_numpy(vals)
+    one = zmod._one_pass_partials(zd, vd, None)
+    assert one is not None
+    np.testing.assert_array_equal(one[0], np.unique(zones))
+    assert one[1][list(one[0]).index(int(zones[60, 100]))] == 0
+    got = xs.zonal_stats(xs.DataArray(zd), xs.DataArray(vd), stats_funcs=stats)
+    want = orc.zonal_stats(zones, vals, stats_funcs=stats)
+    np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'])
+    for col in stats:
+        np.testing.assert_allclose(got[col].to_numpy(), want[col], rtol=1e-6, equal_nan=True, err_msg=col)
+    # one stray id the sample cannot see -> overflow -> two passes, same table; ids spread wider than any window -> no attempt
+    stray = zones.copy()
+    stray[7, 9] = 3_000_000
+    assert zmod._one_pass_partials(xs.DeviceArray.from_numpy(stray), vd, None) is None
+    got = xs.zonal_stats(xs.DataArray(xs.DeviceArray.from_numpy(stray)), xs.DataArray(vd), stats_funcs=['count', 'mean'])
+    want = orc.zonal_stats(stray, vals, stats_funcs=['count', 'mean'])
+    np.testing.assert_array_equal(got['zone'].to_numpy(), want['zone'])
+    np.testing.assert_allclose(got['count'].to_numpy(), want['count'], equal_nan=True)
+    wide = (zones * 200).astype(np.int32)
+    assert zmod._one_pass_partials(xs.DeviceArray.from_numpy(wide), vd, None) is None

@@ -191,6 +191,7 @@ struct WideWalk {
                                    // completes, one byte per owned column
     int lost_slot;                 // (wave-uniform) t mod K of the current step
     int span_total;                // (wave-uniform) NaN cells the rows of this tile have shown their worst lane, summed
+    int lost_o[NC];                // the lost-ring entry of the output row this step completes (read early: its latency hides behind the row's sums)
     int t;                         // input row counter: row y_first + t
     // ---- constants of the tile
     const WalkGeom &g;
@@ -310,6 +311,16 @@ struct WideWalk {
         }
     }
 
+    // The lane index as a value the compiler cannot trace back to `lane`: addresses derived from it are then computed where they are
+    // used -- in the rare NaN blocks -- instead of being hoisted out of the round loop as loop invariants, where there is no
+    // register for them: they were SPILLED, and their reload in the rare block waits with `s_waitcnt vmcnt(0)`, which drains the
+    // DMA ring (8 rows in flight) on every row that holds NaN: 25x25 mean at 0.1 % NaN 1.06 instead of 0.8x ms.
+    __device__ __forceinline__ int lane_here() const {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    }
+
     // (NANOK) the input row of this step holds NaN: every lane overwrites the NaN among ITS cells of the row in the ring (staged
     // cells NC l .. NC l + NC - 1; the first 2 HL / NC lanes also the halo cells TW + NC l ..) with the shift -- a cell equal to
     // the shift adds nothing to any sum -- and notes their positions in the bitmap (bit s = staged cell s).  Then every lane
@@ -318,14 +329,15 @@ struct WideWalk {
     // compile-time masks; ~100 instructions and 2R+1 read-modify-writes of LDS on the rare row, one read at every output.
     __device__ __forceinline__ void mark_row(float *row, int i) {
         typedef float ldsNC __attribute__((ext_vector_type(NC)));
+        const int ln = lane_here();
         unsigned *bm = nanmap;
-        if (lane < NMW) bm[lane] = 0u;
+        if (ln < NMW) bm[ln] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                       // (LDS serves one wave's instructions in order)
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            if (part && lane >= 2 * HL / NC) break;
-            const int s0 = (part ? TW : 0) + NC * lane;
+            if (part && ln >= 2 * HL / NC) break;
+            const int s0 = (part ? TW : 0) + NC * ln;
             ldsNC *p = reinterpret_cast<ldsNC *>(row + s0);
             ldsNC v = *p;
             unsigned mine = 0u;
@@ -344,9 +356,10 @@ struct WideWalk {
     // 2R+1 output rows this input row lies under, the number of them inside that row's run to the lost ring
     __device__ __forceinline__ void spread_lost(int i) {
         unsigned *bm = nanmap;
+        const int ln = lane_here();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                       // (LDS serves one wave's instructions in order)
-        const int s0 = NC * lane;
+        const int s0 = NC * ln;
         const unsigned long long two = ((unsigned long long)bm[(s0 >> 5) + 1] << 32) | bm[s0 >> 5];
         const unsigned span = (unsigned)(two >> (s0 & 31));    // bit k: the lane's cell w[k] of this row is NaN
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -366,9 +379,9 @@ struct WideWalk {
             if (!C::level_used(h)) continue;
 #pragma unroll
             for (int o = 0; o < NC; ++o) lvl[h] |= (unsigned)__popc((span >> (HL + o - h)) & ((2u << (2 * h)) - 1u)) << (8 * o);
-            lvl[h] <<= 16 * (lane & 1);
+            lvl[h] <<= 16 * (ln & 1);
         }
-        unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (lane >> 1);
+        unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (ln >> 1);
 #pragma unroll
         for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
             if (i + j < 2 * R) continue;                       // (the run-in: steps that complete no output row never read their slot)
@@ -379,8 +392,8 @@ struct WideWalk {
 
     // (NANOK) NaN cells under the windows of the output row this step completes: the lane's entry of the lost ring, cleared
     // for the step that will use the slot next
-    __device__ __forceinline__ void lost_cells(int (&lost)[NC]) const {
-        unsigned short *p = lostring + lost_slot * 64 + lane;
+    __device__ __forceinline__ void lost_cells(int (&lost)[NC]) {
+        unsigned short *p = lostring + lost_slot * 64 + lane_here();
         const unsigned v = *p;
         *p = 0;
 #pragma unroll
@@ -414,24 +427,26 @@ struct WideWalk {
                         bad |= isinf(dh);
 #pragma unroll
                         for (int e = 0; e < NC; ++e) bad |= isinf(d[e]);
+                        const int ln = lane_here();
                         unsigned *bm = nanmap;
-                        if (lane < NMW) bm[lane] = 0u;
+                        if (ln < NMW) bm[ln] = 0u;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         unsigned mine = 0u;
 #pragma unroll
                         for (int e = 0; e < NC; ++e)
                             if (isnan(d[e])) { d[e] = 0.0f; mine |= 1u << e; }
-                        if (mine) atomicOr(&bm[(NC * lane) >> 5], mine << ((NC * lane) & 31));
+                        if (mine) atomicOr(&bm[(NC * ln) >> 5], mine << ((NC * ln) & 31));
                         if (isnan(dh)) {
                             dh = 0.0f;
-                            if (lane < 2 * HL) atomicOr(&bm[(TW + lane) >> 5], 1u << ((TW + lane) & 31));
+                            if (ln < 2 * HL) atomicOr(&bm[(TW + ln) >> 5], 1u << ((TW + ln) & 31));
                         }
                         spread_lost(i);
                         inflight |= 1u;
                         saw_nan = true;
                         if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
                     }
+                    if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
                 }
 #pragma unroll
                 for (int e = 0; e + 1 < NC; e += 2) amax = amax3(amax, d[e], d[e + 1]);
@@ -477,6 +492,7 @@ struct WideWalk {
                         saw_nan = true;
                         if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
                     }
+                    if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
                 }
 #pragma unroll
                 for (int b = 0; b < NQ; ++b) {
@@ -557,13 +573,18 @@ struct WideWalk {
                     for (int o = 0; o < NC; ++o) acc[idx][o] += S[o];
                 }
             }
-        } else if (C::SLIDE) {
-            // (EDGE) a row outside the raster: its row sum is 0
-            constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;
+        } else {
+            // (EDGE) a row outside the raster: it holds no NaN and its row sum is 0
+            if constexpr (NANOK) {
+                if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
+            }
+            if constexpr (C::SLIDE) {
+                constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;
 #pragma unroll
-            for (int o = 0; o < NC; ++o) {
-                vsum[o] -= acc[LEFT][o];
-                acc[SLOT][o] = 0.0f;
+                for (int o = 0; o < NC; ++o) {
+                    vsum[o] -= acc[LEFT][o];
+                    acc[SLOT][o] = 0.0f;
+                }
             }
         }
         // ---- the output row R rows up is complete
@@ -572,8 +593,6 @@ struct WideWalk {
             const long yo = y0 + (i - 2 * R);
             const long xo = x_tile + NC * lane;
             float res[NC];
-            int lost_o[NC];
-            if (NANOK && __builtin_expect(inflight != 0u, 0)) lost_cells(lost_o);
 #pragma unroll
             for (int o = 0; o < NC; ++o) {
                 float n = (float)C::NTAPS;

@@ -298,8 +298,9 @@ int xrs_zonal_partials_window_f64(const int32_t *zones_dev, int32_t zone_base, i
                                   double nodata, int has_nodata, double shift, uint64_t *count_dev, double *sum_dev,
                                   double *sumsq_dev, double *min_dev, double *max_dev, unsigned char *present_dev,
                                   int32_t *overflow_dev, void *stream);
-/* n_samples cells at an odd stride through both rasters -> result24_dev = { int32 zmin, zmax; double mean of the valid
- * values; uint64 number of valid values }: the id window to guess and a shift for the moments, from one tiny launch. */
+/* n_samples cells at an odd stride through both rasters -> result24_dev = { int32 zmin, zmax; double SUM of the valid
+ * values; uint64 number of valid values }: the id window to guess and (sum / count) a shift for the moments, from two tiny
+ * launches. */
 int xrs_zonal_sample_f32(const int32_t *zones_dev, const float *values_dev, int64_t n, int64_t n_samples, float nodata,
                          int has_nodata, void *result24_dev, void *stream);
 int xrs_zonal_sample_f64(const int32_t *zones_dev, const double *values_dev, int64_t n, int64_t n_samples, double nodata,

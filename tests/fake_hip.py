@@ -222,7 +222,7 @@ def call(name, *a):
             ok &= v != vt(nodata)
         out = _arr(res, 3, np.float64)
         out[:1].view(np.int32)[:2] = (ids.min(), ids.max())
-        out[1] = float(v[ok].astype(np.float64).mean()) if ok.any() else 0.0
+        out[1] = float(v[ok].astype(np.float64).sum())
         out[2:3].view(np.uint64)[0] = int(ok.sum())
     elif name in ("xrs_zonal_partials_window_f32", "xrs_zonal_partials_window_f64"):
         z, base, window, vals, n, nodata, has_nodata, shift, cnt, s1, s2, mn, mx, present, overflow, _ = a

@@ -122,7 +122,8 @@ def _one_pass_partials(zones_dev: DeviceArray, vdev: DeviceArray, nodata_values)
               stream)
     raw = res.get(stream)
     zmin, zmax = (int(v) for v in raw[:1].view(np.int32)[:2])
-    shift = float(np.rint(raw[1])) if int(raw[2:3].view(np.uint64)[0]) else 0.0     # (an integer, like _pick_shift's)
+    n_valid = int(raw[2:3].view(np.uint64)[0])
+    shift = float(np.rint(raw[1] / n_valid)) if n_valid else 0.0                    # (an integer, like _pick_shift's)
     rng = zmax - zmin + 1
     window = 256
     while window < 2 * rng:

@@ -9,7 +9,7 @@ T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -Xclang -target-feature -Xclang -packed-fp32-ops \
     -DXRS_MOM_PROBE $1 -c kxk_mom_circle.hip -o $T/probe.o -save-temps=obj 2>&1 | grep -v "not a recognized feature" || true
 S=$T/kxk_mom_circle-hip-amdgcn-amd-amdhsa-gfx950.s
-K=_ZN12_GLOBAL__N_116focal_mom_kernelILi12EN3xrs11CircleShapeELi14EEEvNS_7MomArgsE
+K=_ZN12_GLOBAL__N_116focal_mom_kernelILi12EN3xrs11CircleShapeELi${OMSET:-14}EEEvNS_7MomArgsE
 awk -v k="^$K:" '$0 ~ k {f=1} f{print} /^\.Lfunc_end/{if(f) exit}' $S > $T/kernel.s
 grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):" $S | paste - - - - - | grep "$K" | sed -E 's/\s+/ /g'
 # the interior walker's round loop: the first depth-1 loop that holds LDS-DMA instructions; from its header label to the
@@ -22,22 +22,21 @@ for i, l in enumerate(lines):
     m = re.match(r"^(\.LBB\d+_\d+):", l)
     if m:
         labels[m.group(1)] = i
-best = None
+found = []
 for lab, i in labels.items():
     ends = [j for j, l in enumerate(lines) if j > i and re.search(r"s_cbranch\w+\s+" + re.escape(lab) + r"\s*$", l)]
     if not ends:
         continue
     body = lines[i:ends[-1] + 1]
-    # (the SMALLEST loop with the DMA and a round's worth of arithmetic: the tile loop around it holds the edge walker too)
-    if any("global_load_lds" in l for l in body) and sum(1 for l in body if re.match(r"^\s+v_", l)) > 400 \
-            and (best is None or len(body) < best[2]):
-        best = (i, ends[-1], len(body), body)
-if best is None:
+    # (every loop with the DMA and a round's worth of arithmetic: the plain walk's round loop, the carrying walk's, and
+    # the tile-level loops around them -- the innermost ones are the two shortest)
+    if any("global_load_lds" in l for l in body) and sum(1 for l in body if re.match(r"^\s+v_", l)) > 400:
+        found.append((len(body), i, ends[-1], body))
+if not found:
     print("round loop not found")
-else:
-    i, j, n, body = best
+for n, i, j, body in sorted(found):
     c = lambda pat: sum(1 for l in body if re.search(pat, l))
-    counts = (c("v_readlane"), c("v_writelane"), c("^\\s+v_"), c("^\\s+s_"), c("^\\s+ds_"), c("scratch_"))
-    print("round loop (lines %d..%d): v_readlane %d, v_writelane %d, VALU %d, SALU %d, LDS %d, scratch %d" % ((i + 1, j + 1) + counts))
+    counts = (c("v_readlane"), c("v_writelane"), c("^\\s+v_"), c("^\\s+s_"), c("^\\s+ds_"), c("scratch_"), c("global_load_lds"), c("vmcnt\\(0\\)"))
+    print("loop (lines %d..%d): v_readlane %d, v_writelane %d, VALU %d, SALU %d, LDS %d, scratch %d, DMA %d, vmcnt(0) %d" % ((i + 1, j + 1) + counts))
 PY
-rm -rf $T
+[ -n "$KEEP" ] && cp $T/kernel.s $KEEP; rm -rf $T

@@ -60,8 +60,25 @@ __device__ __forceinline__ int mom_clipped_count(long yo, long x, long y_lo, lon
 // cells outside (a reader turns them into w = 0), divisors = the geometric count of in-raster cells under each window,
 // ONE shift per lane for the whole tile (no re-centring: the number of cells a partial sum has seen is not a compile-time
 // constant here).  The guard is the same, so on steep relief an edge tile is more likely to end in the exact walker.
-template <int R, typename Shape, int OM, bool EDGE>
+#ifndef XRS_MOM_CARRY_ALWAYS
+#define XRS_MOM_CARRY_ALWAYS 1    // the carrying walk's output rows: 1 = always through the lost ring (no branch), 0 = only under NaN rows
+#endif
+// CARRY (interior tiles, solid shapes): nodata carried by the walk itself -- the second walk of a tile whose first, plain walk
+// met a NaN (the scheme of wide_impl.h's carrying walk).  At the head of a step the lanes vote on the cells of the row that has
+// just landed in the ring; a row that holds NaN has them overwritten IN THE RING with `fill`, one finite value per tile, and
+// their positions noted in a bitmap; every lane then takes the bits under its own windows and adds, for each of the 2R+1
+// output rows the input row lies under, the number of them inside that row's run to a ring of lost counts in LDS.  From there
+// on a nodata cell is an ordinary cell of value `fill`: the prefix sums, the ring, the re-centring with its compile-time
+// cell counts are the plain walk's.  An output row whose windows lost L cells takes them out again: S -= L (fill - c),
+// Q -= L (fill - c)^2, n = ntaps - L -- the sums are about the lane's CURRENT shift c, whatever it was when the cells went
+// in.  The guard sees the Q that was summed (fill cells included: they are what the rounding happened on), so a fill value
+// far from the window (a tile with more relief than 20 - 40 window standard deviations) fails it and the tile goes on
+// to the NaN-aware walker as before; so do +-inf, dense nodata and windows with fewer than half their cells.
+template <int R, typename Shape, int OM, bool EDGE, bool CARRY = false>
 struct MomWalk {
+    static constexpr bool NANOK = CARRY && !EDGE && !shape_has_hole<Shape>(R) && MomCfg<R, Shape>::NC == 2 &&
+                                  MomCfg<R, Shape>::NV <= 32 && MomCfg<R, Shape>::CELLS <= 160;
+    static constexpr int NMW = 6;  // words of the bitmap (CELLS <= 160 bits, + one the last lane's read may touch)
     static constexpr int NO = OM == 0 ? 1 : ((OM & 1) + (OM >> 1 & 1) + (OM >> 2 & 1) + (OM >> 3 & 1));
     __device__ __forceinline__ bool want(int bit, const float *p) const { return OM ? (OM & bit) != 0 : p != nullptr; }
     using C = MomCfg<R, Shape>;
@@ -89,6 +106,13 @@ struct MomWalk {
     const float *dma_src;          // interior: (wave-uniform) first staged cell of the next row to DMA; the rows are taken in order,
     int dma_adv;                   // so the pointer advances by a row per DMA (dma_adv more times: rows past the tile repeat the last)
     long out_off;                  // interior: offset of the wave tile's next output row in every plane
+    // ---- CARRY
+    float fill;                    // (wave-uniform) the value a nodata cell is replaced with in the ring
+    unsigned inflight;             // (wave-uniform) bit b: input row t - b held NaN cells
+    int lost_slot;                 // (wave-uniform) t mod K of the current step
+    int span_total;                // (wave-uniform) NaN cells the rows of this tile have shown their worst lane, summed
+    unsigned *nanmap;              // LDS: NMW words, the NaN bitmap of the row being marked: bit s = staged cell s is NaN
+    unsigned short *lostring;      // LDS: [K][64] -- slot (step mod K), lane
 
     __device__ __forceinline__ MomWalk(const MomArgs &a_, float *lds_, long xt, long y0_, long ye, int lane_)
         : a(a_), g(a_.g), lds(lds_), x_tile(xt), y0(y0_), lane(lane_) { y_end = ye; }
@@ -119,7 +143,11 @@ struct MomWalk {
         dma_src += dma_adv > 0 ? g.ld_in : 0;
         --dma_adv;
         constexpr int QMAX = C::CELLS / 4 - 1;
-        glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), ring_addr + (unsigned)slot * (C::RBF * 4));
+        // (CARRY: the lane's DMA offset computed afresh per row -- four instructions -- instead of living in a register the
+        // carrying walk does not have: radius 12 with four planes spilled exactly one)
+        int ln = lane;
+        if constexpr (NANOK) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        glds16_s(p, 16u * (unsigned)(ln < QMAX ? ln : QMAX), ring_addr + (unsigned)slot * (C::RBF * 4));
     }
 
     __device__ __forceinline__ void init() {
@@ -162,6 +190,20 @@ struct MomWalk {
         const float *p0 = g.in + y_first * g.ld_in + x_tile + NC * lane;
         const float c0 = 0.25f * ((p0[0] + p0[NC - 1]) + (p0[g.ld_in] + p0[g.ld_in + NC - 1]));
         c = isfinite(c0) ? c0 : 0.0f;
+        if constexpr (NANOK) {
+            // the fill value: the cell at the tile centre, or the first finite one of the 64 to its left
+            const long yc = y0 + (y_end - y0) / 2, xc = x_tile + TW / 2;
+            const float cand = g.in[yc * g.ld_in + (xc - lane >= 0 ? xc - lane : 0)];
+            const unsigned long long fin = __ballot(isfinite(cand));
+            fill = fin ? __shfl(cand, __builtin_ctzll(fin)) : 0.0f;
+            fill = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fill)));
+            if (!isfinite(c0)) c = fill;
+            inflight = 0u;
+            lost_slot = K - 1;
+            span_total = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) lostring[j * 64 + lane] = 0;
+        }
         c_next = c;
         dma_src = uniform_ptr(g.in + y_first * g.ld_in + (x_tile - HL));
         dma_adv = n_in - 1;
@@ -180,10 +222,88 @@ struct MomWalk {
 #ifdef XRS_FLOOR_NO_STORES                                     // (tools/floor_probe.sh: the walk without its output streams)
         if (g.rows >= 0) return;
 #endif
-        const unsigned lane_b = (unsigned)(NC * 4) * (unsigned)lane;
+        const unsigned lane_b = (unsigned)(NC * 4) * (unsigned)(NANOK ? lane_here() : lane);
         if (NC == 2) { lds_dma_v2f q; q[0] = v[0]; q[1] = v[NC - 1]; st_row_nt(uniform_ptr(p), lane_b, q); }
         else if (NC == 1) st_row_nt(uniform_ptr(p), lane_b, v[0]);
         else __builtin_nontemporal_store(v, reinterpret_cast<stNC *>(reinterpret_cast<char *>(p) + lane_b));
+    }
+
+    // (CARRY) The lane index as a value the compiler cannot trace back to `lane`: addresses derived from it are computed where
+    // they are used -- in the rare NaN blocks -- instead of being hoisted out of the round loop as loop invariants, where
+    // there is no register for them (wide_impl.h: a spilled address is reloaded behind `s_waitcnt vmcnt(0)`, which drains
+    // the DMA ring)
+    // -- and computed afresh rather than copied: nothing of it stays live across the loop
+    __device__ __forceinline__ int lane_here() const {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    }
+
+    // (CARRY) the input row of this step holds NaN: every lane overwrites the NaN among ITS cells of the row in the ring (staged
+    // cells NC l .. NC l + NC - 1; the first 2 HL / NC lanes also the halo cells TW + NC l ..) with `fill` and notes their
+    // positions in the bitmap (bit s = staged cell s); then the lost counts of the 2R+1 output rows under it
+    __device__ __forceinline__ bool mark_row(float *row, int i) {
+        const int ln = lane_here();
+        unsigned *bm = nanmap;
+        if (ln < NMW) bm[ln] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (LDS serves one wave's instructions in order)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if (part && ln >= 2 * HL / NC) break;
+            const int s0 = (part ? TW : 0) + NC * ln;
+            ldsNC *p = reinterpret_cast<ldsNC *>(row + s0);
+            ldsNC v = *p;
+            unsigned mine = 0u;
+#pragma unroll
+            for (int e = 0; e < NC; ++e)
+                if (isnan(v[e])) { v[e] = fill; mine |= 1u << e; }
+            if (mine) {
+                *p = v;
+                atomicOr(&bm[s0 >> 5], mine << (s0 & 31));     // (NC cells at a multiple of NC: never across two words)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int s0 = NC * ln;
+        const unsigned long long two = ((unsigned long long)bm[(s0 >> 5) + 1] << 32) | bm[s0 >> 5];
+        const unsigned span = (unsigned)(two >> (s0 & 31));    // bit k: the lane's cell w[k] of this row is NaN
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (the next marked row clears the bitmap)
+        // lost counts are bytes: once the rows of this tile have shown a lane more than 255 NaN cells in all (the sum of the
+        // rows' worst lanes: a scalar) the tile is handed on (dense nodata); below that no byte of the ring can overflow
+        span_total += wave_reduce<WrMax>(__popc(span & ((1u << NV) - 1u)));
+        // every distinct half-width once (both owned columns packed: byte o), then one LDS add per output row in flight; the
+        // ring holds one 16-bit entry per lane, two lanes to a word: an atomic add of the entry shifted to the lane's half
+        constexpr ShapeRows<R, Shape> T{};
+        unsigned lvl[R + 1];
+#pragma unroll
+        for (int h = 0; h <= R; ++h) {
+            lvl[h] = 0u;
+            if (!C::level_used(h)) continue;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) lvl[h] |= (unsigned)__popc((span >> (HL + o - h)) & ((2u << (2 * h)) - 1u)) << (8 * o);
+            lvl[h] <<= 16 * (ln & 1);
+        }
+        unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (ln >> 1);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
+            if (i + j < 2 * R) continue;                       // (the run-in: steps that complete no output row never read their slot)
+            const int slot = lost_slot + j < K ? lost_slot + j : lost_slot + j - K;
+            __hip_atomic_fetch_add(ring32 + slot * 32, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return span_total > 255;
+    }
+
+    // (CARRY) NaN cells under the windows of the output row this step completes: the lane's entry of the lost ring, cleared
+    // for the step that will use the slot next
+    __device__ __forceinline__ unsigned lost_cells() {
+        unsigned short *p = lostring + lost_slot * 64 + lane_here();
+        const unsigned v = *p;
+        unsigned zero;                                         // (a fresh zero: a constant one would live in a register across the loop)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        *p = (unsigned short)zero;
+        return v;
     }
 
     template <int PHASE, bool SQ>
@@ -289,7 +409,31 @@ struct MomWalk {
             // row i was issued D steps ago; younger: D DMAs and -- once the walk emits, from row 2R on -- NO stores per step
             if (i >= 2 * R + D) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D * (1 + NO)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");
-            row = ring_addr + (unsigned)slot_out * (C::RBF * 4) + (unsigned)(NC * 4) * (unsigned)lane;
+            row = ring_addr + (unsigned)slot_out * (C::RBF * 4) + (unsigned)(NC * 4) * (unsigned)(NANOK ? lane_here() : lane);
+            if constexpr (NANOK) {
+                // ---- the row landed in the ring (raw cells): a look at the lane's OWN cells of it (the NC it stages for the wave,
+                // the first lanes also the halo cells), a wave-wide vote, and a row that holds NaN is repaired and counted
+                // BEFORE anybody reads it
+                inflight = (inflight << 1) & ((1u << K) - 1u);
+                lost_slot = lost_slot + 1 == K ? 0 : lost_slot + 1;          // == i mod K (init: K - 1)
+                float *rowp = lds + slot_out * C::RBF;
+                typedef __attribute__((address_space(3))) const ldsNC lds_cvec;
+                const int ln = lane_here();
+                const unsigned halo_b = ln < 2 * HL / NC ? 4u * (unsigned)TW : 0u;     // (the other lanes look at their own cells twice)
+                const ldsNC a0 = *(lds_cvec *)(size_t)row, a1 = *(lds_cvec *)(size_t)(row + halo_b);
+                bool nn = false;
+#pragma unroll
+                for (int e = 0; e < NC; ++e) nn |= !isfinite(a0[e]) || !isfinite(a1[e]);
+                if (__builtin_expect(__any(nn) != 0, 0)) {        // rare, wave-uniform
+                    bool inf = false;
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) inf |= isinf(a0[e]) || isinf(a1[e]);          // +-inf: the tile is handed on
+                    inflight |= 1u;
+                    // (dense nodata: the NaN-aware walker is the faster one)
+                    const bool stop = mark_row(rowp, i) || __popc(inflight) > 18 || __any(inf);
+                    badm |= (unsigned long long)__builtin_amdgcn_readfirstlane(stop ? 1 : 0);   // (a scalar: the verdicts stay in SGPRs)
+                }
+            }
             slot_out = slot_out + 1 == D + 1 ? 0 : slot_out + 1;
         }
 
@@ -352,6 +496,37 @@ struct MomWalk {
             out_off += g.ld_out;
             constexpr float inv = 1.0f / (float)C::NTAPS;
             stNC r_sum, r_mean, r_var, r_std;
+            // (wave-uniform) NaN rows under this output row's windows.  (Marked likely -- at 0.1 % nodata it is 97 % of the output
+            // rows -- the block moves in line and the round loop spills 10 registers; out of line it is the block that spills,
+            // the one of the round's last step only: one column at a time there, below)
+            if (NANOK && (XRS_MOM_CARRY_ALWAYS || __builtin_expect(inflight != 0u, 0))) {
+                const unsigned lost_pk = lost_cells();
+                const float dl = fill - c, dl2 = dl * dl;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    const unsigned lost = (lost_pk >> (8 * o)) & 255u;
+                    const float L = (float)lost;
+                    const float n = (float)C::NTAPS - L;
+                    // (v_rcp_f32, 1 ulp, for every window -- choosing the plain walk's constant for windows that lost nothing costs
+                    // a compare whose zero wants a vector register, and there is none to spare: radius 12 with four planes spilled it)
+                    const float rn = __builtin_amdgcn_rcpf(n);
+                    const float Qa = accQ[DONE][o];                            // as summed: what the rounding happened on
+                    const float S = fmaf(-L, dl, accS[DONE][o]), Q = fmaf(-L, dl2, Qa);
+                    const float ms = S * rn;
+                    const float mean = c + ms;
+                    const float e = Q - S * ms;
+                    const float B = Qa + dqn;
+                    badm |= __builtin_amdgcn_ballot_w64(!(e >= 0.2f * B));
+                    badm |= __builtin_amdgcn_ballot_w64(!(mean * mean * n >= (gm * (float)C::NTAPS) * B));
+                    badm |= __builtin_amdgcn_ballot_w64(L > 0.5f * (float)C::NTAPS);
+                    const float var = e * rn;
+                    r_mean[o] = mean;
+                    r_var[o] = var;
+                    r_std[o] = __builtin_amdgcn_sqrtf(var);           // (v_sqrt_f32, 1 ulp: sqrtf's correction steps want five more registers)
+                    r_sum[o] = fmaf(n, c, S);
+                    __builtin_amdgcn_sched_barrier(0);             // (the columns one after the other: fewer values alive at once)
+                }
+            } else
 #pragma unroll
             for (int o = 0; o < NC; ++o) {
                 const float S = accS[DONE][o], Q = accQ[DONE][o];
@@ -401,20 +576,30 @@ struct MomWalk {
 #ifndef XRS_MOM_T_NONANSTOP
         badm |= __builtin_amdgcn_ballot_w64(c != c);             // a NaN under the round's runs: stop now, not 2R rows later
 #endif
-        dq_old = fmaxf(dq_last * C::HIST_FIRST, dq_old * C::HIST_DECAY);
-        dq_last = d * d;
-        dqn = (float)C::NTAPS * fmaxf(dq_last, dq_old);
+        if constexpr (NANOK) {
+            // (the carrying walk has no registers for the two-term history: ONE decaying maximum, x 0.85 per round -- 0.85, 0.72,
+            // 0.61, 0.52: never below MomCfg's table either, a little more conservative than the plain walk's)
+            dqn = fmaxf((float)C::NTAPS * (d * d), dqn * C::HIST_FIRST);
+        } else {
+            dq_old = fmaxf(dq_last * C::HIST_FIRST, dq_old * C::HIST_DECAY);
+            dq_last = d * d;
+            dqn = (float)C::NTAPS * fmaxf(dq_last, dq_old);
+        }
     }
 
     template <int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         if (EDGE) (load_row(t + P, pf_own[P], pf_halo[P]), ...);      // edge tiles: all loads of the round first
+        // (CARRY: the re-centring at the head of the NEXT round instead of behind this round's last step -- the same place in the
+        // walk, another place in the code: behind the last step its arithmetic was scheduled into that step's out-of-line nodata
+        // output block, which then spilled 20 registers)
+        if (NANOK && t > 0) recentre(std::make_integer_sequence<int, K>{});
         (step<P>(), ...);
         ring_rotate<K, U>(accS);
         ring_rotate<K, U>(accQ);
         t += U;
 #ifndef XRS_MOM_T_NORECENTRE
-        if (!EDGE) recentre(std::make_integer_sequence<int, K>{});
+        if (!EDGE && !NANOK) recentre(std::make_integer_sequence<int, K>{});
 #endif
     }
 
@@ -446,6 +631,9 @@ __device__ __forceinline__ void mom_exact_tile(const MomArgs &a, long x_tile, in
     }
 }
 
+#ifndef XRS_MOM_CARRY
+#define XRS_MOM_CARRY 1           // NaN tiles: the carrying walk before the NaN-aware one-column walker
+#endif
 #ifndef XRS_MOM_WAVES
 #define XRS_MOM_WAVES 2           // workgroups per CU = waves per SIMD
 #endif
@@ -453,6 +641,9 @@ template <int R, typename Shape, int OM>
 __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const MomArgs a) {
     using C = MomCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float lds_rows[4][(C::D + 1) * C::RBF];
+    constexpr bool CARRIES = XRS_MOM_CARRY && OM != 0 && MomWalk<R, Shape, OM, false, true>::NANOK;
+    __shared__ unsigned nan_row[4][8];                         // per wave: the NaN bitmap of the row being marked
+    __shared__ unsigned short lost_ring[4][CARRIES ? C::K * 64 : 1];   // per wave: NaN cells under the windows in flight
     long ty, gx;
     if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     if (std::is_same<Shape, BoxShape>::value && a.todo && !a.todo[ty * a.groups_x + gx]) return;   // (boxsep.hip did this tile)
@@ -492,6 +683,20 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
         return;
     }
 #endif
+    // NaN cells under a window (scattered nodata, a nodata region's rim): the SAME two-column walk again, this time carrying
+    // them (MomWalk<.., CARRY>: ~1.2x a plain walk; the plain walk in front of it stopped at the first round that met a
+    // NaN, so a clean raster pays nothing).  Interior tiles of solid shapes with a compile-time plane set.
+    if constexpr (CARRIES) {
+        if (interior) {
+            MomWalk<R, Shape, OM, false, true> w(a, lds_rows[wv], x_tile, y0, y_end, lane);
+            w.nanmap = nan_row[wv];
+            w.lostring = lost_ring[wv];
+            if (w.run()) return;
+#ifdef XRS_MOM_CARRY_ONLY          // (probe builds: what the carrying walk alone costs, and which tiles it hands on -- their outputs stay unwritten)
+            return;
+#endif
+        }
+    }
     // otherwise the NaN-aware float32 walker, 64 columns at a time; what fails THAT guard (+-inf, windows with a few valid
     // cells at the edge of a nodata region, ill-conditioned sums) goes to the exact float64 walker.
     // (Tried: the four waves of the workgroup sharing those exact walks behind a barrier -- a nodata boundary leaves one

@@ -208,3 +208,51 @@ def test_large_window_mean_sum_carry_nodata(kind, radius):
                 n = float(np.count_nonzero(k == 1))
                 np.testing.assert_allclose(got[fin], want[fin], rtol=max(RTOL, 1.01 * (n - 1) * 2.0 ** -24), atol=0,
                                            err_msg=f"{kind} r={radius} {name} sum")
+
+
+@pytest.mark.parametrize("kind,radius", [("circle", 12), ("circle", 7), ("circle", 4), ("box", 12), ("box", 6)])
+def test_large_window_moments_carry_nodata(kind, radius):
+    """mean / var / std (and the seven statistics) over large windows on rasters with nodata (mom_impl.h: a tile whose plain
+    walk meets a NaN is walked again by the same two-column walker CARRYING the NaN cells -- in-ring repair with one fill value
+    per tile, lost ring in LDS, S -= L (fill - c), Q -= L (fill - c)^2 at the output): scattered NaN at 0.1 % and 2 %, NaN at the
+    cells the shift and the fill value are taken from, NaN along the raster's edges (edge tiles: the NaN-aware one-column
+    walker, whose first shift at the TOP edge comes from rows inside the raster), a raster with a cliff through its tiles (fill
+    value hundreds of window standard deviations from one side: the guard has to hand those tiles on), a dense patch, a
+    nodata block larger than the window and +-inf -- against the oracle, NaN patterns exactly; extrema bit-exact."""
+    from xrspatial_amd.convolution import circle_kernel
+    K = 2 * radius + 1
+    k = circle_kernel(1, 1, radius) if kind == "circle" else np.ones((K, K))
+    rows, cols = 700, 1500
+    rng = np.random.default_rng(200 * radius + (kind == "box"))
+    base = (1000.0 + 40.0 * np.sin(np.arange(cols)[None, :] / 90.0) * np.cos(np.arange(rows)[:, None] / 70.0)
+            + rng.normal(0, 2.0, (rows, cols))).astype(np.float32)
+    cases = {}
+    z = base.copy(); z[rng.random(z.shape) < 1e-3] = np.nan; cases["0.1 % scattered"] = z
+    z = base.copy(); z[rng.random(z.shape) < 0.02] = np.nan; cases["2 % scattered"] = z
+    z = base.copy(); z[::13, 64::128] = np.nan; z[65::130, ::17] = np.nan; z[:40:3, ::2] = np.nan; cases["tile centres, first rows, a lattice"] = z
+    z = base.copy(); z[:3, ::7] = np.nan; z[-2:, 5::11] = np.nan; z[::9, :2] = np.nan; z[4::10, -3:] = np.nan; cases["raster edges"] = z
+    z = base.copy(); z[:, 700:] += 5000.0; z[:, 1100:] -= 9000.0; z[rng.random(z.shape) < 5e-4] = np.nan; cases["cliffs through the tiles"] = z
+    z = base.copy(); z[300:420, 500:800][rng.random((120, 300)) < 0.6] = np.nan; z[500:500 + 2 * K + 5, 900:900 + 3 * K] = np.nan
+    z[100, 1200] = np.inf; z[600, 300] = -np.inf; cases["dense patch, nodata block, inf"] = z
+    for name, z in cases.items():
+        agg = xs.DataArray(xs.DeviceArray.from_numpy(z), dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+        with np.errstate(all='ignore'):
+            want = {st: corc.focal_apply(z, k, st, nthreads=8) for st in ('mean', 'max', 'min', 'range', 'std', 'var', 'sum')}
+        for funcs in (['mean', 'var', 'std'], ['mean', 'max', 'min', 'range', 'std', 'var', 'sum']):
+            got = focal_stats(agg, k, stats_funcs=funcs).data.get()
+            for i, st in enumerate(funcs):
+                msg = f"{kind} r={radius} {name} {st} of {len(funcs)}"
+                g, w = got[i], want[st]
+                assert (np.isnan(g) == np.isnan(w)).all(), msg + ": NaN pattern"
+                fin = np.isfinite(w)
+                assert (g[~fin & ~np.isnan(w)] == w[~fin & ~np.isnan(w)]).all(), msg + ": infinities"
+                if st in ('max', 'min', 'range'):
+                    np.testing.assert_array_equal(g[fin], w[fin], err_msg=msg)
+                elif st == 'sum':
+                    n = float(np.count_nonzero(k == 1))
+                    np.testing.assert_allclose(g[fin], w[fin], rtol=max(RTOL, 1.01 * (n - 1) * 2.0 ** -24), atol=0, err_msg=msg)
+                else:
+                    # (std of a flat window next to a cliff: sqrt halves the exponent of a tiny variance -- absolute 1e-5 of the mean's scale)
+                    np.testing.assert_allclose(g[fin], w[fin], rtol=RTOL, atol=0, err_msg=msg)
+                    parity_log.record("large-window moments on nodata (carrying walk), 700x1500", f"{kind} {K}x{K} {name} {st}", g[fin], w[fin],
+                                      tol="rtol 1e-5")

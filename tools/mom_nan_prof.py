@@ -1,5 +1,7 @@
+"""rocprofv3 --kernel-trace --stats target: the large-window moments / extrema kernels on the benchmark DEM with 0.1 % nodata
+(per-kernel durations of focal_stats with 25x25 circle and box masks).  cd /tmp && rocprofv3 --kernel-trace --stats -- python tools/mom_nan_prof.py"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import xrspatial_amd as xs
 from xrspatial_amd import focal

@@ -242,7 +242,7 @@ struct MomWalk {
     // (CARRY) the input row of this step holds NaN: every lane overwrites the NaN among ITS cells of the row in the ring (staged
     // cells NC l .. NC l + NC - 1; the first 2 HL / NC lanes also the halo cells TW + NC l ..) with `fill` and notes their
     // positions in the bitmap (bit s = staged cell s); then the lost counts of the 2R+1 output rows under it
-    __device__ __forceinline__ bool mark_row(float *row, int i) {
+    __device__ __forceinline__ bool mark_row(float *row) {
         const int ln = lane_here();
         unsigned *bm = nanmap;
         if (ln < NMW) bm[ln] = 0u;
@@ -288,7 +288,8 @@ struct MomWalk {
         unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (ln >> 1);
 #pragma unroll
         for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
-            if (i + j < 2 * R) continue;                       // (the run-in: steps that complete no output row never read their slot)
+            // (no test for the run-in here -- 25 scalar branches in this block: a step that completes no output row clears
+            // its slot instead, step())
             const int slot = lost_slot + j < K ? lost_slot + j : lost_slot + j - K;
             __hip_atomic_fetch_add(ring32 + slot * 32, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -430,7 +431,7 @@ struct MomWalk {
                     for (int e = 0; e < NC; ++e) inf |= isinf(a0[e]) || isinf(a1[e]);          // +-inf: the tile is handed on
                     inflight |= 1u;
                     // (dense nodata: the NaN-aware walker is the faster one)
-                    const bool stop = mark_row(rowp, i) || __popc(inflight) > 18 || __any(inf);
+                    const bool stop = mark_row(rowp) || __popc(inflight) > 18 || __any(inf);
                     badm |= (unsigned long long)__builtin_amdgcn_readfirstlane(stop ? 1 : 0);   // (a scalar: the verdicts stay in SGPRs)
                 }
             }
@@ -548,6 +549,10 @@ struct MomWalk {
             if (want(MOM_VAR, a.out_var)) store_row(a.out_var + rowoff, r_var);
             if (want(MOM_STD, a.out_std)) store_row(a.out_std + rowoff, r_std);
             if (want(MOM_SUM, a.out_sum)) store_row(a.out_sum + rowoff, r_sum);
+        }
+        if constexpr (NANOK) {
+            // (the run-in: what NaN rows added for a step that completes no output row is dropped here, before the slot comes round again)
+            if (i < 2 * R) (void)lost_cells();
         }
 #pragma unroll
         for (int o = 0; o < NC; ++o) { accS[DONE][o] = 0.0f; accQ[DONE][o] = 0.0f; }

@@ -384,7 +384,8 @@ struct WideWalk {
         unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (ln >> 1);
 #pragma unroll
         for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
-            if (i + j < 2 * R) continue;                       // (the run-in: steps that complete no output row never read their slot)
+            // (no test for the run-in here -- it was 25 scalar branches in this block: a step that completes no output row
+            // reads and clears its slot like any other, process())
             const int slot = lost_slot + j < K ? lost_slot + j : lost_slot + j - K;
             __hip_atomic_fetch_add(ring32 + slot * 32, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -446,7 +447,7 @@ struct WideWalk {
                         saw_nan = true;
                         if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
                     }
-                    if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
+                    if (__builtin_expect(inflight != 0u, 0)) lost_cells(lost_o);        // (run-in steps too: what was added for them is dropped)
                 }
 #pragma unroll
                 for (int e = 0; e + 1 < NC; e += 2) amax = amax3(amax, d[e], d[e + 1]);
@@ -492,7 +493,7 @@ struct WideWalk {
                         saw_nan = true;
                         if (__popc(inflight) > 18) bad = true;         // (dense nodata: the NaN-aware walker is the faster one)
                     }
-                    if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
+                    if (__builtin_expect(inflight != 0u, 0)) lost_cells(lost_o);        // (run-in steps too: what was added for them is dropped)
                 }
 #pragma unroll
                 for (int b = 0; b < NQ; ++b) {
@@ -576,7 +577,7 @@ struct WideWalk {
         } else {
             // (EDGE) a row outside the raster: it holds no NaN and its row sum is 0
             if constexpr (NANOK) {
-                if (__builtin_expect(inflight != 0u, 0) && i >= 2 * R) lost_cells(lost_o);
+                if (__builtin_expect(inflight != 0u, 0)) lost_cells(lost_o);        // (run-in steps too: what was added for them is dropped)
             }
             if constexpr (C::SLIDE) {
                 constexpr int LEFT = ((SLOT - K) % C::KR + C::KR) % C::KR;

@@ -593,6 +593,8 @@ def run_headline(ctx):
                                               None, 0, 0, stream))
         both("focal_stats7_25x25", lambda p: L("xrs_focal_stats_f32", p, ptr7, 127, rows, cols, cols, cols, k25.ctypes.data, 25, 25,
                                                 None, 0, 0, stream))
+        both("focal_mean_var_std_25x25", lambda p: L("xrs_focal_stats_f32", p, ptr7, 1 | 16 | 32, rows, cols, cols, cols, k25.ctypes.data,
+                                                      25, 25, None, 0, 0, stream))
         both("focal_stats7_5x5", lambda p: L("xrs_focal_stats_f32", p, ptr7, 127, rows, cols, cols, cols, kernel.ctypes.data, 5, 5,
                                               None, 0, 0, stream))
         both("slope", lambda p: L("xrs_slope_f32", p, out_hill.ptr, rows, cols, cols, cols, 1.0, 1.0, 0, 0, stream))

@@ -48,6 +48,10 @@ for s in $STEPS; do
     fuzz)
       for seed in 51 52; do timeout 600 python tests/fuzz_parity.py --seed $seed --cases 1500 > $OUT/fuzz_s$seed.log 2>&1; tail -3 $OUT/fuzz_s$seed.log; done
       timeout 600 python tests/fuzz_parity.py --seed 53 --cases 40 --big > $OUT/fuzz_big.log 2>&1; tail -3 $OUT/fuzz_big.log ;;
+    momnan)
+      # per-kernel durations of the large-window moments / extrema kernels on the benchmark DEM with 0.1 % nodata
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/momnan_$TAG -o s -- python $ROOT/tools/mom_nan_prof.py > /dev/null 2>&1)
+      find /tmp/momnan_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/mom_nan_kernel_stats.csv \; ; cut -c1-180 $OUT/mom_nan_kernel_stats.csv | head -8 ;;
     s64bench)
       timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
     *) echo "unknown step $s" ;;

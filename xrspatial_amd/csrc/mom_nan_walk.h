@@ -101,6 +101,7 @@ struct MomWalkN {
     float c, snapS, snapN;                                 // the shift; sum / count of the round's widest runs about it
     float dq_last, dq_old, dqm;                            // d^2 of the last re-centring, decaying maximum of the older ones, max
     unsigned long long badm;
+    bool seeded;                                           // (wave-uniform) the first shift has been chosen
     float gmf;
     int t, n_in;
 
@@ -138,10 +139,18 @@ struct MomWalkN {
         n_in = (int)(y_end - y0) + 2 * R;
         lds_z = lds_addr(lds) + 4u * (unsigned)lane;
         c = 0.0f;
+        seeded = false;
     }
 
-    // first shift, from the rows of the first round: the mean of the lane's valid cells (staged cell `lane` = raster column
-    // x - R: close enough for a first value), else any lane's, else 0 -- the first re-centring replaces it
+    // first shift, from the rows of the FIRST ROUND THAT HOLDS A VALID CELL: the mean of the lane's valid cells (staged cell
+    // `lane` = raster column x - R: close enough for a first value), else any lane's -- the next re-centring replaces it.
+    // (Until round 5 it came from the tile's first round whatever that held: a tile whose first rows lie outside the raster
+    // -- every top-edge tile -- or inside a nodata region started about 0, met values around 1000 some rounds later and
+    // re-centred by 1000 with those cells already in its sums; the guard then failed the tile's first output rows and the
+    // whole half tile went to the exact float64 walker, ~3 ms of a lone wave.  All 128 top-edge tiles of a 16384^2 raster with
+    // scattered nodata: the launch could not end before they did, 25x25 mean + var + std 2.4 instead of 1.8 ms, with the sum
+    // plane 3.3; the tile row along the lower rim of a nodata region likewise.  Before the first valid cell every sum is
+    // zero, so the shift is free to be anything: it is simply not chosen yet.)
     __device__ __forceinline__ void first_shift() {
         float s = 0.0f, n = 0.0f;
 #pragma unroll
@@ -150,29 +159,11 @@ struct MomWalkN {
             s += ok ? pf_own[r] : 0.0f;
             n += ok ? 1.0f : 0.0f;
         }
-        if (y_first < -(long)g.halo_top) {
-            // a tile at the raster's top edge: its first rows lie outside, and a walk that starts about 0 and meets values
-            // around 1000 three rounds later re-centres by 1000 with those cells already in its sums -- the guard then fails
-            // the tile's first output rows and the whole half tile goes to the exact walker (every top-edge tile of a raster
-            // with nodata: 128 tiles of 3 ms each at 16384^2, the kernel could not end before they did: 25x25 mean + var +
-            // std 2.4 instead of 1.8 ms, with the sum plane 3.3).  The nearest rows inside the raster instead.
-            s = n = 0.0f;
-            const long xa = xw - R + lane;
-            const long xc = xa < 0 ? 0 : xa >= g.cols ? g.cols - 1 : xa;
-#pragma unroll
-            for (int r = 0; r < U; ++r) {
-                long yy = -(long)g.halo_top + r;
-                yy = yy < g.rows + g.halo_bot ? yy : g.rows + g.halo_bot - 1;
-                const float v = g.in[yy * g.ld_in + xc];
-                const bool ok = isfinite(v);
-                s += ok ? v : 0.0f;
-                n += ok ? 1.0f : 0.0f;
-            }
-        }
         const float m = n > 0.0f ? s / n : 0.0f;
         const unsigned long long have = __ballot(n > 0.0f);
         const float m_any = __shfl(m, have ? __ffsll((long long)have) - 1 : 0);      // (every lane executes the shuffle)
         c = n > 0.0f ? m : have ? m_any : 0.0f;
+        seeded = have != 0;
         c_lo = c_hi = c;
     }
 
@@ -333,7 +324,7 @@ struct MomWalkN {
     template <int... P>
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (load_row(t + P, pf_own[P], pf_halo[P]), ...);
-        if (t == 0) first_shift();
+        if (!seeded) first_shift();
         (step<P>(), ...);
         ring_rotate<K, U>(accN);
         ring_rotate<K, U>(accS);

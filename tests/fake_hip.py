@@ -134,6 +134,13 @@ def call(name, *a):
         excl = tuple(float(v) for v in _arr(ex, nex, np.float64)) if nex else ()
         view = _plane(i, rows, cols, ld_i, ht, hb, np.float64 if is64 else np.float32).copy()
         _put(o, rows, cols, ld_o, orc.focal_mean3x3(view, excl)[ht:ht + rows], np.float64)
+    elif name == "xrs_focal_mean3x3_passes":
+        i, is64, o, _scratch, passes, rows, cols, ex, nex, _ = a
+        excl = tuple(float(v) for v in _arr(ex, nex, np.float64)) if nex else ()
+        cur = _plane(i, rows, cols, cols, 0, 0, np.float64 if is64 else np.float32).astype(np.float64)
+        for _ in range(int(passes)):
+            cur = orc.focal_mean3x3(cur, excl)
+        _put(o, rows, cols, cols, cur, np.float64)
     elif name == "xrs_convolve2d_f32":
         i, o, rows, cols, ld_i, ld_o, k, kr, kc, _, ht, hb, _ = a
         kern = _kernel(k, kr, kc)

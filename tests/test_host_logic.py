@@ -606,3 +606,57 @@ def test_zonal_one_pass_window_host_logic(monkeypatch):
     np.testing.assert_allclose(got['count'].to_numpy(), want['count'], equal_nan=True)
     wide = (zones * 200).astype(np.int32)
     assert zmod._one_pass_partials(xs.DeviceArray.from_numpy(wide), vd, None) is None
+
+
+def test_dask_slot_runs_block_by_block(monkeypatch):
+    """The dask slot of the public functions (utils.py: dask_overlap / dask_blocks): the reference wraps its numpy runners in
+    map_overlap(depth, boundary=nan) / map_blocks (slope.py:86-97, aspect.py:151-160, curvature.py:56-59, hillshade.py:42-45,
+    focal.py:70-75 and 329-340, convolution.py:316-327, multispectral.py:845-848) and so does this package, around ITS numpy
+    runners.  dask is not installable here: `tests/fake_dask.py` supplies the four calls the slot makes, with dask's overlap
+    semantics, and `tests/fake_hip.py` answers the C ABI.  A dask-backed DataArray must give exactly what the numpy-backed one
+    gives -- stencils across chunk boundaries included -- and must have been computed chunk by chunk."""
+    from tests import fake_dask, fake_hip
+    from xrspatial_amd import utils, focal as xfocal, convolution
+    import xrspatial_amd as xs
+    fake_hip.install(monkeypatch)
+    monkeypatch.setattr(utils, "da", fake_dask)
+    monkeypatch.setattr(xfocal, "da", fake_dask)
+    rng = np.random.default_rng(5)
+    z = (100 + np.cumsum(rng.normal(0, 1, (37, 53)), axis=1) + rng.normal(0, 3, (37, 53))).astype(np.float32)
+    z[7, 9] = np.nan
+    z[20:23, 30:33] = np.nan
+    coords = {'y': np.arange(37)[::-1] * 2.0, 'x': np.arange(53) * 2.0}
+    host = xs.DataArray(z, dims=['y', 'x'], coords=coords, attrs={'res': (2.0, 2.0)})
+
+    def lazy(values=z, chunks=(16, 20)):
+        return xs.DataArray(fake_dask.from_array(values, chunks), dims=['y', 'x'], coords=coords, attrs={'res': (2.0, 2.0)})
+
+    k5 = convolution.circle_kernel(2, 2, 4)
+    cases = {
+        'slope': lambda a: xs.slope(a), 'aspect': lambda a: xs.aspect(a), 'curvature': lambda a: xs.curvature(a),
+        'hillshade': lambda a: xs.hillshade(a, 315, 30),
+        'focal.mean x2': lambda a: xfocal.mean(a, passes=2),
+        'focal.apply': lambda a: xfocal.apply(a, k5),
+        'focal_stats': lambda a: xfocal.focal_stats(a, k5, stats_funcs=['max', 'mean', 'std']),
+        'convolution_2d': lambda a: convolution.convolution_2d(a, k5 / k5.sum()),
+    }
+    for name, fn in cases.items():
+        want = fn(host)
+        arg = lazy()
+        got = fn(arg)
+        assert isinstance(got.data, fake_dask.Array), name                      # lazy in, lazy out -- like upstream
+        assert got.dims == want.dims and got.name == want.name, name
+        np.testing.assert_array_equal(got.data.compute(), np.asarray(want.data), err_msg=name)
+        assert got.data.compute().dtype == np.asarray(want.data).dtype, name
+        seen = got.data.blocks_seen
+        assert len(seen) >= 6 and max(s[0] for s in seen) < 37 and max(s[1] for s in seen) < 53, (name, seen)   # 3 x 3 chunks, never the whole
+    # per-cell indices: map_blocks over equally chunked bands
+    nir = rng.random((37, 53)).astype(np.float32)
+    red = rng.random((37, 53)).astype(np.float32)
+    want = xs.ndvi(xs.DataArray(nir, dims=['y', 'x']), xs.DataArray(red, dims=['y', 'x']))
+    got = xs.ndvi(lazy(nir), lazy(red))
+    assert isinstance(got.data, fake_dask.Array)
+    np.testing.assert_array_equal(got.data.compute(), want.data)
+    # a backend that has no dask slot still says so (zonal.stats on dask needs the block-partials combine: ShardedArray's job here)
+    with pytest.raises((NotImplementedError, TypeError)):
+        xfocal.hotspots(lazy(), k5)

@@ -11,7 +11,7 @@ from ._xr import DataArray
 from .dataset_support import supports_dataset
 from .device import DeviceArray
 from .geodesic import extract_latlon, run_geodesic, z_factor_of
-from .utils import ArrayTypeFunctionMapping
+from .utils import ArrayTypeFunctionMapping, dask_overlap
 
 
 def _run(data):
@@ -41,6 +41,6 @@ def aspect(agg: DataArray,
     scope = fused.current()
     if scope is not None:
         return scope.defer('aspect', agg, name, {})
-    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run, dask_func=dask_overlap(_run, (1, 1)))
     out = mapper(agg)(agg.data)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

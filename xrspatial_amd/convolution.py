@@ -15,7 +15,7 @@ from ._launch import finish, get_stream, pipeline_ok, pipelined_rows, plane_args
 from ._xr import DataArray
 from .device import DeviceArray, to_device_f32
 from .sharded import ShardedArray
-from .utils import get_dataarray_resolution
+from .utils import dask_overlap, get_dataarray_resolution, is_dask
 
 DEFAULT_UNIT = 'meter'
 _UNIT_IN_METERS = {
@@ -153,6 +153,9 @@ def convolve_2d(data, kernel):
         return _convolve_2d_hip(data, kernel)
     if isinstance(data, ShardedArray):
         return _convolve_2d_sharded(data, kernel)
+    if is_dask(data):                       # convolution.py:316-327: map_overlap(depth = k // 2, boundary = nan)
+        k = _kernel_f64(kernel)
+        return dask_overlap(_convolve_2d_hip, (k.shape[0] // 2, k.shape[1] // 2))(data, kernel)
     raise TypeError("Unsupported Array Type: {}".format(type(data)))
 
 

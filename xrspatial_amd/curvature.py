@@ -9,7 +9,7 @@ from . import fused
 from ._launch import stencil
 from ._xr import DataArray
 from .dataset_support import supports_dataset
-from .utils import ArrayTypeFunctionMapping, get_dataarray_resolution
+from .utils import ArrayTypeFunctionMapping, dask_overlap, get_dataarray_resolution
 
 
 def _run(data, cellsize):
@@ -28,6 +28,6 @@ def curvature(agg: DataArray, name: Optional[str] = 'curvature') -> DataArray:
     if scope is not None:       # the pass derives (cellsize_x + cellsize_y) / 2 itself
         return scope.defer('curvature', agg, name, {'cellsize': (float(cellsize_x), float(cellsize_y))})
     cellsize = (cellsize_x + cellsize_y) / 2
-    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run, dask_func=dask_overlap(_run, (1, 1)))
     out = mapper(agg)(agg.data, cellsize)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

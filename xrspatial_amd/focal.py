@@ -14,7 +14,7 @@ from .convolution import _kernel_f64, custom_kernel
 from .dataset_support import supports_dataset
 from .device import DeviceArray, to_device_f32
 from .sharded import ShardedArray, ShardedStack
-from .utils import ArrayTypeFunctionMapping
+from .utils import ArrayTypeFunctionMapping, da, dask_overlap, is_dask
 
 # order of the XRS_STAT_* enum in include/xrs_hip.h
 _STAT_INDEX = {'mean': 0, 'max': 1, 'min': 2, 'range': 3, 'std': 4, 'var': 5, 'sum': 6}
@@ -214,6 +214,15 @@ def _mean_hip(data, excludes, passes):
     return finish(out, like_numpy)
 
 
+def _mean_dask(data, excludes, passes):
+    # focal.py:70-75, 257-259: `.astype(float)`, then one map_overlap(depth=(1, 1), boundary=nan) per pass
+    out = data.astype(float)
+    one_pass = dask_overlap(_mean_hip, (1, 1))
+    for _ in range(int(passes)):
+        out = one_pass(out, excludes, 1)
+    return out
+
+
 @supports_dataset
 def mean(agg, passes=1, excludes=[np.nan], name='mean'):
     """3x3 NaN-skipping moving average, `passes` times; cells equal to a value in `excludes`
@@ -222,7 +231,8 @@ def mean(agg, passes=1, excludes=[np.nan], name='mean'):
         raise ValueError("`agg` must be 2D")
     if len(excludes) > 8:
         raise ValueError("at most 8 exclude values are supported by the MI355X backend")
-    mapper = ArrayTypeFunctionMapping(numpy_func=_mean_hip, hip_func=_mean_hip, sharded_func=_mean_sharded)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_mean_hip, hip_func=_mean_hip, sharded_func=_mean_sharded,
+                                      dask_func=_mean_dask)
     out = mapper(agg)(agg.data, tuple(excludes), passes)
     return DataArray(out, name=name, dims=agg.dims, coords=agg.coords, attrs=agg.attrs)
 
@@ -308,7 +318,9 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
             return _focal_stats_banded(data, kernel, [stat])[0]
         return _focal_stats_hip(data, kernel, [stat])[stat]
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=_apply_sharded)
+    # (dask: focal.py:329-340 -- map_overlap(depth = k // 2, boundary = nan) around the numpy runner)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=_apply_sharded,
+                                      dask_func=dask_overlap(run, (kernel.shape[0] // 2, kernel.shape[1] // 2)))
     out = mapper(raster)(raster.data, kernel, stat)
     return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
 
@@ -333,6 +345,16 @@ def focal_stats(agg, kernel, stats_funcs=['mean', 'max', 'min', 'range', 'std', 
         coords['stats'] = np.array(stats_funcs, dtype=object)
         return DataArray(ShardedStack([planes[s] for s in stats_funcs]), dims=('stats',) + tuple(agg.dims), coords=coords,
                          attrs=agg.attrs)
+    if is_dask(agg.data):
+        # the reference runs one apply() per statistic and concatenates them (focal.py:782-797); per block the numpy runner
+        # computes the requested statistic (one launch), map_overlap(depth = k // 2, boundary = nan) as in apply()
+        def one(block, stat):
+            return _focal_stats_hip(block, kernel, [stat])[stat]
+        depth = (kernel.shape[0] // 2, kernel.shape[1] // 2)
+        stacked = da.stack([dask_overlap(one, depth)(agg.data, s) for s in stats_funcs])
+        coords = dict(agg.coords.items())
+        coords['stats'] = np.array(stats_funcs, dtype=object)
+        return DataArray(stacked, dims=('stats',) + tuple(agg.dims), coords=coords, attrs=agg.attrs)
     if not isinstance(agg.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(agg)))
     if pipeline_ok(agg.data) and len(set(stats_funcs)) == len(stats_funcs) and max(kernel.shape) // 2 < 128:

@@ -11,6 +11,7 @@ from ._xr import DataArray
 from .dataset_support import supports_dataset
 from .device import DeviceArray
 from .sharded import ShardedArray
+from .utils import dask_overlap, is_dask
 
 # The reference's NumPy runner returns float64 under NumPy >= 2 (its final combine is
 # promoted by a np.float64 scalar) and float32 under NumPy 1.x; its CuPy
@@ -54,6 +55,8 @@ def hillshade(agg: DataArray,
         out = _run_numpy(agg.data, azimuth, angle_altitude)
     elif isinstance(agg.data, (DeviceArray, ShardedArray)):
         out = _run_hip(agg.data, azimuth, angle_altitude)
+    elif is_dask(agg.data):                 # hillshade.py:38-46: map_overlap(depth=(1, 1), boundary=nan) around the numpy runner
+        out = dask_overlap(_run_numpy, (1, 1))(agg.data, azimuth, angle_altitude)
     else:
         raise TypeError('Unsupported Array Type: {}'.format(type(agg.data)))
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

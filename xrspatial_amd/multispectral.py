@@ -12,7 +12,7 @@ from ._xr import DataArray
 from .dataset_support import supports_dataset_bands
 from .device import DTYPE_CODE, DeviceArray, to_device_f32
 from .sharded import ShardedArray, same_layout
-from .utils import ArrayTypeFunctionMapping, validate_arrays
+from .utils import ArrayTypeFunctionMapping, dask_blocks, validate_arrays
 
 
 def _percell(fn_name, bands, extra):
@@ -46,7 +46,8 @@ def _wrap(out, name, like):
 
 def _nr_index(band1, band2, name):
     validate_arrays(band1, band2)
-    mapper = ArrayTypeFunctionMapping(numpy_func=_normalized_ratio, hip_func=_normalized_ratio, sharded_func=_normalized_ratio)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_normalized_ratio, hip_func=_normalized_ratio, sharded_func=_normalized_ratio,
+                                      dask_func=dask_blocks(_normalized_ratio))
     return _wrap(mapper(band1)(band1.data, band2.data), name, band1)
 
 
@@ -95,7 +96,7 @@ def evi(nir_agg, red_agg, blue_agg, c1=6.0, c2=7.5, soil_factor=1.0, gain=2.5, n
         return _percell("xrs_evi_f32", (nir, red, blue),
                         (float(c1), float(c2), float(soil_factor), float(gain)))
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run, dask_func=dask_blocks(run))
     return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data, blue_agg.data), name, nir_agg)
 
 
@@ -110,7 +111,7 @@ def savi(nir_agg, red_agg, soil_factor=1.0, name='savi'):
     def run(nir, red):         # replaces _savi_cpu (multispectral.py:876-890)
         return _percell("xrs_savi_f32", (nir, red), (float(soil_factor),))
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run, dask_func=dask_blocks(run))
     return _wrap(mapper(red_agg)(nir_agg.data, red_agg.data), name, nir_agg)
 
 
@@ -121,7 +122,7 @@ def _simple_index(fn_name, like, bands, name, order=None):
     def run(*arrays):
         return _percell(fn_name, arrays, ())
 
-    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=run, hip_func=run, sharded_func=run, dask_func=dask_blocks(run))
     return _wrap(mapper(like)(*[b.data for b in bands]), name, like)
 
 

@@ -11,7 +11,7 @@ from ._xr import DataArray
 from .dataset_support import supports_dataset
 from .device import DeviceArray
 from .geodesic import extract_latlon, run_geodesic, z_factor_of
-from .utils import ArrayTypeFunctionMapping, get_dataarray_resolution
+from .utils import ArrayTypeFunctionMapping, dask_overlap, get_dataarray_resolution
 
 
 def _run(data, cellsize_x, cellsize_y):
@@ -43,6 +43,6 @@ def slope(agg: DataArray,
     scope = fused.current()
     if scope is not None:
         return scope.defer('slope', agg, name, {'cellsize': (float(cellsize_x), float(cellsize_y))})
-    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_run, hip_func=_run, sharded_func=_run, dask_func=dask_overlap(_run, (1, 1)))
     out = mapper(agg)(agg.data, cellsize_x, cellsize_y)
     return DataArray(out, name=name, coords=agg.coords, dims=agg.dims, attrs=agg.attrs)

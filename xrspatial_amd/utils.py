@@ -7,6 +7,8 @@ get_dataarray_resolution (:233-277), not_implemented_func (:113-114).
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -26,6 +28,42 @@ def has_hip() -> bool:
 
 def has_dask_array() -> bool:
     return da is not None
+
+
+def is_dask(data) -> bool:
+    return da is not None and isinstance(data, da.Array)
+
+
+# dask's threaded scheduler calls a block function from several threads at once; the numpy runners share one stream and
+# reuse staging buffers between calls, and the device serialises the launches anyway: one block at a time
+_DASK_BLOCK_LOCK = threading.Lock()
+
+
+def dask_overlap(block_func, depth):
+    """The dask slot of a stencil runner.  The reference wraps its numpy runner in
+    `data.map_overlap(func, depth=depth, boundary=np.nan, meta=np.array(()))` (slope.py:86-97, aspect.py:151-160,
+    curvature.py:56-59, hillshade.py:42-45, focal.py:70-75 and 329-340, convolution.py:316-327); so does this: every
+    block (with `depth` cells of its neighbours, NaN beyond the raster) goes through this package's numpy runner --
+    staged through HBM, computed by the HIP kernels, brought back -- and dask trims the overlap.  Lazy like upstream:
+    nothing runs before `.compute()`.  (Rasters that fit one node's GPUs are better served as a `ShardedArray`; this slot
+    exists so that a dask-backed DataArray that worked upstream works here.)"""
+    def run(data, *args, **kwargs):
+        def on_block(block):
+            with _DASK_BLOCK_LOCK:
+                return np.asarray(block_func(np.ascontiguousarray(block), *args, **kwargs))
+        return data.map_overlap(on_block, depth=depth, boundary=np.nan, meta=np.array(()))
+    return run
+
+
+def dask_blocks(block_func):
+    """The dask slot of a per-cell runner over one or more equally chunked rasters: `da.map_blocks(func, *arrays,
+    meta=np.array(()))` around the numpy runner (multispectral.py:60-63, 205-208, 845-848 ...)."""
+    def run(*arrays):
+        def on_blocks(*blocks):
+            with _DASK_BLOCK_LOCK:
+                return np.asarray(block_func(*[np.ascontiguousarray(b) for b in blocks]))
+        return da.map_blocks(on_blocks, *arrays, meta=np.array(()))
+    return run
 
 
 def not_implemented_func(agg, *args, messages='Not yet implemented.'):

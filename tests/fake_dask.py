@@ -2,7 +2,7 @@
 
 dask is not installable where this project is built and tested.  The slot (xrspatial_amd/utils.py: dask_overlap,
 dask_blocks) only needs `Array.map_overlap(func, depth, boundary, meta)`, `Array.astype`, `map_blocks(func, *arrays,
-meta)` and `stack`; this module provides exactly those over numpy arrays cut into chunks, with dask's semantics:
+meta)`, `stack`, and for hotspots `nanmean` / `nanstd` / `compute`; this module provides exactly those over numpy arrays cut into chunks, with dask's semantics:
 a block is extended by `depth` cells of its neighbours (the `boundary` value beyond the array), the function runs on
 the extended block, the overlap is trimmed from its result.  Evaluation is eager (`compute()` returns what is already
 there); the chunk log lets a test check that the work really went block by block."""
@@ -80,6 +80,18 @@ def map_blocks(func, *arrays, meta=None, **kwargs):
     result = Array(out, first.chunks)
     result.blocks_seen = first.blocks_seen
     return result
+
+
+def nanmean(a):
+    return np.nanmean(a._v)
+
+
+def nanstd(a):
+    return np.nanstd(a._v)
+
+
+def compute(*values):
+    return tuple(values)
 
 
 def stack(arrays):

@@ -657,6 +657,19 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
     got = xs.ndvi(lazy(nir), lazy(red))
     assert isinstance(got.data, fake_dask.Array)
     np.testing.assert_array_equal(got.data.compute(), want.data)
-    # a backend that has no dask slot still says so (zonal.stats on dask needs the block-partials combine: ShardedArray's job here)
+    # hotspots: the two global scalars first (eagerly), then convolution + z-score + classes per chunk (focal.py:940-976)
+    spots = z.copy()
+    spots[:12, :14] += 60.0                      # a hot corner and a cold one: several confidence classes in the result
+    spots[-12:, -14:] -= 60.0
+    want = xfocal.hotspots(xs.DataArray(spots, dims=['y', 'x'], coords=coords), k5)
+    got = xfocal.hotspots(lazy(spots), k5)
+    assert isinstance(got.data, fake_dask.Array) and got.data.compute().dtype == np.int8 and got.attrs['unit'] == '%'
+    np.testing.assert_array_equal(got.data.compute(), np.asarray(want.data))
+    assert len(np.unique(np.asarray(want.data))) > 1
+    with pytest.raises(ZeroDivisionError):
+        xfocal.hotspots(lazy(np.full((37, 53), 7.0, np.float32)), k5)
+    # what has no dask slot still says so (zonal.stats on dask needs the block-partials combine: ShardedArray's job here)
+    from xrspatial_amd import zonal as xzonal
+    zones = xs.DataArray(fake_dask.from_array((np.arange(37 * 53).reshape(37, 53) % 5).astype(np.int32), (16, 20)), dims=['y', 'x'])
     with pytest.raises((NotImplementedError, TypeError)):
-        xfocal.hotspots(lazy(), k5)
+        xzonal.stats(zones, lazy())

@@ -442,6 +442,30 @@ def _hotspots_sharded(data, kernel):
     return out
 
 
+def _hotspots_dask(data, kernel):
+    # focal.py:940-976 -- pass 1: the two global scalars, computed eagerly (all chunks read once, 8 bytes kept); pass 2:
+    # convolution + z-score + classification fused per chunk under map_overlap(depth = k // 2, boundary = nan), int8 out
+    from .convolution import _convolve_2d_hip
+    if not np.issubdtype(data.dtype, np.floating):
+        data = data.astype(np.float32)
+    global_mean, global_std = da.compute(da.nanmean(data), da.nanstd(data))
+    global_mean, global_std = np.float32(global_mean), np.float32(global_std)
+    if global_std == 0:
+        raise ZeroDivisionError("Standard deviation of the input raster values is 0.")
+    k = np.asarray(kernel, dtype=np.float64)
+    norm = k / k.sum()
+
+    def chunk(block):
+        src = to_device_f32(block)
+        mean_array = _convolve_2d_hip(src, norm)
+        out = DeviceArray(src.shape, np.int8)
+        _lib.call("xrs_hotspots_classify_f32", mean_array.ptr, out.ptr, out.size, float(global_mean), float(global_std),
+                  get_stream())
+        return finish(out, True)
+
+    return dask_overlap(chunk, (k.shape[0] // 2, k.shape[1] // 2), meta=np.array((), dtype=np.int8))(data)
+
+
 def hotspots(raster, kernel):
     """Getis-Ord Gi* hot / cold spots: int8 raster of {0, +-90, +-95, +-99} confidence levels.
 
@@ -452,7 +476,8 @@ def hotspots(raster, kernel):
         raise TypeError("`raster` must be instance of DataArray")
     if raster.ndim != 2:
         raise ValueError("`raster` must be 2D")
-    mapper = ArrayTypeFunctionMapping(numpy_func=_hotspots_hip, hip_func=_hotspots_hip, sharded_func=_hotspots_sharded)
+    mapper = ArrayTypeFunctionMapping(numpy_func=_hotspots_hip, hip_func=_hotspots_hip, sharded_func=_hotspots_sharded,
+                                      dask_func=_hotspots_dask)
     out = mapper(raster)(raster.data, kernel)
     attrs = copy.deepcopy(raster.attrs)
     attrs['unit'] = '%'

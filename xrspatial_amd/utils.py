@@ -39,7 +39,7 @@ def is_dask(data) -> bool:
 _DASK_BLOCK_LOCK = threading.Lock()
 
 
-def dask_overlap(block_func, depth):
+def dask_overlap(block_func, depth, meta=None):
     """The dask slot of a stencil runner.  The reference wraps its numpy runner in
     `data.map_overlap(func, depth=depth, boundary=np.nan, meta=np.array(()))` (slope.py:86-97, aspect.py:151-160,
     curvature.py:56-59, hillshade.py:42-45, focal.py:70-75 and 329-340, convolution.py:316-327); so does this: every
@@ -51,7 +51,7 @@ def dask_overlap(block_func, depth):
         def on_block(block):
             with _DASK_BLOCK_LOCK:
                 return np.asarray(block_func(np.ascontiguousarray(block), *args, **kwargs))
-        return data.map_overlap(on_block, depth=depth, boundary=np.nan, meta=np.array(()))
+        return data.map_overlap(on_block, depth=depth, boundary=np.nan, meta=np.array(()) if meta is None else meta)
     return run
 
 

@@ -40,7 +40,8 @@ class Array:
         depth = (depth,) * self.ndim if np.isscalar(depth) else tuple(depth)
         assert len(depth) == self.ndim == 2 and boundary is not None and boundary != boundary, "the slot asks for a NaN boundary"
         (d0, d1) = depth
-        padded = np.pad(self._v.astype(np.result_type(self._v.dtype, np.float32)), ((d0, d0), (d1, d1)), constant_values=np.nan)
+        assert np.issubdtype(self._v.dtype, np.floating), "a NaN boundary on an integer array: dask would not give NaN there"
+        padded = np.pad(self._v, ((d0, d0), (d1, d1)), constant_values=np.nan)
         rows, cols = self._spans()
         out = None
         for (r0, r1) in rows:

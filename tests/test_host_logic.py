@@ -650,6 +650,12 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
         assert got.data.compute().dtype == np.asarray(want.data).dtype, name
         seen = got.data.blocks_seen
         assert len(seen) >= 6 and max(s[0] for s in seen) < 37 and max(s[1] for s in seen) < 53, (name, seen)   # 3 x 3 chunks, never the whole
+    # an integer raster: cast to float32 before the NaN boundary is attached (slope.py:89)
+    zi = (z * 10).astype(np.int32)
+    zi[np.isnan(z)] = 0
+    np.testing.assert_array_equal(xs.slope(lazy(zi)).data.compute(),
+                                  np.asarray(xs.slope(xs.DataArray(zi.astype(np.float32), dims=['y', 'x'], coords=coords,
+                                                                   attrs={'res': (2.0, 2.0)})).data))
     # per-cell indices: map_blocks over equally chunked bands
     nir = rng.random((37, 53)).astype(np.float32)
     red = rng.random((37, 53)).astype(np.float32)

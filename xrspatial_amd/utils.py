@@ -48,6 +48,9 @@ def dask_overlap(block_func, depth, meta=None):
     nothing runs before `.compute()`.  (Rasters that fit one node's GPUs are better served as a `ShardedArray`; this slot
     exists so that a dask-backed DataArray that worked upstream works here.)"""
     def run(data, *args, **kwargs):
+        if not np.issubdtype(data.dtype, np.floating):
+            data = data.astype(np.float32)      # (a NaN boundary needs a float raster; the runners cast to float32 anyway)
+
         def on_block(block):
             with _DASK_BLOCK_LOCK:
                 return np.asarray(block_func(np.ascontiguousarray(block), *args, **kwargs))

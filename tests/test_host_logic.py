@@ -651,8 +651,7 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
         seen = got.data.blocks_seen
         assert len(seen) >= 6 and max(s[0] for s in seen) < 37 and max(s[1] for s in seen) < 53, (name, seen)   # 3 x 3 chunks, never the whole
     # an integer raster: cast to float32 before the NaN boundary is attached (slope.py:89)
-    zi = (z * 10).astype(np.int32)
-    zi[np.isnan(z)] = 0
+    zi = (np.nan_to_num(z, nan=0.0) * 10).astype(np.int32)
     np.testing.assert_array_equal(xs.slope(lazy(zi)).data.compute(),
                                   np.asarray(xs.slope(xs.DataArray(zi.astype(np.float32), dims=['y', 'x'], coords=coords,
                                                                    attrs={'res': (2.0, 2.0)})).data))

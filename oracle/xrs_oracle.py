@@ -657,8 +657,15 @@ def crosstab_2d(zones, values, zone_ids=None, cat_ids=None, nodata_values=None, 
         zv = values[zones == z]
         zv = zv[np.isfinite(zv) & (zv != nodata_values)]
         total.append(zv.shape[0])
-        for c in cat_sel:
-            out[c].append(int((zv == c).sum()))
+        # zonal.py:716-725: the run start only moves past SELECTED categories, so with a strict subset in cat_ids a
+        # selected category's count also takes the unselected ones sorted between its predecessor and it
+        zs = np.sort(zv)
+        start = 0
+        for c in unique_cats:
+            if c in cat_sel:
+                end = int(np.searchsorted(zs, c, side='right'))
+                out[c].append(end - start)
+                start = end
     total = np.array(total, dtype=F32)
     for c in cat_sel:
         out[c] = np.array(out[c])

@@ -682,9 +682,16 @@ def _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_va
     zrows = [i for i, z in enumerate(unique_zones) if z in sel_zones]
     total = counts[zrows].sum(axis=1).astype(np.float32)                 # all valid cells of the zone (zonal.py:708-709)
     frame = {'zone': sel_zones}
-    for c in sel_cats:
-        j = int(np.flatnonzero(unique_cats == c)[0])
-        frame[c] = counts[zrows, j]
+    # The reference walks the categories in sorted order and advances its run start only past SELECTED ones
+    # (`cat_start`, zonal.py:719-725): with `cat_ids` a strict subset, a selected category's column also holds the cells
+    # of the unselected categories that sort between the previous selected category and it.  Reproduced as executed
+    # (tests/golden/make_reference_exec.py, cases ct/*); with cat_ids=None the runs are the plain per-category counts.
+    runs = np.cumsum(counts, axis=1)
+    prev = None
+    for j, c in enumerate(unique_cats):
+        if c in sel_cats:
+            frame[c] = runs[zrows, j] - (0 if prev is None else runs[zrows, prev])
+            prev = j
     if agg == 'percentage':
         total[total == 0] = np.nan
         for c in sel_cats:

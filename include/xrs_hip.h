@@ -347,6 +347,19 @@ int xrs_zonal_majority_f32(const int32_t *zone_idx_dev, const float *values_dev,
 int xrs_zonal_majority_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones,
                            double nodata, int has_nodata, void *work_dev, size_t work_bytes,
                            double *majority_dev, void *stream);
+/* majority WITHOUT a sort (csrc/zonal_mode.hip): the cells are routed zone by zone and then, inside a zone, by a hash
+ * of the value's bits until every part fits an LDS hash table that counts multiplicities; same result as
+ * xrs_zonal_majority_* (ties -> smallest value, -0.0 == +0.0, NaN for a zone without a valid cell) at ~1/6 of the traffic.
+ * majority_dev holds n_zones + 1 doubles: the LAST one is the number of parts whose table overflowed (a zone of more
+ * than ~2^27 cells of all-distinct values) -- nonzero means the results are not valid and the caller must use
+ * xrs_zonal_majority_*.  n_zones <= xrs_zonal_mode_max_zones(); n < 2^31; `work_dev` holds
+ * xrs_zonal_mode_workspace_bytes(n, n_zones, values_f64) bytes. */
+size_t xrs_zonal_mode_workspace_bytes(int64_t n, int n_zones, int values_f64);
+int xrs_zonal_mode_max_zones(void);
+int xrs_zonal_mode_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones, float nodata,
+                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream);
+int xrs_zonal_mode_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones, double nodata,
+                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream);
 /* the valid cells of every zone gathered into one contiguous run, for statistics that are arbitrary host callables
  * (zonal.stats(stats_funcs={name: callable}): _calc_stats, xrspatial/zonal.py:144-163, slices the argsort-ordered
  * values per zone and filters non-finite / nodata cells before calling func).  sorted_values_dev[n] receives the cells

@@ -329,6 +329,14 @@ class _FakeLib:
         return 256
 
     @staticmethod
+    def xrs_zonal_mode_workspace_bytes(n, nz, f64):
+        return 256
+
+    @staticmethod
+    def xrs_zonal_mode_max_zones():
+        return 16384
+
+    @staticmethod
     def xrs_free(ptr):
         _live.pop(int(ptr), None)
 

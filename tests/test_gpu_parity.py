@@ -1083,7 +1083,7 @@ def test_zonal_majority_and_dataarray(golden, golden_tables):
         want = orc.zonal_stats(zz, vv, stats_funcs=['majority', 'count'], nodata_values=3)
         # integral values in a bounded range are counted (crosstab kernel); XRS_ZONAL_MAJORITY=sort forces the two radix
         # sorts every other raster takes; halves (vv / 2) are not integral and sort by themselves
-        for mode in ('', 'sort'):
+        for mode in ('', 'sort', 'hash'):
             os.environ['XRS_ZONAL_MAJORITY'] = mode
             try:
                 got = xs.zonal_stats(raster(zz), raster(vv), stats_funcs=['majority', 'count'], nodata_values=3)
@@ -1107,6 +1107,73 @@ def test_zonal_majority_and_dataarray(golden, golden_tables):
     assert np.isnan(got['majority'][2]) and np.isnan(got['majority'][4])
     with pytest.raises(ValueError):
         xs.zonal_stats(zones, values, stats_funcs={'double_sum': 'not callable'})
+
+
+def _majority_three_ways(zz, vv, nz, nodata=None):
+    """zonal_majority through the partition-and-count path, the sorting path, and np.unique per zone."""
+    from xrspatial_amd.zonal import zonal_majority
+    out = {}
+    for mode in ('hash', 'sort'):
+        os.environ['XRS_ZONAL_MAJORITY'] = mode
+        try:
+            out[mode] = zonal_majority(zz, vv, nz, nodata)
+        finally:
+            del os.environ['XRS_ZONAL_MAJORITY']
+    want = np.full(nz, np.nan)
+    flat_z, flat_v = zz.ravel(), vv.ravel()
+    ok = np.isfinite(flat_v) & (flat_z >= 0) & (flat_z < nz)
+    if nodata is not None:
+        ok &= flat_v != nodata
+    order = np.argsort(flat_z[ok], kind='stable')
+    zs, vs = flat_z[ok][order], flat_v[ok][order]
+    cuts = np.searchsorted(zs, np.arange(nz + 1))
+    for z in range(nz):
+        if cuts[z + 1] > cuts[z]:
+            vals, counts = np.unique(vs[cuts[z]:cuts[z + 1]], return_counts=True)     # zonal.py:56-60
+            want[z] = vals[np.argmax(counts)]
+    return out['hash'], out['sort'], want
+
+
+@pytest.mark.parametrize("vdtype", [np.float32, np.float64])
+def test_zonal_majority_partition_and_count(vdtype):
+    """csrc/zonal_mode.hip (cells routed by zone, then by a hash of the value, counted in LDS hash tables) against
+    np.unique + argmax per zone (xrspatial/zonal.py:56-68) and against the sorting path: continuous values (every zone cut
+    into parts), quantised values (heavy duplicates in few parts), ties -> smallest, -0.0 == +0.0, infinities skipped,
+    nodata, empty zones, zones of 1 cell, cells outside every zone, and a zone large enough for the one-atomic-per-key
+    variant of the part passes."""
+    rng = np.random.default_rng(23)
+    cases = []
+    H, W = 600, 1000
+    blocky = ((np.arange(H)[:, None] // 100) * 4 + np.arange(W)[None, :] // 250).astype(np.int32)          # 24 zones of 25 000
+    cont = rng.normal(100, 20, (H, W)).astype(vdtype)
+    cont[rng.random((H, W)) < 0.01] = np.nan
+    cont[3, 4], cont[5, 6] = np.inf, -np.inf
+    cases.append(("continuous, blocky zones", blocky, cont, 24, None))
+    quant = np.round(rng.normal(0, 3, (H, W)) * 4) / 4
+    quant[quant == 0] *= -1.0
+    cases.append(("quarters, -0.0", blocky, quant.astype(vdtype), 24, 0.25))
+    scattered = rng.integers(-1, 40, (H, W)).astype(np.int32)                                              # -1: outside every zone
+    scattered[scattered == 17] = 18                                                                        # zone 17 is empty
+    cases.append(("continuous, scattered zones with an empty one", scattered, cont, 40, None))
+    ties = np.tile(np.array([5.5, 2.5, 2.5, 5.5, 9.0], dtype=vdtype), H * W // 5).reshape(H, W)
+    cases.append(("ties -> smallest", blocky, ties, 24, None))
+    tiny = np.arange(H * W, dtype=np.int32).reshape(H, W) % 5000                                           # 5000 zones of 120 cells
+    cases.append(("many small zones", tiny, np.round(cont), 5000, None))
+    allnan = np.full((H, W), np.nan, dtype=vdtype)
+    cases.append(("no valid cell at all", blocky, allnan, 24, None))
+    # one zone of ~4.2 M cells next to small ones: 2^12 parts, the variant without an LDS histogram
+    Hb, Wb = 2100, 2100
+    big = np.zeros((Hb, Wb), dtype=np.int32)
+    big[:60] = 1 + (np.arange(Wb)[None, :] // 700)
+    vbig = rng.normal(50, 10, (Hb, Wb)).astype(vdtype)
+    vbig[1000, :8] = 42.125                                      # the only value of zone 0 that occurs 8 times
+    cases.append(("a 4 M-cell zone", big, vbig, 4, None))
+    for name, zz, vv, nz, nodata in cases:
+        got_hash, got_sort, want = _majority_three_ways(zz, vv, nz, nodata)
+        np.testing.assert_array_equal(got_hash, want, err_msg=f"{name}: partition-and-count vs np.unique")
+        np.testing.assert_array_equal(got_sort, want, err_msg=f"{name}: sort vs np.unique")
+        assert (np.signbit(got_hash) == np.signbit(want)).all(), name
+    assert cases[-1][2][1000, 0] == 42.125 and _majority_three_ways(*cases[-1][1:4])[0][0] == 42.125
 
 
 def test_zonal_custom_callables(golden, golden_tables):

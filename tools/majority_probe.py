@@ -25,3 +25,15 @@ t = Timer()
 for name, vals in (("continuous", dem), ("categorical32", cat)):
     med, mn = t.time(lambda: L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None), 3, warmup=1)
     print(f"majority {name:14s} {med:9.2f} ms  ({n*n/med/1e3:8.0f} Mcells/s)  workspace {nbytes/2**30:.1f} GiB", flush=True)
+
+# the same rasters through the partition-and-count path (csrc/zonal_mode.hip), and the two results compared
+nbytes2 = int(_lib.load().xrs_zonal_mode_workspace_bytes(n * n, nz, 0))
+work2 = xs.DeviceArray((nbytes2,), np.uint8)
+out2 = xs.DeviceArray((nz + 1,), np.float64)
+for name, vals in (("continuous", dem), ("categorical32", cat)):
+    med, mn = t.time(lambda: L("xrs_zonal_mode_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work2.ptr, nbytes2, out2.ptr, None), 5, warmup=1)
+    L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None)
+    a, b = out2.get(), out.get()
+    same = np.array_equal(a[:nz], b, equal_nan=True)
+    print(f"mode     {name:14s} {med:9.2f} ms  ({n*n/med/1e3:8.0f} Mcells/s)  workspace {nbytes2/2**30:.1f} GiB  overflow {a[nz]:.0f}  "
+          f"equal to the sort: {same}", flush=True)

@@ -316,16 +316,29 @@ def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
     _lib.require_device()
     stream = get_stream()
     zdev, vdev = _stage(zone_idx, values)
-    if os.environ.get("XRS_ZONAL_MAJORITY", "") != "sort":          # (A/B and tests: force the sorting path)
+    how = os.environ.get("XRS_ZONAL_MAJORITY", "")                  # A/B and tests: "sort" / "hash" force one path
+    f64 = vdev.dtype == np.float64
+    has_nodata = nodata_values is not None
+    nodata = float(nodata_values) if has_nodata else 0.0
+    if how not in ("sort", "hash"):
         counted = _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream)
         if counted is not None:
             return counted
-    f64 = vdev.dtype == np.float64
+    if how != "sort" and 0 < n_zones <= int(_lib.load().xrs_zonal_mode_max_zones()):
+        # continuous values: route the cells by (zone, hash of the value) into LDS-sized parts and count there
+        # (csrc/zonal_mode.hip); the entry behind the zones counts parts that did not fit -- then, and only then, sort
+        out = DeviceArray((n_zones + 1,), np.float64)
+        nbytes = int(_lib.load().xrs_zonal_mode_workspace_bytes(vdev.size, n_zones, int(f64)))
+        work = DeviceArray((nbytes,), np.uint8)
+        _lib.call("xrs_zonal_mode_f64" if f64 else "xrs_zonal_mode_f32", zdev.ptr, vdev.ptr, vdev.size, n_zones, nodata,
+                  int(has_nodata), work.ptr, nbytes, out.ptr, stream)
+        res = out.get(stream)
+        del work
+        if res[n_zones] == 0:
+            return res[:n_zones]
     out = DeviceArray((n_zones,), np.float64)
     nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(vdev.size, n_zones, int(f64)))
     work = DeviceArray((nbytes,), np.uint8)
-    has_nodata = nodata_values is not None
-    nodata = float(nodata_values) if has_nodata else 0.0
     _lib.call("xrs_zonal_majority_f64" if f64 else "xrs_zonal_majority_f32", zdev.ptr, vdev.ptr, vdev.size,
               n_zones, nodata, int(has_nodata), work.ptr, nbytes, out.ptr, stream)
     return out.get(stream)
@@ -688,6 +701,8 @@ def _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_va
     # (tests/golden/make_reference_exec.py, cases ct/*); with cat_ids=None the runs are the plain per-category counts.
     runs = np.cumsum(counts, axis=1)
     prev = None
+    for c in sel_cats:
+        frame[c] = None                   # (columns keep the caller's labels: 0 stays 0 where the raster holds 0.0)
     for j, c in enumerate(unique_cats):
         if c in sel_cats:
             frame[c] = runs[zrows, j] - (0 if prev is None else runs[zrows, prev])

@@ -601,7 +601,48 @@ def run_headline(ctx):
         nd["fused_frac_of_hbm_peak"] = round(ALG_BYTES_FUSED * rows * cols / (nd["fused_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         nd["fused_mcells_s"] = round(rows * cols / (nd["fused_ms"] * 1e-3) / 1e6, 1)
         extra["nan_dem"] = nd
-        del nan_buf, out_d
+        # Nodata as real DEMs carry it: REGIONS (sea, the collar of a tile), not salt.  The same raster with its first third
+        # nodata -- rows 0..rows/3 (a horizontal rim) and columns 0..cols/3 (a vertical one, which cuts through a tile of
+        # every tile row) -- then 5 % scattered, and the 21x21 annulus on the 0.1 % raster.  Large windows through the *_ex
+        # entry with the workspace the host layer passes (the moments kernels note their slow tiles there: mom_impl.h).
+        wsb = int(ctx._lib.load().xrs_focal_workspace_bytes(rows, cols, 25, 25))
+        fwork = xs.DeviceArray((wsb,), np.uint8)
+        ann21 = np.ascontiguousarray(annulus_kernel(1, 1, 10, 6), dtype=np.float64)
+
+        def ex(p, k, mask, ptrs):
+            return L("xrs_focal_stats_f32_ex", p, ptrs, mask, rows, cols, cols, cols, k.ctypes.data, k.shape[0], k.shape[1], fwork.ptr,
+                     wsb, 0, 0, 0, stream)
+        reg = {"what": "the headline raster with one third of it a nodata REGION (rows: the first third of the rows; cols: the first "
+                       "third of the columns), with 5 % of its cells NaN (scattered), and the 21x21 annulus on the 0.1 % raster; ms per "
+                       "launch, clean-raster times in nan_dem / other_kernels_ms"}
+        region_buf = xs.DeviceArray((rows, cols), np.float32)
+        for variant in ("rows", "cols", "scattered_5pct"):
+            for y0 in range(0, rows, band):
+                n = min(band, rows - y0)
+                if variant == "scattered_5pct":
+                    host = synth.asv_dem(n, cols, y0=y_begin + y0, total_rows=total_rows, nan_frac=0.05)
+                else:
+                    host = synth.asv_dem(n, cols, y0=y_begin + y0, total_rows=total_rows).copy()
+                    if variant == "rows":
+                        host[: max(0, min(n, rows // 3 - y0))] = np.nan
+                    else:
+                        host[:, : cols // 3] = np.nan
+                L("xrs_memcpy_h2d", region_buf.ptr + y0 * cols * 4, host.ctypes.data, host.nbytes, stream)
+                L("xrs_stream_sync", stream)
+            rp = region_buf.ptr
+            r = {}
+            r["focal_mean_25x25_ms"] = round(timed(lambda: ex(rp, k25, 1, outs), reps=5), 4)
+            r["focal_mean_var_std_25x25_ms"] = round(timed(lambda: ex(rp, k25, 1 | 16 | 32, ptr7), reps=5), 4)
+            r["focal_stats7_25x25_ms"] = round(timed(lambda: ex(rp, k25, 127, ptr7), reps=5), 4)
+            r["fused_ms"] = round(timed(lambda: L("xrs_raster_pass_f32", rp, None, None, None, out_hill.ptr, out_focal.ptr, kernel.ctypes.data,
+                                                  kr, kc, None, rows, cols, cols, cols, 1.0, 1.0, 225.0, 25.0, 0, 0, stream), reps=10), 4)
+            reg[variant] = r
+        reg["annulus_21x21_stats7_at_0.1pct_ms"] = round(timed(lambda: ex(nan_buf.ptr, ann21, 127, ptr7), reps=5), 4)
+        reg["clean_with_workspace"] = {"focal_mean_25x25_ms": round(timed(lambda: ex(dem_ptr, k25, 1, outs), reps=5), 4),
+                                       "focal_mean_var_std_25x25_ms": round(timed(lambda: ex(dem_ptr, k25, 1 | 16 | 32, ptr7), reps=5), 4),
+                                       "focal_stats7_25x25_ms": round(timed(lambda: ex(dem_ptr, k25, 127, ptr7), reps=5), 4)}
+        extra["nodata_region"] = reg
+        del nan_buf, out_d, region_buf, fwork
         ok["slope_frac_of_hbm_peak"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
         ok["slope_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["slope"] * 1e-3) / 1e9 / copy_gbs, 3)
         ok["focal_mean_25x25_frac_of_measured_copy"] = round(8.0 * rows * cols / (ok["focal_mean_25x25_circle"] * 1e-3) / 1e9 / copy_gbs, 3)

@@ -256,3 +256,55 @@ def test_large_window_moments_carry_nodata(kind, radius):
                     np.testing.assert_allclose(g[fin], w[fin], rtol=RTOL, atol=0, err_msg=msg)
                     parity_log.record("large-window moments on nodata (carrying walk), 700x1500", f"{kind} {K}x{K} {name} {st}", g[fin], w[fin],
                                       tol="rtol 1e-5")
+
+
+@pytest.mark.parametrize("variant", ["rows", "cols"])
+def test_16k_nodata_region_rim(variant):
+    """Nodata as a REGION (a sea, the collar of a tile): the first third of the 16384^2 benchmark raster is NaN -- its rows
+    (a horizontal rim) or its columns (a vertical rim through a tile of every tile row).  The 25x25 circle statistics on a
+    band that straddles the rim, where the windows hold anything from 441 valid cells down to one: extrema bit for bit, moments
+    to 1e-5, NaN exactly where no valid cell is under the window (xrspatial/focal.py:305-326 with numba's nan-reductions).
+    These are the tiles the moments kernel hands to its rescue launch (csrc/mom_impl.h: focal_mom_rescue_kernel), whose
+    windows of a few cells are recomputed one by one in float64."""
+    n, R, B = 16384, 12, 72
+    cut = n // 3
+    dev = xs.DeviceArray((n, n), np.float32)
+    y_band = cut - R - B // 2 if variant == "rows" else 9000          # first row of the compared band
+    keep = None
+    for y0 in range(0, n, 2048):
+        host = synth.asv_dem(2048, n, y0=y0, total_rows=n).copy()
+        if variant == "rows":
+            host[: max(0, min(2048, cut - y0))] = np.nan
+        else:
+            host[:, :cut] = np.nan
+        lo, hi = y_band - R, y_band + B + R
+        if y0 <= lo and hi <= y0 + 2048:
+            keep = host[lo - y0:hi - y0].copy()
+        _lib.call("xrs_memcpy_h2d", dev.ptr + y0 * n * 4, host.ctypes.data, host.nbytes, None)
+        _lib.call("xrs_stream_sync", None)
+    assert keep is not None
+    agg = xs.DataArray(dev, dims=['y', 'x'], attrs={'res': (1.0, 1.0)})
+    k25 = circle_kernel(1, 1, 12)
+    stats25 = focal_stats(agg, k25)
+    names = [str(s) for s in np.asarray(stats25['stats'].data)]
+    mean_alone = apply(agg, k25).data
+    cfg = f"C3 16384^2 nodata REGION ({variant}): 25x25 circle statistics on the band across the rim"
+    few = 0
+    for i, stat in enumerate(names):
+        want = corc.focal_apply(keep, k25, stat, nthreads=8)[R:-R]
+        got = xs.DeviceArray((B, n), np.float32, _ptr=stats25.data.ptr + (i * n + y_band) * n * 4, _base=stats25.data).get()
+        parity_log.record(cfg, f"focal_stats_25x25 {stat}", got, want, tol="bit-exact" if stat in ('max', 'min', 'range') else "rtol 1e-5")
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=f"{variant} {stat}: NaN pattern")
+        if stat in ('max', 'min', 'range'):
+            np.testing.assert_array_equal(got, want, err_msg=f"{variant} {stat}")
+        else:
+            # (var / std of a window with ONE valid cell are exactly 0 in the reference; a handful of equal cells likewise)
+            np.testing.assert_allclose(got, want, rtol=RTOL, atol=0 if stat in ('mean', 'sum') else 1e-12, equal_nan=True, err_msg=f"{variant} {stat}")
+        if stat == 'mean':
+            g1 = xs.DeviceArray((B, n), np.float32, _ptr=mean_alone.ptr + y_band * n * 4, _base=mean_alone).get()
+            np.testing.assert_allclose(g1, want, rtol=RTOL, atol=0, equal_nan=True, err_msg=f"{variant} mean alone")
+            few = int(np.isnan(want).sum())
+    assert few > 1000                                             # the band does reach into the region
+    del dev, stats25, mean_alone
+    from xrspatial_amd import device
+    device.empty_cache()

@@ -1172,7 +1172,6 @@ def test_zonal_majority_partition_and_count(vdtype):
         got_hash, got_sort, want = _majority_three_ways(zz, vv, nz, nodata)
         np.testing.assert_array_equal(got_hash, want, err_msg=f"{name}: partition-and-count vs np.unique")
         np.testing.assert_array_equal(got_sort, want, err_msg=f"{name}: sort vs np.unique")
-        assert (np.signbit(got_hash) == np.signbit(want)).all(), name
     assert cases[-1][2][1000, 0] == 42.125 and _majority_three_ways(*cases[-1][1:4])[0][0] == 42.125
 
 

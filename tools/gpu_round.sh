@@ -52,6 +52,16 @@ for s in $STEPS; do
       # per-kernel durations of the large-window moments / extrema kernels on the benchmark DEM with 0.1 % nodata
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/momnan_$TAG -o s -- python $ROOT/tools/mom_nan_prof.py > /dev/null 2>&1)
       find /tmp/momnan_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/mom_nan_kernel_stats.csv \; ; cut -c1-180 $OUT/mom_nan_kernel_stats.csv | head -8 ;;
+    region)
+      # the large-window kernels on a raster whose first third is ONE nodata region (tools/mom_region_prof.py), per kernel
+      for r in rows third; do
+        (cd /tmp && REGION=$r timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/region_${TAG}_$r -o s -- python $ROOT/tools/mom_region_prof.py > /dev/null 2>&1)
+        find /tmp/region_${TAG}_$r -name "*kernel_stats.csv" -exec cp {} $OUT/region_${r}_kernel_stats.csv \; ; echo "REGION=$r"; cut -d, -f1-4 $OUT/region_${r}_kernel_stats.csv | cut -c1-160 | head -6
+      done ;;
+    majority)
+      timeout 300 python tools/majority_probe.py 32768 > $OUT/majority_probe.log 2>&1; cat $OUT/majority_probe.log
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/maj_$TAG -o s -- python $ROOT/tools/majority_probe.py 32768 > /dev/null 2>&1)
+      find /tmp/maj_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/majority_kernel_stats.csv \; ; cut -d, -f1-4 $OUT/majority_kernel_stats.csv | cut -c1-200 | head -24 ;;
     s64bench)
       timeout 600 python bench.py --workload s64 --steps 10 --warmup 3 > $OUT/bench_s64.json 2> $OUT/bench_s64.err; cat $OUT/bench_s64.json ;;
     *) echo "unknown step $s" ;;

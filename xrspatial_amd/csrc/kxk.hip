@@ -1060,11 +1060,13 @@ size_t xrs_kxk_workspace_bytes(int krows, int kcols) {
     return (size_t)krows * kcols * sizeof(double);       // float64 weights of convolve2d
 }
 
-// the kernel copy (256-byte aligned) + the tile map of the separable box walk (boxsep.hip)
+// the kernel copy (256-byte aligned) + the tile map of the separable box walk (boxsep.hip) + the work-list of the moments
+// kernels' slow tiles (mom_impl.h: focal_mom_rescue_kernel)
 static size_t weights_span(int krows, int kcols) { return ((size_t)krows * kcols * sizeof(double) + 255) & ~(size_t)255; }
+static size_t todo_span(long rows, long cols) { return (box_todo_bytes(rows, cols) + 255) & ~(size_t)255; }
 size_t xrs_focal_workspace_bytes(int64_t rows, int64_t cols, int krows, int kcols) {
     if (krows <= 0 || kcols <= 0 || rows < 0 || cols < 0) return 0;
-    return weights_span(krows, kcols) + box_todo_bytes(rows, cols);
+    return weights_span(krows, kcols) + todo_span(rows, cols) + mom_rescue_bytes(rows, cols);
 }
 
 int xrs_convolve2d_f32(const float *in_dev, float *out_dev, int64_t rows, int64_t cols, int64_t ld_in,
@@ -1153,8 +1155,14 @@ int xrs_focal_stats_f32_ex(const float *in_dev, float *const *outs_dev, unsigned
                                       halo_bot, s);
     }
     // np.ones((k, k)): scratch for the tile map of the separable walk (boxsep.hip), if the caller brought enough
-    unsigned char *const box_todo = (work_dev && work_bytes >= xrs_focal_workspace_bytes(rows, cols, krows, kcols))
-                                        ? static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) : nullptr;
+    const bool have_work = work_dev && work_bytes >= xrs_focal_workspace_bytes(rows, cols, krows, kcols);
+    unsigned char *const box_todo = have_work ? static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) : nullptr;
+    // ... and for the work-list of the moments kernels (mom_impl.h); without it their slow tiles are walked in place
+    struct RescueScope {
+        explicit RescueScope(unsigned *p) { mom_rescue_slot() = p; }
+        ~RescueScope() { mom_rescue_slot() = nullptr; }
+    } rescue_scope(have_work ? reinterpret_cast<unsigned *>(static_cast<unsigned char *>(work_dev) + weights_span(krows, kcols) + todo_span(rows, cols))
+                             : nullptr);
     // Large circles / boxes: the float32 walkers of wide_impl.h / ext_impl.h / mom_impl.h.  XRS_FOCAL_EXACT_MOMENTS keeps
     // the float64 column walkers (mean / var / std within ~1 ulp of the reference's float64 accumulators, ~2x the time);
     // XRS_FOCAL_SEQUENTIAL_SUM keeps `sum` on the kernel that adds the taps in the reference's order in float32 (bit-exact

@@ -702,8 +702,21 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
 #endif
         }
     }
-    // otherwise the NaN-aware float32 walker, 64 columns at a time; what fails THAT guard (+-inf, windows with a few valid
-    // cells at the edge of a nodata region, ill-conditioned sums) goes to the exact float64 walker.
+    // What is left -- the rim of a nodata region, dense nodata, raster-edge tiles on nodata, +-inf -- is slow work for one wave
+    // (the one-column NaN-aware walker, in the worst case the exact float64 walker behind it: 0.7 - 2.5 ms), and a launch
+    // cannot end before its last lone wave does.  With a work-list the tile is noted and this wave is free; focal_mom_rescue_kernel,
+    // launched behind this kernel, takes the noted tiles apart into half tiles x row bands, one per wave, all at once.
+    if (a.rescue) {
+        unsigned idx = 0;
+        if (lane == 0) idx = atomicAdd(a.rescue, 1u);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx < a.rescue_cap) {
+            if (lane == 0) a.rescue[2 + idx] = (unsigned)((ty * a.groups_x + gx) * 4 + wv);
+            return;
+        }
+    }
+    // (no list, or a full one: in place.)  The NaN-aware float32 walker, 64 columns at a time; what fails THAT guard (+-inf,
+    // windows with a few valid cells at the edge of a nodata region, ill-conditioned sums) goes to the exact float64 walker.
     // (Tried: the four waves of the workgroup sharing those exact walks behind a barrier -- a nodata boundary leaves one
     // slow tile per tile row, ~0.8 ms of kernel tail.  It shortened that raster's time by 7 % and cost EVERY raster 5 %:
     // the changed control flow pushed scalar registers of the interior loop into VGPR lanes, 48-56 v_readlane per round
@@ -717,6 +730,54 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
 #ifndef XRS_MOM_NO_EXACT           // (debug builds: keep what the NaN-aware walker wrote -- tests/mom_boundary_probe.py)
         mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end, q, 1);
 #endif
+    }
+}
+
+// The tiles focal_mom_kernel noted, redone with every wave of the chip: an item = (wave tile, 64-column half, band of rows); the
+// NaN-aware float32 walker runs the band (2R rows of run-in each: bands only while the list is short enough for their
+// latency to matter more than their overhead), windows that fail its guard are recomputed one by one in float64
+// (mom_fix_cells) instead of condemning the band, and only a band with more of those than the list holds -- +-inf spread
+// over it, flat ground next to relief -- takes the exact float64 column walker.
+constexpr int RESCUE_FIX = 1024;
+template <int R, typename Shape, int OM>
+__global__ void __launch_bounds__(256) focal_mom_rescue_kernel(const MomArgs a) {
+    using C = MomCfg<R, Shape>;
+    __shared__ __attribute__((aligned(16))) float stage[4][2 * (64 + 2 * R)];
+    __shared__ unsigned short fixes[4][RESCUE_FIX];
+    const unsigned count = a.rescue[0] < a.rescue_cap ? a.rescue[0] : a.rescue_cap;
+    if (!count) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const WalkGeom &g = a.g;
+    // bands of ~48 output rows while fewer than ~8 waves per CU would be busy otherwise
+    const int nb = (long)count * C::NC >= 2048 ? 1 : (a.tile_rows + 47) / 48;
+    const int band_rows = (a.tile_rows + nb - 1) / nb;
+    const long items = (long)count * C::NC * nb;
+    for (long it = (long)blockIdx.x * 4 + wv; it < items; it += (long)gridDim.x * 4) {
+        const unsigned ent = a.rescue[2 + it / (C::NC * nb)];
+        const int sub = (int)(it % (C::NC * nb)), q = sub / nb, band = sub % nb;
+        const long grp = ent >> 2;
+        const long ty = grp / a.groups_x, gx = grp % a.groups_x;
+        const long x_tile = (gx * 4 + (long)(ent & 3u)) * C::TW;
+        const long xw = x_tile + 64 * q;
+        if (xw >= g.cols) continue;
+        const long yt0 = ty * a.tile_rows;
+        const long yt1 = yt0 + a.tile_rows < g.rows ? yt0 + a.tile_rows : g.rows;
+        const long y0 = yt0 + (long)band * band_rows;
+        const long y_end = y0 + band_rows < yt1 ? y0 + band_rows : yt1;
+        if (y0 >= y_end) continue;
+        MomWalkN<R, Shape, OM> w(a, stage[wv], xw, y0, y_end, lane);
+        w.fix_list = fixes[wv];
+        w.fix_cap = RESCUE_FIX;
+        if (w.run()) {
+            if (w.n_fix) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                mom_fix_cells<R, Shape>(a, fixes[wv], w.n_fix, xw, y0, lane);
+            }
+        } else {
+            mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end, q, 1);
+        }
     }
 }
 
@@ -747,6 +808,12 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     }
     const int om = (a.out_sum ? MOM_SUM : 0) | (a.out_mean ? MOM_MEAN : 0) | (a.out_var ? MOM_VAR : 0) | (a.out_std ? MOM_STD : 0);
     constexpr int ALL = MOM_SUM | MOM_MEAN | MOM_VAR | MOM_STD, MVS = MOM_MEAN | MOM_VAR | MOM_STD;
+    a.rescue = mom_rescue_slot();
+    if (a.rescue) {
+        a.rescue_cap = (unsigned)(g.tiles_x * tiles_y);
+        if (mom_rescue_bytes(g.rows, g.cols) < 8 + 4 * (size_t)a.rescue_cap) a.rescue = nullptr;
+        else XRS_HIP(hipMemsetAsync(a.rescue, 0, 8, s));
+    }
     // (annuli: one instantiation per (outer, inner) radius pair, the run-time plane set -- 66 pairs up to radius 12)
     if constexpr (shape_has_hole<Shape>(R)) {
         (void)om; (void)ALL; (void)MVS;
@@ -757,6 +824,15 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
         else hipLaunchKernelGGL((focal_mom_kernel<R, Shape, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
     }
     XRS_LAUNCH_CHECK();
+    if (a.rescue) {
+        // (the plane set at run time: one instantiation per shape; an empty list costs the launch, ~5 us)
+        int dev = 0, n_cu = 256;
+        hipDeviceProp_t prop;
+        static thread_local int cus = 0;
+        if (!cus) cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : n_cu;
+        hipLaunchKernelGGL((focal_mom_rescue_kernel<R, Shape, 0>), dim3((unsigned)(cus * 4)), dim3(256), 0, s, a);
+        XRS_LAUNCH_CHECK();
+    }
     return 0;
 }
 

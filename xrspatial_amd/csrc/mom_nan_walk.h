@@ -20,7 +20,10 @@ struct MomArgs {
     int tile_rows;                // output rows per tile (tile_rows + 2R input rows = a whole number of rounds)
     int rim_first;                // work order (circle_walk.h RimFirst)
     const unsigned char *todo;    // boxes behind boxsep.hip's fast walk: one byte per workgroup tile, 0 = nothing to do; else NULL
+    unsigned *rescue;             // work-list of the wave tiles the fast walks handed on: [0] count, [2..] tiles; or NULL
+    unsigned rescue_cap;          // entries it holds
 };
+
 
 template <int R, typename Shape>
 struct MomCfg {
@@ -108,6 +111,8 @@ struct MomWalkN {
     const MomArgs &a;
     const WalkGeom &g;
     float *lds;                                            // Z[STG] then F[STG]
+    unsigned short *fix_list = nullptr;                    // LDS: outputs that failed their guard, (row in the band) << 6 | lane; the
+    int fix_cap = 0, n_fix = 0;                            // caller recomputes them one by one (mom_fix_cells); NULL: a failure hands on the half tile
     unsigned lds_z;                                        // LDS byte address of Z[lane]
     long xw, x, y0, y_end, y_first;
     int lane;
@@ -287,7 +292,18 @@ struct MomWalkN {
         }
         // (outside the lane-divergent block: the verdict must be the same in EVERY lane, columns beyond the raster
         // included -- the exact walker's wave-wide reductions need the whole wave to arrive together)
-        badm |= __builtin_amdgcn_ballot_w64(bad);
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(bad);
+        if (bm) {                                              // (rare)
+            const int nb = __popcll(bm);
+            if (fix_list && n_fix + nb <= fix_cap) {
+                // a window that failed its guard (a few valid cells at the rim of a nodata region whose sample variance is small
+                // by chance, +-inf under it): noted, the walk goes on -- one window in a thousand is no reason to redo 64 x 200
+                if (bad) fix_list[n_fix + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)(((i - 2 * R) << 6) | lane);
+                n_fix += nb;
+            } else {
+                badm |= bm;
+            }
+        }
         accN[DONE] = 0.0f; accS[DONE] = 0.0f; accQ[HAVE_Q ? DONE : 0] = 0.0f;
     }
 
@@ -352,5 +368,61 @@ struct MomWalkN {
         return true;
     }
 };
+
+// The outputs MomWalkN noted (fix_list) computed directly, one window at a time by the whole wave: float64, the reference's
+// own arithmetic (numba nanmean: float64 sum / count; nanvar: two passes; nansum: here the exactly rounded sum, like every
+// large-window sum of this library).  Lane l takes the window's column x - R + l of each of the 2R+1 rows (the mask decides
+// per row whether that cell is a tap), keeps the 2R+1 cells in registers for the second pass.  A few microseconds per window.
+template <int R, typename Shape>
+__device__ __forceinline__ void mom_fix_cells(const MomArgs &a, const unsigned short *list, int n, long xw, long y0, int lane) {
+    constexpr int K = 2 * R + 1;
+    const WalkGeom &g = a.g;
+    for (int e = 0; e < n; ++e) {
+        const unsigned ent = list[e];                          // (wave-uniform)
+        const long yo = y0 + (long)(ent >> 6), x = xw + (long)(ent & 63u);
+        const int dx = lane - R;                               // this lane's column offset (lanes >= K idle)
+        const long xc = x + dx;
+        const bool col_ok = lane < K && xc >= 0 && xc < g.cols;
+        float v[K];
+        double s = 0.0, cnt = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int dy = j - R, ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+            const long yy = yo + dy;
+            const bool tap = col_ok && adx <= Shape::hw(R, ady) && adx > Shape::hwi(R, ady) && yy >= -(long)g.halo_top && yy < g.rows + g.halo_bot;
+            float t = nan_f32();
+            if (tap) t = g.in[yy * g.ld_in + xc];
+            v[j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool ok = v[j] == v[j];
+            s += ok ? (double)v[j] : 0.0;
+            cnt += ok ? 1.0 : 0.0;
+        }
+        s = wave_reduce<WrSum>(s);
+        cnt = wave_reduce<WrSum>(cnt);
+        float mean = nan_f32(), var = nan_f32(), sd = nan_f32();
+        if (cnt > 0.0) {
+            const double m = s / cnt;
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const double d = (double)v[j] - m;
+                q += v[j] == v[j] ? d * d : 0.0;
+            }
+            q = wave_reduce<WrSum>(q);
+            const double vr = q / cnt;
+            mean = (float)m; var = (float)vr; sd = (float)sqrt(vr);
+        }
+        if (lane == 0) {
+            const long off = yo * g.ld_out + x;
+            if (a.out_mean) a.out_mean[off] = mean;
+            if (a.out_var) a.out_var[off] = var;
+            if (a.out_std) a.out_std[off] = sd;
+            if (a.out_sum) a.out_sum[off] = (float)s;
+        }
+    }
+}
 
 }  // namespace

@@ -325,5 +325,14 @@ int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_
                    unsigned char *todo, long fb_groups_x, int fb_tile_rows, int fb_group_cols, hipStream_t s);
 // bytes of `todo` that is always enough for a rows x cols raster (host side of xrs_focal_workspace_bytes)
 inline size_t box_todo_bytes(long rows, long cols) { return (size_t)(cols / 512 + 2) * (size_t)(rows / 64 + 2); }
+// the moments kernels' work-list of wave tiles handed on to focal_mom_rescue_kernel (mom_impl.h): [0] count, [2..] tiles;
+// wave tiles are at least 64 columns x 16 rows
+inline size_t mom_rescue_bytes(long rows, long cols) { return 256 + 4 * (size_t)(cols / 64 + 2) * (size_t)(rows / 16 + 2); }
+// ... handed from xrs_focal_stats_f32 (kxk.hip, which owns the caller's workspace) to launch_mom (mom_impl.h, nine
+// translation units) without widening every entry point in between: set around the call, NULL otherwise
+inline unsigned *&mom_rescue_slot() {
+    static thread_local unsigned *p = nullptr;
+    return p;
+}
 
 }  // namespace xrs

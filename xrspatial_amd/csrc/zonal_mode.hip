@@ -79,8 +79,9 @@ __device__ __forceinline__ unsigned slot_of(unsigned long long k) { return slot_
 
 // per-launch bookkeeping in the workspace
 struct Hdr {
-    unsigned n_valid, n_parts, n_chunks, overflow;
+    unsigned n_valid, n_parts, n_chunks, overflow, n_direct;     // n_direct: zones cut into more than 2^LDS_B parts
 };
+constexpr unsigned IN_KEYS = 0x80000000u;   // part_off flag: the part is a whole zone and lies in the zone-ordered key array
 
 template <typename VT>
 __device__ __forceinline__ bool cell_valid(int z, VT v, int nz, VT nodata, int has_nodata) {
@@ -133,7 +134,7 @@ __device__ __forceinline__ int parts_log2(unsigned count) {
 __global__ void __launch_bounds__(1024) plan_kernel(const unsigned *__restrict__ zone_count, int nz, unsigned *__restrict__ key_off,
                                                     unsigned *__restrict__ zone_cursor, unsigned *__restrict__ part_base,
                                                     unsigned *__restrict__ chunk_base, unsigned char *__restrict__ zone_B,
-                                                    unsigned *__restrict__ part_count, Hdr *hdr) {
+                                                    unsigned *__restrict__ part_count, unsigned *__restrict__ part_off, Hdr *hdr) {
     __shared__ unsigned s_wave[3][16];
     __shared__ unsigned s_carry[3];
     if (threadIdx.x < 3) s_carry[threadIdx.x] = 0;
@@ -170,7 +171,8 @@ __global__ void __launch_bounds__(1024) plan_kernel(const unsigned *__restrict__
             part_base[z] = excl[1];
             chunk_base[z] = excl[2];
             zone_B[z] = (unsigned char)B;
-            if (B == 0) part_count[excl[1]] = c;      // the zone is its own part (parts of cut zones: part_hist)
+            if (B == 0) { part_count[excl[1]] = c; part_off[excl[1]] = excl[0] | IN_KEYS; }   // the zone is its own part
+            if (B > LDS_B) atomicAdd(&hdr->n_direct, 1u);
         }
         __syncthreads();
         if (threadIdx.x == 1023) {
@@ -240,14 +242,10 @@ __global__ void __launch_bounds__(TILE_THREADS) scatter_zone_kernel(const int32_
         if (zone[j] >= 0) keys[hist[zone[j]] + rank[j]] = key[j];
 }
 
-// chunk (workgroup of passes 4 and 6) / part (pass 7) -> its zone
-__device__ __forceinline__ int find_owner(const unsigned *__restrict__ base, int nz, unsigned c) {
-    int lo = 0, hi = nz;                            // base[nz] = total > c
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (base[mid] <= c) lo = mid; else hi = mid;
-    }
-    return lo;                                      // base[lo] <= c < base[lo + 1]: zones that own nothing are stepped over
+// chunk -> zone, as a table (a binary search over the zones per workgroup is ten dependent L2 round trips before any work)
+__global__ void __launch_bounds__(256) chunk_table_kernel(const unsigned *__restrict__ chunk_base, int nz, unsigned short *__restrict__ chunk_zone) {
+    const int z = blockIdx.x;
+    for (unsigned c = chunk_base[z] + threadIdx.x; c < chunk_base[z + 1]; c += 256) chunk_zone[c] = (unsigned short)z;
 }
 
 // 4. histogram of the parts of every cut zone.  DIRECT = false: zones of up to 2^LDS_B parts, through an LDS histogram of the
@@ -256,11 +254,12 @@ template <typename K, bool DIRECT>
 __global__ void __launch_bounds__(TILE_THREADS) part_hist_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
                                                                  const unsigned *__restrict__ part_base,
                                                                  const unsigned *__restrict__ chunk_base,
+                                                                 const unsigned short *__restrict__ chunk_zone,
                                                                  const unsigned char *__restrict__ zone_B, int nz,
                                                                  const Hdr *__restrict__ hdr, unsigned *__restrict__ part_count) {
-    if (blockIdx.x >= hdr->n_chunks) return;
+    if (blockIdx.x >= hdr->n_chunks || (DIRECT && !hdr->n_direct)) return;
     __shared__ unsigned hist[DIRECT ? 1 : (1 << LDS_B)];
-    const int z = find_owner(chunk_base, nz, blockIdx.x);
+    const int z = chunk_zone[blockIdx.x];
     const int B = zone_B[z];
     if ((B > LDS_B) != DIRECT) return;
     const unsigned np = 1u << B, pb = part_base[z];
@@ -323,12 +322,13 @@ template <typename K, bool DIRECT>
 __global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
                                                                     const unsigned *__restrict__ part_base,
                                                                     const unsigned *__restrict__ chunk_base,
+                                                                    const unsigned short *__restrict__ chunk_zone,
                                                                     const unsigned char *__restrict__ zone_B, int nz,
                                                                     const Hdr *__restrict__ hdr, unsigned *__restrict__ part_cursor,
                                                                     K *__restrict__ parted) {
-    if (blockIdx.x >= hdr->n_chunks) return;
+    if (blockIdx.x >= hdr->n_chunks || (DIRECT && !hdr->n_direct)) return;
     __shared__ unsigned hist[DIRECT ? 1 : (1 << LDS_B)];
-    const int z = find_owner(chunk_base, nz, blockIdx.x);
+    const int z = chunk_zone[blockIdx.x];
     const int B = zone_B[z];
     if ((B > LDS_B) != DIRECT) return;
     const unsigned np = 1u << B, pb = part_base[z];
@@ -375,61 +375,110 @@ __global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__r
 // No pass over the table at the end: the add that counts a key returns how many there were before it, so the LAST of a
 // key's cells to arrive holds its multiplicity, and the maximum over every cell of (what its add returned + 1, key) is
 // the maximum over the table.
+// Persistent workgroups, one part after the other; the descriptor and the first keys of the NEXT part are fetched while
+// this one is counted (a part is ~1024 keys: without that every part is three dependent round trips to memory for a
+// microsecond of LDS work).  A wave whose 64 keys are one value (categories, quantised rasters) counts them with one add.
+constexpr int CNT_BATCH = 4;                       // keys per thread and batch: 1024 keys, the usual part in one batch
 template <typename K>
 __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, const K *__restrict__ parted,
-                                                    const unsigned *__restrict__ key_off, const unsigned *__restrict__ part_base,
                                                     const unsigned *__restrict__ part_off, const unsigned *__restrict__ part_count,
-                                                    const unsigned char *__restrict__ zone_B, int nz, Hdr *__restrict__ hdr,
-                                                    unsigned *__restrict__ best_count, K *__restrict__ best_key) {
-    if (blockIdx.x >= hdr->n_parts) return;
-    __shared__ K t_key[SLOTS];
-    __shared__ unsigned t_cnt[SLOTS];
+                                                    Hdr *__restrict__ hdr, unsigned *__restrict__ best_count, K *__restrict__ best_key) {
+    __shared__ __attribute__((aligned(16))) K t_key[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned t_cnt[SLOTS];
     __shared__ unsigned s_cnt[4];
     __shared__ K s_key[4];
     const K EMPTY = ~(K)0;                          // no finite value encodes to all-ones
-    const int z = find_owner(part_base, nz, blockIdx.x);
-    const K *src;
-    unsigned len;
-    if (zone_B[z] == 0) { src = keys + key_off[z]; len = key_off[z + 1] - key_off[z]; }
-    else { src = parted + part_off[blockIdx.x]; len = part_count[blockIdx.x]; }
-    unsigned bc = 0;
-    K bk = EMPTY;
-    if (len) {                                      // (uniform over the workgroup)
-        for (int s = threadIdx.x; s < SLOTS; s += 256) { t_key[s] = EMPTY; t_cnt[s] = 0; }
-        __syncthreads();
-        bool lost = false;
-        for (unsigned i = threadIdx.x; i < len; i += 256) {
-            const K k = src[i];
-            unsigned s = slot_of(k);
-            int probes = 0;
-            for (;;) {
-                const K prev = atomicCAS(&t_key[s], EMPTY, k);
-                if (prev == EMPTY || prev == k) {
-                    const unsigned c = atomicAdd(&t_cnt[s], 1u) + 1u;
-                    if (c > bc || (c == bc && k < bk)) { bc = c; bk = k; }
-                    break;
-                }
-                s = (s + 1) & (SLOTS - 1);
-                if (++probes >= SLOTS) { lost = true; break; }
-            }
-        }
-        if (lost) atomicAdd(&hdr->overflow, 1u);
-    }
-    // workgroup maximum of (count, then smallest key)
+    const unsigned n_parts = hdr->n_parts;
+    const int lane = threadIdx.x & 63;
+    unsigned p = blockIdx.x;
+    if (p >= n_parts) return;
+    unsigned off = part_off[p], len = part_count[p];
+    K pre[CNT_BATCH];
+    auto fetch = [&](unsigned o, unsigned l, unsigned base, K (&k)[CNT_BATCH]) {
+        const K *src = (o & IN_KEYS) ? keys + (o & ~IN_KEYS) : parted + o;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned oc = __shfl_xor(bc, off);
-        const K ok = __shfl_xor(bk, off);
-        if (oc > bc || (oc == bc && ok < bk)) { bc = oc; bk = ok; }
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            const unsigned i = base + j * 256 + threadIdx.x;
+            k[j] = i < l ? src[i] : EMPTY;
+        }
+    };
+    fetch(off, len, 0, pre);
+    bool lost = false;
+    for (;;) {
+        const unsigned pn = p + gridDim.x;
+        unsigned off_n = 0, len_n = 0;
+        if (pn < n_parts) { off_n = part_off[pn]; len_n = part_count[pn]; }
+        unsigned bc = 0;
+        K bk = EMPTY;
+        if (len) {                                  // (uniform over the workgroup)
+            {
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u *ck = reinterpret_cast<v4u *>(t_key), *cc = reinterpret_cast<v4u *>(t_cnt);
+                const v4u ones = {~0u, ~0u, ~0u, ~0u}, zeros = {0u, 0u, 0u, 0u};
+                for (int s = threadIdx.x; s < (int)(SLOTS * sizeof(K) / 16); s += 256) ck[s] = ones;
+                for (int s = threadIdx.x; s < SLOTS / 4; s += 256) cc[s] = zeros;
+            }
+            __syncthreads();
+            K cur[CNT_BATCH];
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j) cur[j] = pre[j];
+            for (unsigned base = 0; base < len; base += 256 * CNT_BATCH) {
+                // the next batch of this part, or the first of the next part, on its way while this one is counted
+                if (base + 256 * CNT_BATCH < len) fetch(off, len, base + 256 * CNT_BATCH, pre);
+                else if (pn < n_parts) fetch(off_n, len_n, 0, pre);
+#pragma unroll
+                for (int j = 0; j < CNT_BATCH; ++j) {
+                    const K k = cur[j];
+                    const bool has = k != EMPTY;
+                    const unsigned long long hm = __ballot(has);
+                    if (!hm) continue;
+                    unsigned add = 1;
+                    bool mine = has;
+                    // one value in the whole wave: its first lane adds for all
+                    const int leader = __ffsll((long long)hm) - 1;
+                    const K kl = __shfl(k, leader);
+                    if (__all(!has || k == kl)) { add = (unsigned)__popcll(hm); mine = lane == leader; }
+                    if (mine) {
+                        unsigned s = slot_of(k);
+                        int probes = 0;
+                        for (;;) {
+                            const K prev = atomicCAS(&t_key[s], EMPTY, k);
+                            if (prev == EMPTY || prev == k) {
+                                const unsigned c = atomicAdd(&t_cnt[s], add) + add;
+                                if (c > bc || (c == bc && k < bk)) { bc = c; bk = k; }
+                                break;
+                            }
+                            s = (s + 1) & (SLOTS - 1);
+                            if (++probes >= SLOTS) { lost = true; break; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CNT_BATCH; ++j) cur[j] = pre[j];
+            }
+        } else if (pn < n_parts) {
+            fetch(off_n, len_n, 0, pre);
+        }
+        // workgroup maximum of (count, then smallest key)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned oc = __shfl_xor(bc, o);
+            const K ok = __shfl_xor(bk, o);
+            if (oc > bc || (oc == bc && ok < bk)) { bc = oc; bk = ok; }
+        }
+        if (lane == 0) { s_cnt[threadIdx.x >> 6] = bc; s_key[threadIdx.x >> 6] = bk; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_cnt[w] > bc || (s_cnt[w] == bc && s_key[w] < bk)) { bc = s_cnt[w]; bk = s_key[w]; }
+            best_count[p] = bc;
+            best_key[p] = bk;
+        }
+        if (pn >= n_parts) break;
+        p = pn; off = off_n; len = len_n;
+        __syncthreads();                            // (s_cnt / the table are reused)
     }
-    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = bc; s_key[threadIdx.x >> 6] = bk; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (s_cnt[w] > bc || (s_cnt[w] == bc && s_key[w] < bk)) { bc = s_cnt[w]; bk = s_key[w]; }
-        best_count[blockIdx.x] = bc;
-        best_key[blockIdx.x] = bk;
-    }
+    if (lost) atomicAdd(&hdr->overflow, 1u);
 }
 
 // 8. best part of every zone -> the value
@@ -464,7 +513,7 @@ template <typename VT>
 struct Plan {
     using K = typename Key<VT>::K;
     size_t off_hdr, off_zone_count, off_key_off, off_zone_cursor, off_part_base, off_chunk_base, off_zone_B, off_part_count,
-        off_part_off, off_part_cursor, off_best_count, off_best_key, off_keys, off_parted, zero_bytes, total;
+        off_part_off, off_part_cursor, off_best_count, off_best_key, off_keys, off_parted, off_chunk_zone, zero_bytes, total;
     long max_parts, max_chunks;
     bool direct;
     Plan(long n, int nz) {
@@ -486,6 +535,7 @@ struct Plan {
         off_part_cursor = o; o += up256((size_t)max_parts * 4);
         off_best_count = o; o += up256((size_t)max_parts * 4);
         off_best_key = o; o += up256((size_t)max_parts * sizeof(K));
+        off_chunk_zone = o; o += up256((size_t)max_chunks * 2);
         off_keys = o; o += up256((size_t)n * sizeof(K));
         off_parted = o; o += up256((size_t)n * sizeof(K));
         total = o;
@@ -515,6 +565,7 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
              *part_base = u32(pl.off_part_base), *chunk_base = u32(pl.off_chunk_base), *part_count = u32(pl.off_part_count),
              *part_off = u32(pl.off_part_off), *part_cursor = u32(pl.off_part_cursor), *best_count = u32(pl.off_best_count);
     unsigned char *zone_B = reinterpret_cast<unsigned char *>(w + pl.off_zone_B);
+    unsigned short *chunk_zone = reinterpret_cast<unsigned short *>(w + pl.off_chunk_zone);
     K *best_key = reinterpret_cast<K *>(w + pl.off_best_key), *keys = reinterpret_cast<K *>(w + pl.off_keys),
       *parted = reinterpret_cast<K *>(w + pl.off_parted);
     XRS_HIP(hipMemsetAsync(w, 0, pl.zero_bytes, s));
@@ -527,18 +578,20 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
         XRS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, zone_count, nz, key_off, zone_cursor, part_base, chunk_base, zone_B,
-                       part_count, hdr);
+                       part_count, part_off, hdr);
+    XRS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_table_kernel, dim3(nz), dim3(256), 0, s, chunk_base, nz, chunk_zone);
     XRS_LAUNCH_CHECK();
     if (n_tiles) {
         hipLaunchKernelGGL((scatter_zone_kernel<VT>), dim3((unsigned)n_tiles), dim3(TILE_THREADS), zone_lds, s, zidx, vals, n, nz, nodata,
                            has_nodata, zone_cursor, keys);
         XRS_LAUNCH_CHECK();
         hipLaunchKernelGGL((part_hist_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
-                           part_base, chunk_base, zone_B, nz, hdr, part_count);
+                           part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_count);
         XRS_LAUNCH_CHECK();
         if (pl.direct) {                           // only a raster large enough to hold a zone of more than 2^LDS_B parts
             hipLaunchKernelGGL((part_hist_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
-                               part_base, chunk_base, zone_B, nz, hdr, part_count);
+                               part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_count);
             XRS_LAUNCH_CHECK();
         }
     }
@@ -546,16 +599,26 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
     XRS_LAUNCH_CHECK();
     if (n_tiles) {
         hipLaunchKernelGGL((scatter_part_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
-                           part_base, chunk_base, zone_B, nz, hdr, part_cursor, parted);
+                           part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_cursor, parted);
         XRS_LAUNCH_CHECK();
         if (pl.direct) {
             hipLaunchKernelGGL((scatter_part_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
-                               part_base, chunk_base, zone_B, nz, hdr, part_cursor, parted);
+                               part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_cursor, parted);
             XRS_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL((count_kernel<K>), dim3((unsigned)pl.max_parts), dim3(256), 0, s, keys, parted, key_off, part_base, part_off,
-                       part_count, zone_B, nz, hdr, best_count, best_key);
+    {
+        static thread_local int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const long slots = (long)cus * (160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64));
+        hipLaunchKernelGGL((count_kernel<K>), dim3((unsigned)(slots < pl.max_parts ? slots : pl.max_parts)), dim3(256), 0, s, keys, parted,
+                           part_off, part_count, hdr, best_count, best_key);
+    }
     XRS_LAUNCH_CHECK();
     hipLaunchKernelGGL((reduce_kernel<VT>), dim3(nz), dim3(64), 0, s, best_count, best_key, part_base, nz, hdr, majority);
     XRS_LAUNCH_CHECK();

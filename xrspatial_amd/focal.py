@@ -113,11 +113,14 @@ def _focal_stats_banded(host, kernel, stats):
         for s, ptr in zip(stats, out_ptrs):
             ptrs[_STAT_INDEX[s]] = ptr
         # one workspace per band launch (the bands run on several streams: no shared tile map) -- np.ones boxes then take the
-        # separable walk here as they do for device-resident rasters, so both backends give the same var / std; the block goes
-        # back to the pool behind the launch, fenced on `stream` (device.py)
+        # separable walk here as they do for device-resident rasters, so both backends give the same var / std
         work = _window_workspace(k, n_rows, cols)
         _stats_call(in_ptr, ptrs, mask, n_rows, cols, cols, cols, k, work, ht, hb, stream)
+        keep.append(work)
 
+    # (the workspaces live until pipelined_rows has synchronised its streams: a block freed earlier is fenced on the GLOBAL
+    # stream by device.py, not on the band's, and could be handed out again while the band's kernels still use it)
+    keep = []
     return pipelined_rows(host, [np.float32] * len(stats), launch, k.shape[0] // 2)
 
 
@@ -127,8 +130,10 @@ def _window_workspace(k, rows=0, cols=0):
     separable box walk (csrc/boxsep.hip; xrs_focal_workspace_bytes).  The block goes back to the pool behind the launch on
     the launch's stream (device.py fences recycled blocks with an event), so nobody has to wait for it."""
     big = max(k.shape) > 63
-    box = k.shape[0] == k.shape[1] and 9 <= k.shape[0] <= 25 and bool((k == 1.0).all())
-    if not (big or box):
+    # 9x9 .. 25x25: the moments kernels (circles, boxes, annuli) note the tiles their fast walks hand on -- the rim of a
+    # nodata region, dense nodata -- in a work-list inside this block (csrc/mom_impl.h: focal_mom_rescue_kernel)
+    walked = k.shape[0] == k.shape[1] and 9 <= k.shape[0] <= 25 and k.shape[0] % 2 == 1
+    if not (big or walked):
         return None
     return DeviceArray((int(_lib.load().xrs_focal_workspace_bytes(int(rows), int(cols), k.shape[0], k.shape[1])),), np.uint8)
 

@@ -608,6 +608,29 @@ def test_zonal_one_pass_window_host_logic(monkeypatch):
     assert zmod._one_pass_partials(xs.DeviceArray.from_numpy(wide), vd, None) is None
 
 
+def _second_largest(w):
+    v = np.sort(w[np.isfinite(w)])
+    return v[-2] if v.size > 1 else np.nan
+
+
+def test_dask_block_functions_pickle():
+    """What the dask slot hands to map_overlap / map_blocks must survive cloudpickle (dask's process and distributed
+    schedulers ship it to workers): a module-level function + functools.partial, the lock looked up where the block runs."""
+    import functools
+    import pickle
+    import cloudpickle
+    from xrspatial_amd import utils, focal as xfocal
+    k = np.ones((3, 3))
+
+    def nested_runner(data, kernel, stat):                     # (the public functions pass closures like this one)
+        return xfocal._focal_stats_hip(data, kernel, [stat])[stat]
+    for block_func, args in ((xfocal._apply_callable, (k, _second_largest)), (nested_runner, (k, 'mean'))):
+        blob = cloudpickle.dumps(functools.partial(utils._run_block, block_func, args, {}))
+        back = pickle.loads(blob)
+        assert back.func.__name__ == '_run_block' and back.args[1][0].shape == (3, 3)
+    assert b'_thread' not in blob
+
+
 def test_dask_slot_runs_block_by_block(monkeypatch):
     """The dask slot of the public functions (utils.py: dask_overlap / dask_blocks): the reference wraps its numpy runners in
     map_overlap(depth, boundary=nan) / map_blocks (slope.py:86-97, aspect.py:151-160, curvature.py:56-59, hillshade.py:42-45,
@@ -639,6 +662,8 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
         'focal.apply': lambda a: xfocal.apply(a, k5),
         'focal_stats': lambda a: xfocal.focal_stats(a, k5, stats_funcs=['max', 'mean', 'std']),
         'convolution_2d': lambda a: convolution.convolution_2d(a, k5 / k5.sum()),
+        # a user callable: the reference's _apply_dask_numpy runs it per chunk (focal.py:329-340), never on the whole raster
+        'focal.apply(callable)': lambda a: xfocal.apply(a, k5, func=_second_largest),
     }
     for name, fn in cases.items():
         want = fn(host)

@@ -740,7 +740,8 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
 // over it, flat ground next to relief -- takes the exact float64 column walker.
 constexpr int RESCUE_FIX = 1024;
 template <int R, typename Shape, int OM>
-__global__ void __launch_bounds__(256) focal_mom_rescue_kernel(const MomArgs a) {
+__global__ void __launch_bounds__(256, 2) focal_mom_rescue_kernel(const MomArgs a) {     // (2 waves per SIMD: the float64 walker behind
+                                                                                          //  the band may spill; it is the rare path)
     using C = MomCfg<R, Shape>;
     __shared__ __attribute__((aligned(16))) float stage[4][2 * (64 + 2 * R)];
     __shared__ unsigned short fixes[4][RESCUE_FIX];
@@ -749,8 +750,12 @@ __global__ void __launch_bounds__(256) focal_mom_rescue_kernel(const MomArgs a) 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WalkGeom &g = a.g;
-    // bands of ~48 output rows while fewer than ~8 waves per CU would be busy otherwise
-    const int nb = (long)count * C::NC >= 2048 ? 1 : (a.tile_rows + 47) / 48;
+    // as many bands per half tile as there are waves to take them (every band pays 2R rows of run-in: latency against work),
+    // of 16 output rows at least
+    const long waves = (long)gridDim.x * 4;
+    long want_nb = waves / ((long)count * C::NC);
+    const int max_nb = (a.tile_rows + 15) / 16;
+    const int nb = want_nb < 1 ? 1 : want_nb > max_nb ? max_nb : (int)want_nb;
     const int band_rows = (a.tile_rows + nb - 1) / nb;
     const long items = (long)count * C::NC * nb;
     for (long it = (long)blockIdx.x * 4 + wv; it < items; it += (long)gridDim.x * 4) {
@@ -766,9 +771,15 @@ __global__ void __launch_bounds__(256) focal_mom_rescue_kernel(const MomArgs a) 
         const long y0 = yt0 + (long)band * band_rows;
         const long y_end = y0 + band_rows < yt1 ? y0 + band_rows : yt1;
         if (y0 >= y_end) continue;
+#ifdef XRS_RESCUE_EXACT_ONLY        // (probe builds: which stage of the rescue is responsible for a wrong cell)
+        mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end, q, 1);
+        continue;
+#endif
         MomWalkN<R, Shape, OM> w(a, stage[wv], xw, y0, y_end, lane);
+#ifndef XRS_RESCUE_NO_FIX
         w.fix_list = fixes[wv];
         w.fix_cap = RESCUE_FIX;
+#endif
         if (w.run()) {
             if (w.n_fix) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -830,7 +841,7 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
         hipDeviceProp_t prop;
         static thread_local int cus = 0;
         if (!cus) cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : n_cu;
-        hipLaunchKernelGGL((focal_mom_rescue_kernel<R, Shape, 0>), dim3((unsigned)(cus * 4)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((focal_mom_rescue_kernel<R, Shape, 0>), dim3((unsigned)(cus * 2)), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
     return 0;

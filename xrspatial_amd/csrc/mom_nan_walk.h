@@ -157,15 +157,23 @@ struct MomWalkN {
     // plane 3.3; the tile row along the lower rim of a nodata region likewise.  Before the first valid cell every sum is
     // zero, so the shift is free to be anything: it is simply not chosen yet.)
     __device__ __forceinline__ void first_shift() {
-        float s = 0.0f, n = 0.0f;
+        // (the HALO cells count too: a half tile whose own 64 staged columns are all nodata while its halo columns hold data
+        // -- the last columns left of a region's rim -- was never "seeded" by its own cells, and this function then put c back
+        // to 0 at the head of EVERY round, under sums accumulated about the shift the re-centring had moved to: garbage that
+        // no guard sees.  Masked until round 6 because such a tile always held a window that failed and went to the exact
+        // walker as a whole; tools/rescue_debug.py found it the day single windows began to be repaired.)
+        float s = 0.0f, n = 0.0f, sh = 0.0f, nh = 0.0f;
 #pragma unroll
         for (int r = 0; r < U; ++r) {
             const bool ok = isfinite(pf_own[r]);
             s += ok ? pf_own[r] : 0.0f;
             n += ok ? 1.0f : 0.0f;
+            const bool okh = lane < 2 * R && isfinite(pf_halo[r]);
+            sh += okh ? pf_halo[r] : 0.0f;
+            nh += okh ? 1.0f : 0.0f;
         }
-        const float m = n > 0.0f ? s / n : 0.0f;
-        const unsigned long long have = __ballot(n > 0.0f);
+        const float m = n > 0.0f ? s / n : nh > 0.0f ? sh / nh : 0.0f;
+        const unsigned long long have = __ballot(n > 0.0f || nh > 0.0f);
         const float m_any = __shfl(m, have ? __ffsll((long long)have) - 1 : 0);      // (every lane executes the shuffle)
         c = n > 0.0f ? m : have ? m_any : 0.0f;
         seeded = have != 0;
@@ -415,6 +423,9 @@ __device__ __forceinline__ void mom_fix_cells(const MomArgs &a, const unsigned s
             const double vr = q / cnt;
             mean = (float)m; var = (float)vr; sd = (float)sqrt(vr);
         }
+#ifdef XRS_RESCUE_MARK             // (probe builds: flagged windows show up as -12345 in the mean plane)
+        mean = -12345.0f;
+#endif
         if (lane == 0) {
             const long off = yo * g.ld_out + x;
             if (a.out_mean) a.out_mean[off] = mean;

@@ -432,7 +432,9 @@ template <typename VT>
 __global__ void __launch_bounds__(1024) zonal_sample_kernel(const int32_t *zones, const VT *vals, long n, long n_samples, VT nodata,
                                                             int has_nodata, SampleResult *out) {
     // an odd stride (co-prime to the power-of-two row pitches zone blocks align with) and a start in the middle of it
-    const long stride = ((n / n_samples) | 1L) > 0 ? ((n / n_samples) | 1L) : 1L;
+    // (rounded UP: with n / n_samples a raster of 64 K .. 128 K cells got stride 1 and only its first n_samples cells looked at;
+    //  the positions wrap around the end instead)
+    const long stride = ((n + n_samples - 1) / n_samples) | 1L;
     const long k = (long)blockIdx.x * 1024 + threadIdx.x;
     int zlo = 0x7fffffff, zhi = (int)0x80000000;
     double sum = 0.0;

@@ -33,6 +33,8 @@ namespace {
 constexpr int TILE_THREADS = 256;
 constexpr int PER_THREAD = 16;
 constexpr int TILE = TILE_THREADS * PER_THREAD;   // cells / keys per workgroup of the scatter passes
+constexpr int CHUNK_THREADS = 1024;               // the part passes: 16384 keys per workgroup -- a zone of 2^10 parts then gets 16 keys =
+constexpr int CHUNK = CHUNK_THREADS * PER_THREAD;  // one 64-byte line per part and chunk (4096-key chunks: 16-byte runs, 2 TB/s)
 constexpr int PART_TARGET = 1024;                 // a zone is cut into 2^B parts of (512, 1024] keys on average
 constexpr int MAX_B = 16;                         // most parts per zone
 constexpr int LDS_B = 11;                         // zones of up to 2^LDS_B parts: per-chunk LDS histogram (8 KiB); above: one
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(1024) plan_kernel(const unsigned *__restrict__
         const int z = z0 + threadIdx.x;
         const unsigned c = z < nz ? zone_count[z] : 0;
         const int B = parts_log2(c);
-        unsigned v[3] = {c, z < nz ? (1u << B) : 0u, B ? (c + TILE - 1) / TILE : 0u};
+        unsigned v[3] = {c, z < nz ? (1u << B) : 0u, B ? (c + CHUNK - 1) / CHUNK : 0u};
         unsigned incl[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(256) chunk_table_kernel(const unsigned *__rest
 // 4. histogram of the parts of every cut zone.  DIRECT = false: zones of up to 2^LDS_B parts, through an LDS histogram of the
 // chunk; DIRECT = true: the zones above (a chunk meets each of their parts less than twice: nothing to aggregate).
 template <typename K, bool DIRECT>
-__global__ void __launch_bounds__(TILE_THREADS) part_hist_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
+__global__ void __launch_bounds__(CHUNK_THREADS) part_hist_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
                                                                  const unsigned *__restrict__ part_base,
                                                                  const unsigned *__restrict__ chunk_base,
                                                                  const unsigned short *__restrict__ chunk_zone,
@@ -264,13 +266,13 @@ __global__ void __launch_bounds__(TILE_THREADS) part_hist_kernel(const K *__rest
     if ((B > LDS_B) != DIRECT) return;
     const unsigned np = 1u << B, pb = part_base[z];
     if (!DIRECT) {
-        for (unsigned d = threadIdx.x; d < np; d += TILE_THREADS) hist[d] = 0;
+        for (unsigned d = threadIdx.x; d < np; d += CHUNK_THREADS) hist[d] = 0;
         __syncthreads();
     }
-    const unsigned lo = key_off[z] + (blockIdx.x - chunk_base[z]) * TILE, hi = key_off[z + 1];
+    const unsigned lo = key_off[z] + (blockIdx.x - chunk_base[z]) * CHUNK, hi = key_off[z + 1];
 #pragma unroll 4
     for (int j = 0; j < PER_THREAD; ++j) {
-        const unsigned i = lo + j * TILE_THREADS + threadIdx.x;
+        const unsigned i = lo + j * CHUNK_THREADS + threadIdx.x;
         if (i < hi) {
             const unsigned d = part_of<K>(keys[i], B);
             if (DIRECT) atomicAdd(&part_count[pb + d], 1u);
@@ -279,17 +281,17 @@ __global__ void __launch_bounds__(TILE_THREADS) part_hist_kernel(const K *__rest
     }
     if (!DIRECT) {
         __syncthreads();
-        for (unsigned d = threadIdx.x; d < np; d += TILE_THREADS)
+        for (unsigned d = threadIdx.x; d < np; d += CHUNK_THREADS)
             if (hist[d]) atomicAdd(&part_count[pb + d], hist[d]);
     }
 }
 
 // 5. offsets of the parts: per zone, an exclusive scan of its part counts behind the zone's key offset
 __global__ void __launch_bounds__(256) part_offsets_kernel(const unsigned *__restrict__ part_count, const unsigned *__restrict__ key_off,
-                                                           const unsigned *__restrict__ part_base, int nz,
-                                                           unsigned *__restrict__ part_off, unsigned *__restrict__ part_cursor) {
+                                                           const unsigned *__restrict__ part_base, const unsigned char *__restrict__ zone_B,
+                                                           int nz, unsigned *__restrict__ part_off, unsigned *__restrict__ part_cursor) {
     const int z = blockIdx.x;
-    if (z >= nz) return;
+    if (z >= nz || zone_B[z] == 0) return;       // (an uncut zone is its own part: described by the plan, IN_KEYS)
     __shared__ unsigned s_wave[4];
     __shared__ unsigned s_carry;
     const unsigned pb = part_base[z], np = part_base[z + 1] - pb;
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(256) part_offsets_kernel(const unsigned *__res
 
 // 6. keys of a cut zone -> its parts
 template <typename K, bool DIRECT>
-__global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
+__global__ void __launch_bounds__(CHUNK_THREADS) scatter_part_kernel(const K *__restrict__ keys, const unsigned *__restrict__ key_off,
                                                                     const unsigned *__restrict__ part_base,
                                                                     const unsigned *__restrict__ chunk_base,
                                                                     const unsigned short *__restrict__ chunk_zone,
@@ -332,11 +334,11 @@ __global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__r
     const int B = zone_B[z];
     if ((B > LDS_B) != DIRECT) return;
     const unsigned np = 1u << B, pb = part_base[z];
-    const unsigned lo = key_off[z] + (blockIdx.x - chunk_base[z]) * TILE, hi = key_off[z + 1];
+    const unsigned lo = key_off[z] + (blockIdx.x - chunk_base[z]) * CHUNK, hi = key_off[z + 1];
     if (DIRECT) {
 #pragma unroll 4
         for (int j = 0; j < PER_THREAD; ++j) {
-            const unsigned i = lo + j * TILE_THREADS + threadIdx.x;
+            const unsigned i = lo + j * CHUNK_THREADS + threadIdx.x;
             if (i < hi) {
                 const K k = keys[i];
                 parted[atomicAdd(&part_cursor[pb + part_of<K>(k, B)], 1u)] = k;
@@ -344,13 +346,13 @@ __global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__r
         }
         return;
     }
-    for (unsigned d = threadIdx.x; d < np; d += TILE_THREADS) hist[d] = 0;
+    for (unsigned d = threadIdx.x; d < np; d += CHUNK_THREADS) hist[d] = 0;
     __syncthreads();
     K key[PER_THREAD];
     unsigned part[PER_THREAD], rank[PER_THREAD];
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j) {
-        const unsigned i = lo + j * TILE_THREADS + threadIdx.x;
+        const unsigned i = lo + j * CHUNK_THREADS + threadIdx.x;
         part[j] = 0xffffffffu;
         rank[j] = 0;
         key[j] = 0;
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(TILE_THREADS) scatter_part_kernel(const K *__r
         }
     }
     __syncthreads();
-    for (unsigned d = threadIdx.x; d < np; d += TILE_THREADS) {
+    for (unsigned d = threadIdx.x; d < np; d += CHUNK_THREADS) {
         const unsigned c = hist[d];
         if (c) hist[d] = atomicAdd(&part_cursor[pb + d], c);
     }
@@ -426,32 +428,50 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
                 // the next batch of this part, or the first of the next part, on its way while this one is counted
                 if (base + 256 * CNT_BATCH < len) fetch(off, len, base + 256 * CNT_BATCH, pre);
                 else if (pn < n_parts) fetch(off_n, len_n, 0, pre);
+                // the batch's keys probe TOGETHER: a compare-and-swap and an add that return are ~2 x 150 cycles of LDS latency
+                // per probe, and one key after the other is four such chains in a row; four slots in flight instead
+                unsigned slot[CNT_BATCH], add[CNT_BATCH];
+                unsigned open = 0;                     // bit j: key j has not been counted yet
 #pragma unroll
                 for (int j = 0; j < CNT_BATCH; ++j) {
                     const K k = cur[j];
                     const bool has = k != EMPTY;
-                    const unsigned long long hm = __ballot(has);
-                    if (!hm) continue;
-                    unsigned add = 1;
+                    slot[j] = slot_of(k);
+                    add[j] = 1;
                     bool mine = has;
-                    // one value in the whole wave: its first lane adds for all
-                    const int leader = __ffsll((long long)hm) - 1;
-                    const K kl = __shfl(k, leader);
-                    if (__all(!has || k == kl)) { add = (unsigned)__popcll(hm); mine = lane == leader; }
-                    if (mine) {
-                        unsigned s = slot_of(k);
-                        int probes = 0;
-                        for (;;) {
-                            const K prev = atomicCAS(&t_key[s], EMPTY, k);
-                            if (prev == EMPTY || prev == k) {
-                                const unsigned c = atomicAdd(&t_cnt[s], add) + add;
-                                if (c > bc || (c == bc && k < bk)) { bc = c; bk = k; }
-                                break;
-                            }
-                            s = (s + 1) & (SLOTS - 1);
-                            if (++probes >= SLOTS) { lost = true; break; }
-                        }
+                    const unsigned long long hm = __ballot(has);
+                    if (hm) {
+                        // one value in the whole wave (categories, quantised rasters): its first lane adds for all
+                        const int leader = __ffsll((long long)hm) - 1;
+                        const K kl = __shfl(k, leader);
+                        if (__all(!has || k == kl)) { add[j] = (unsigned)__popcll(hm); mine = lane == leader; }
                     }
+                    open |= mine ? 1u << j : 0u;
+                }
+                for (int probes = 0; __any(open != 0); ++probes) {
+                    K prev[CNT_BATCH];
+#pragma unroll
+                    for (int j = 0; j < CNT_BATCH; ++j)
+                        if (open >> j & 1) prev[j] = atomicCAS(&t_key[slot[j]], EMPTY, cur[j]);
+                    unsigned got = 0;
+#pragma unroll
+                    for (int j = 0; j < CNT_BATCH; ++j) {
+                        if (!(open >> j & 1)) continue;
+                        if (prev[j] == EMPTY || prev[j] == cur[j]) got |= 1u << j;
+                        else slot[j] = (slot[j] + 1) & (SLOTS - 1);
+                    }
+                    unsigned cnt[CNT_BATCH];
+#pragma unroll
+                    for (int j = 0; j < CNT_BATCH; ++j)
+                        if (got >> j & 1) cnt[j] = atomicAdd(&t_cnt[slot[j]], add[j]) + add[j];
+#pragma unroll
+                    for (int j = 0; j < CNT_BATCH; ++j)
+                        if (got >> j & 1) {
+                            const K k = cur[j];
+                            if (cnt[j] > bc || (cnt[j] == bc && k < bk)) { bc = cnt[j]; bk = k; }
+                        }
+                    open &= ~got;
+                    if (probes >= SLOTS) { lost = lost || open != 0; break; }
                 }
 #pragma unroll
                 for (int j = 0; j < CNT_BATCH; ++j) cur[j] = pre[j];
@@ -518,9 +538,9 @@ struct Plan {
     bool direct;
     Plan(long n, int nz) {
         direct = n > ((long)PART_TARGET << LDS_B);
-        // sum over zones of 2^B <= 2 n / PART_TARGET + nz; of ceil(count / TILE) <= n / TILE + nz
+        // sum over zones of 2^B <= 2 n / PART_TARGET + nz; of ceil(count / CHUNK) <= n / CHUNK + nz
         max_parts = 2 * (n / PART_TARGET + 1) + nz;
-        max_chunks = n / TILE + 1 + nz;
+        max_chunks = n / CHUNK + 1 + nz;
         size_t o = 0;
         off_hdr = o; o += 256;
         off_zone_count = o; o += up256((size_t)nz * 4);
@@ -586,23 +606,23 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
         hipLaunchKernelGGL((scatter_zone_kernel<VT>), dim3((unsigned)n_tiles), dim3(TILE_THREADS), zone_lds, s, zidx, vals, n, nz, nodata,
                            has_nodata, zone_cursor, keys);
         XRS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((part_hist_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
+        hipLaunchKernelGGL((part_hist_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(CHUNK_THREADS), 0, s, keys, key_off,
                            part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_count);
         XRS_LAUNCH_CHECK();
         if (pl.direct) {                           // only a raster large enough to hold a zone of more than 2^LDS_B parts
-            hipLaunchKernelGGL((part_hist_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
+            hipLaunchKernelGGL((part_hist_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(CHUNK_THREADS), 0, s, keys, key_off,
                                part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_count);
             XRS_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(part_offsets_kernel, dim3(nz), dim3(256), 0, s, part_count, key_off, part_base, nz, part_off, part_cursor);
+    hipLaunchKernelGGL(part_offsets_kernel, dim3(nz), dim3(256), 0, s, part_count, key_off, part_base, zone_B, nz, part_off, part_cursor);
     XRS_LAUNCH_CHECK();
     if (n_tiles) {
-        hipLaunchKernelGGL((scatter_part_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
+        hipLaunchKernelGGL((scatter_part_kernel<K, false>), dim3((unsigned)pl.max_chunks), dim3(CHUNK_THREADS), 0, s, keys, key_off,
                            part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_cursor, parted);
         XRS_LAUNCH_CHECK();
         if (pl.direct) {
-            hipLaunchKernelGGL((scatter_part_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(TILE_THREADS), 0, s, keys, key_off,
+            hipLaunchKernelGGL((scatter_part_kernel<K, true>), dim3((unsigned)pl.max_chunks), dim3(CHUNK_THREADS), 0, s, keys, key_off,
                                part_base, chunk_base, chunk_zone, zone_B, nz, hdr, part_cursor, parted);
             XRS_LAUNCH_CHECK();
         }
@@ -615,7 +635,9 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
         }
-        const long slots = (long)cus * (160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64));
+        // (an ODD number of workgroups: the heavy parts of a categorical raster sit at the same offsets d in every zone's
+        //  2^B parts, and a stride that divides 2^B hands all of them to the same few workgroups: 55 ms instead of 5)
+        const long slots = ((long)cus * (160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64)) - 1) | 1;
         hipLaunchKernelGGL((count_kernel<K>), dim3((unsigned)(slots < pl.max_parts ? slots : pl.max_parts)), dim3(256), 0, s, keys, parted,
                            part_off, part_count, hdr, best_count, best_key);
     }

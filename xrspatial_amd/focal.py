@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import copy
 import ctypes
+import os
 
 import numpy as np
 
@@ -133,6 +134,8 @@ def _window_workspace(k, rows=0, cols=0):
     # 9x9 .. 25x25: the moments kernels (circles, boxes, annuli) note the tiles their fast walks hand on -- the rim of a
     # nodata region, dense nodata -- in a work-list inside this block (csrc/mom_impl.h: focal_mom_rescue_kernel)
     walked = k.shape[0] == k.shape[1] and 9 <= k.shape[0] <= 25 and k.shape[0] % 2 == 1
+    if os.environ.get("XRS_MOM_RESCUE") == "0":            # (A/B: no work-list, slow tiles are walked in place as before round 6)
+        walked = bool((k == 1.0).all())
     if not (big or walked):
         return None
     return DeviceArray((int(_lib.load().xrs_focal_workspace_bytes(int(rows), int(cols), k.shape[0], k.shape[1])),), np.uint8)
@@ -312,6 +315,11 @@ def apply(raster, kernel, func=_calc_mean, name='focal_apply'):
     if scope is not None and stat == 'mean':
         return scope.defer('focal_mean', raster, name, {'kernel': _kernel_f64(kernel)})
 
+    if stat is None and is_dask(raster.data):
+        # focal.py:329-340 (`_apply_dask_numpy`): the user's callable per chunk, lazily -- the windows of a block are
+        # gathered on the device and reduced on the host when the block is computed, never the whole raster at once
+        out = dask_overlap(_apply_callable, (kernel.shape[0] // 2, kernel.shape[1] // 2))(raster.data, kernel, func)
+        return DataArray(out, name=name, coords=raster.coords, dims=raster.dims, attrs=raster.attrs)
     if stat is None:
         out = _apply_callable(raster.data, kernel, func)
         if isinstance(raster.data, ShardedArray):             # the result is a shard again, like every other operator's

@@ -7,6 +7,7 @@ get_dataarray_resolution (:233-277), not_implemented_func (:113-114).
 """
 from __future__ import annotations
 
+import functools
 import threading
 
 import numpy as np
@@ -39,6 +40,14 @@ def is_dask(data) -> bool:
 _DASK_BLOCK_LOCK = threading.Lock()
 
 
+def _run_block(block_func, args, kwargs, *blocks):
+    """One dask block (or one block of each raster) through a numpy runner.  Module level on purpose: dask pickles the
+    block function for its process / distributed schedulers, and a closure defined inside dask_overlap would drag the
+    lock below along by value ("cannot pickle '_thread.lock'"); here it is looked up when the block runs."""
+    with _DASK_BLOCK_LOCK:
+        return np.asarray(block_func(*[np.ascontiguousarray(b) for b in blocks], *args, **kwargs))
+
+
 def dask_overlap(block_func, depth, meta=None):
     """The dask slot of a stencil runner.  The reference wraps its numpy runner in
     `data.map_overlap(func, depth=depth, boundary=np.nan, meta=np.array(()))` (slope.py:86-97, aspect.py:151-160,
@@ -46,15 +55,13 @@ def dask_overlap(block_func, depth, meta=None):
     block (with `depth` cells of its neighbours, NaN beyond the raster) goes through this package's numpy runner --
     staged through HBM, computed by the HIP kernels, brought back -- and dask trims the overlap.  Lazy like upstream:
     nothing runs before `.compute()`.  (Rasters that fit one node's GPUs are better served as a `ShardedArray`; this slot
-    exists so that a dask-backed DataArray that worked upstream works here.)"""
+    exists so that a dask-backed DataArray that worked upstream works here.)  `meta` is the reference's, float64 `np.array(())`
+    over float32 blocks included: what `.dtype` says before `.compute()` is upstream's answer too."""
     def run(data, *args, **kwargs):
         if not np.issubdtype(data.dtype, np.floating):
             data = data.astype(np.float32)      # (a NaN boundary needs a float raster; the runners cast to float32 anyway)
-
-        def on_block(block):
-            with _DASK_BLOCK_LOCK:
-                return np.asarray(block_func(np.ascontiguousarray(block), *args, **kwargs))
-        return data.map_overlap(on_block, depth=depth, boundary=np.nan, meta=np.array(()) if meta is None else meta)
+        return data.map_overlap(functools.partial(_run_block, block_func, args, kwargs), depth=depth, boundary=np.nan,
+                                meta=np.array(()) if meta is None else meta)
     return run
 
 
@@ -62,10 +69,7 @@ def dask_blocks(block_func):
     """The dask slot of a per-cell runner over one or more equally chunked rasters: `da.map_blocks(func, *arrays,
     meta=np.array(()))` around the numpy runner (multispectral.py:60-63, 205-208, 845-848 ...)."""
     def run(*arrays):
-        def on_blocks(*blocks):
-            with _DASK_BLOCK_LOCK:
-                return np.asarray(block_func(*[np.ascontiguousarray(b) for b in blocks]))
-        return da.map_blocks(on_blocks, *arrays, meta=np.array(()))
+        return da.map_blocks(functools.partial(_run_block, block_func, (), {}), *arrays, meta=np.array(()))
     return run
 
 

@@ -438,7 +438,7 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
         if tab is not None:
             unique_zones, zmin, rng, lut_dev = tab
             nz = len(unique_zones)
-            _, vdev = _stage(zones_data, values_data)
+            # (the values staged for the one-pass attempt above: not uploaded a second time)
             count, s1, s2, mn, mx, shift = zonal_partials(zones_data, vdev, nz, nodata_values, comm, table=(zmin, rng, lut_dev))
             cols = finalize_stats(stat_names, count, s1, s2, mn, mx, None, shift)
             if zone_ids is None:

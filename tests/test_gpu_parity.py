@@ -19,6 +19,12 @@ from xrspatial_amd.focal import apply, focal_stats, _calc_sum
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+# Large-window moments (9x9 .. 25x25) on tiles with nodata / at the raster edge: float32 sums about a shift that trails the walk,
+# a guard per window (amplification <= 2.5 in the rescue walker), windows that fail it recomputed in float64.  Until round 6 ONE
+# failing window sent its whole tile through the float64 walker, and on the small rasters of these tests (every tile an edge tile,
+# every raster with a NaN block) that made the results float64-exact by accident; a window now stands on its own guard.  Measured
+# <= 2.4e-6 on these rasters; DESIGN.md documents 5e-6 for this path, north_star asks for 1e-5.
+RIM_MOMENT_RTOL = 3e-6
 
 
 
@@ -314,7 +320,7 @@ def test_kxk_vs_oracle(kname, shape):
         elif stat in ('max', 'min', 'range'):
             np.testing.assert_array_equal(got.data[i], want, err_msg=stat)
         else:
-            np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=stat)
+            np.testing.assert_allclose(got.data[i], want, rtol=RIM_MOMENT_RTOL if max(k.shape) >= 9 else 1e-6, atol=1e-9, equal_nan=True, err_msg=stat)
     np.testing.assert_allclose(apply(agg, k).data, corc.focal_apply(z, k, 'mean'), rtol=1e-6, equal_nan=True)
     check_window_sum(apply(agg, k, _calc_sum).data, z, k, kname)
 
@@ -344,9 +350,9 @@ def test_circular_masks_column_walker(radius, shape_kind):
             check_window_sum(got.data[0], z, k, f"sum {shape}")
             for i, stat in ((1, 'max'), (2, 'min'), (3, 'range')):
                 np.testing.assert_array_equal(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), err_msg=f"{stat} {shape}")
-            for i, stat in ((4, 'mean'), (5, 'var'), (6, 'std')):     # float64 moments (kxk_circle64.hip)
-                np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=0,
-                                           equal_nan=True, err_msg=f"{stat} {shape}")
+            for i, stat in ((4, 'mean'), (5, 'var'), (6, 'std')):
+                np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6 if stat == 'mean' else RIM_MOMENT_RTOL,
+                                           atol=0, equal_nan=True, err_msg=f"{stat} {shape}")
         if shape[0] > 100:
             inner = got.data[5][100 + radius:140 - radius, 200 + radius:280 - radius]
             assert inner.size and (inner == 0).all()
@@ -584,7 +590,7 @@ def test_large_window_statistic_subsets():
         for names in subsets:
             got = focal_stats(raster(z), k, stats_funcs=names).data
             for i, st in enumerate(names):
-                np.testing.assert_allclose(got[i], want[st], rtol=2e-6 if st != 'sum' else 1e-5, atol=0, equal_nan=True,
+                np.testing.assert_allclose(got[i], want[st], rtol=RIM_MOMENT_RTOL if st != 'sum' else 1e-5, atol=0, equal_nan=True,
                                            err_msg=f"{kind} r={radius} {names} -> {st}")
                 parity_log.record(f'{shape[0]}x{shape[1]}', f'focal_stats {kind}{K} subset {st}', got[i], want[st])
         for st, fn in (('max', xfocal._calc_max), ('min', xfocal._calc_min), ('range', xfocal._calc_range), ('std', xfocal._calc_std),
@@ -620,8 +626,10 @@ def test_flat_windows_have_exactly_zero_variance():
             np.testing.assert_array_equal(got.data[1][inner], 0.0, err_msg=f"{name} var {val}")
             np.testing.assert_array_equal(got.data[2][inner], 0.0, err_msg=f"{name} std {val}")
         for i, stat in enumerate(('mean', 'var', 'std')):
-            np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=1e-6, atol=0,
-                                       equal_nan=True, err_msg=f"{name} {stat}")
+            # (5e-6 for the large windows: the blocks of 16777217.0 and 3.3e-5 sit next to relief around 2000, windows across their
+            # rims are the worst conditioning a float32 sum about one shift meets)
+            np.testing.assert_allclose(got.data[i], corc.focal_apply(z, k, stat, nthreads=8), rtol=5e-6 if k.shape[0] >= 9 and stat != 'mean' else 1e-6,
+                                       atol=0, equal_nan=True, err_msg=f"{name} {stat}")
 
 
 @pytest.mark.parametrize("shape_kind", ["circle", "box"])
@@ -1753,7 +1761,7 @@ def test_banded_host_pipeline_equals_single_call(monkeypatch):
                 # float32 in wide_impl.h): cutting the raster into bands moves the tiles, and the last bit may move with them
                 # (std / var of the float32 moments kernels: each within ~2e-7 of the float64 result, the raster here has
                 # NaN cells, and the NaN-aware walker's shift follows the tile too)
-                tol = 1e-6 if stat in ('std', 'var') else 2e-6 if stat == 'sum' else 3e-7        # (sum: n c + S in float32)
+                tol = RIM_MOMENT_RTOL if stat in ('std', 'var') else 2e-6 if stat == 'sum' else 3e-7        # (sum: n c + S in float32)
                 np.testing.assert_allclose(got.data[i], want[i], rtol=tol, atol=0, equal_nan=True, err_msg=f"focal_stats {stat} {k.shape}")
             else:
                 np.testing.assert_array_equal(got.data[i], want[i], err_msg=f"focal_stats {stat} {k.shape}")
@@ -2266,7 +2274,7 @@ def test_large_mask_stats_conditioning():
         elif stat in ('min', 'max'):
             np.testing.assert_array_equal(got.data[i], want, err_msg=stat)
         else:
-            np.testing.assert_allclose(got.data[i], want, rtol=1e-6, atol=0, equal_nan=True, err_msg=stat)
+            np.testing.assert_allclose(got.data[i], want, rtol=1e-6 if stat == 'mean' else RIM_MOMENT_RTOL, atol=0, equal_nan=True, err_msg=stat)
     lake_var = got.data[1][45:65, 115:175]
     assert (lake_var[np.isfinite(lake_var)] >= 0).all()
 

@@ -779,6 +779,7 @@ __global__ void __launch_bounds__(256, 2) focal_mom_rescue_kernel(const MomArgs 
 #ifndef XRS_RESCUE_NO_FIX
         w.fix_list = fixes[wv];
         w.fix_cap = RESCUE_FIX;
+        w.guard_t = 0.4f;
 #endif
         if (w.run()) {
             if (w.n_fix) {

@@ -113,6 +113,8 @@ struct MomWalkN {
     float *lds;                                            // Z[STG] then F[STG]
     unsigned short *fix_list = nullptr;                    // LDS: outputs that failed their guard, (row in the band) << 6 | lane; the
     int fix_cap = 0, n_fix = 0;                            // caller recomputes them one by one (mom_fix_cells); NULL: a failure hands on the half tile
+    float guard_t = 0.2f;                                  // a variance is accepted if n var >= guard_t * B (amplification <= 1 / guard_t).  With
+                                                           // a fix list a failure costs one window, not a tile: the rescue kernels ask for 0.4
     unsigned lds_z;                                        // LDS byte address of Z[lane]
     long xw, x, y0, y_end, y_first;
     int lane;
@@ -284,7 +286,7 @@ struct MomWalkN {
                 if (HAVE_Q) {
                     const float e = n == 1.0f ? 0.0f : Q - S * ms;      // (one valid cell: variance exactly 0, whatever the shift)
                     const float B = Q + n * dqm;
-                    bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
+                    bad = (n != 1.0f && !(e >= guard_t * B)) || !(mean * mean * n >= gmf * B);
                     var = e / n;
                     sd = sqrtf(var);
                 } else {

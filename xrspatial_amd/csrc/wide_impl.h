@@ -83,6 +83,8 @@ struct WideArgs {
     int rim_first;                // work order (circle_walk.h RimFirst)
     long n_groups;                // workgroups = groups of 4 horizontally adjacent wave tiles
     long groups_x;
+    unsigned *rescue;             // work-list of the wave tiles handed on to focal_wide_rescue_kernel: [0] count, [2..] tiles; or NULL
+    unsigned rescue_cap;
 };
 
 template <int R, typename Shape>
@@ -774,6 +776,18 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
         for (int q = 0; q < C::NC; ++q) walk_conv_columns<R, Shape>(g, a.out, a.wgt, a.weights, x_tile + 64 * q, lane, y0, y_end);
         return;
     }
+    // the slow tiles -- the rim of a nodata region, dense nodata -- are noted for focal_wide_rescue_kernel, which takes them apart
+    // into half tiles x row bands for every wave of the chip (mom_impl.h has the same arrangement and the reasons)
+    if (a.rescue) {
+        unsigned idx = 0;
+        if (lane == 0) idx = atomicAdd(a.rescue, 1u);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx < a.rescue_cap) {
+            if (lane == 0) a.rescue[2 + idx] = (unsigned)((ty * a.groups_x + gx) * 4 + wv);
+            return;
+        }
+    }
+    // (no list, or a full one: in place.)
     // NaN cells under a window (nodata, the raster's edge): the NaN-aware float32 walker of mom_nan_walk.h without its
     // squares -- validity and counts carried with the sums, the shift trails the walk, the rounding of S bounded at the end
     // of the tile like this kernel's own -- 64 columns at a time.  What fails that (+-inf, values straddling zero), and
@@ -796,6 +810,73 @@ __global__ void __launch_bounds__(256, XRS_WIDE_WAVES) focal_wide_kernel(const W
     }
 }
 
+// The tiles focal_wide_kernel noted: the NaN-aware float32 walker band by band, windows it flags (+-inf under them) recomputed
+// one by one in float64, a band whose rounding bound fails as a whole through the float64 column walker.
+template <int R, typename Shape, int MODE>
+__global__ void __launch_bounds__(256, 2) focal_wide_rescue_kernel(const WideArgs a) {
+    using C = WideCfg<R, Shape>;
+    constexpr bool SUM = MODE == WIDE_SUM;
+    __shared__ __attribute__((aligned(16))) float stage[4][2 * (64 + 2 * R)];
+    __shared__ unsigned short fixes[4][1024];
+    const unsigned count = a.rescue[0] < a.rescue_cap ? a.rescue[0] : a.rescue_cap;
+    if (!count) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const WalkGeom &g = a.g;
+    MomArgs ma;
+    ma.g = g;
+    ma.out_sum = SUM ? a.out : nullptr; ma.out_mean = SUM ? nullptr : a.out; ma.out_var = nullptr; ma.out_std = nullptr;
+    ma.todo = nullptr; ma.rescue = nullptr; ma.rescue_cap = 0;
+    const WalkOuts o = {SUM ? a.out : nullptr, nullptr, nullptr, nullptr, SUM ? nullptr : a.out, nullptr, nullptr};
+    const long waves = (long)gridDim.x * 4;
+    const long want_nb = waves / ((long)count * C::NC);
+    const int max_nb = (a.tile_rows + 15) / 16;
+    const int nb = want_nb < 1 ? 1 : want_nb > max_nb ? max_nb : (int)want_nb;
+    const int band_rows = (a.tile_rows + nb - 1) / nb;
+    const long items = (long)count * C::NC * nb;
+    for (long it = (long)blockIdx.x * 4 + wv; it < items; it += waves) {
+        const unsigned ent = a.rescue[2 + it / (C::NC * nb)];
+        const int sub = (int)(it % (C::NC * nb)), q = sub / nb, band = sub % nb;
+        const long grp = ent >> 2;
+        const long ty = grp / a.groups_x, gx = grp % a.groups_x;
+        const long xw = (gx * 4 + (long)(ent & 3u)) * C::TW + 64 * q;
+        if (xw >= g.cols) continue;
+        const long yt0 = ty * a.tile_rows;
+        const long yt1 = yt0 + a.tile_rows < g.rows ? yt0 + a.tile_rows : g.rows;
+        const long y0 = yt0 + (long)band * band_rows;
+        const long y_end = y0 + band_rows < yt1 ? y0 + band_rows : yt1;
+        if (y0 >= y_end) continue;
+        MomWalkN<R, Shape, SUM ? MOM_SUM : MOM_MEAN> w(ma, stage[wv], xw, y0, y_end, lane);
+        w.fix_list = fixes[wv];
+        w.fix_cap = 1024;
+        if (w.run()) {
+            if (w.n_fix) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                mom_fix_cells<R, Shape>(ma, fixes[wv], w.n_fix, xw, y0, lane);
+            }
+        } else if (!SUM) {
+            walk_columns<R, Shape, false, false, false, true, false>(g, o, xw, lane, y0, y_end);
+        } else {
+            walk_columns<R, Shape, true, true, false, false, false>(g, o, xw, lane, y0, y_end);
+        }
+    }
+}
+
+template <int R, typename Shape, int MODE>
+int launch_wide_rescue(WideArgs &a, long tiles_y, hipStream_t s) {
+    static thread_local int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    hipLaunchKernelGGL((focal_wide_rescue_kernel<R, Shape, MODE>), dim3((unsigned)(cus * 2)), dim3(256), 0, s, a);
+    XRS_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int R, typename Shape>
 int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     using C = WideCfg<R, Shape>;
@@ -811,16 +892,25 @@ int launch_wide(WideArgs &a, float *out_mean, float *out_sum, hipStream_t s) {
     a.rim_first = RimFirst::mode_from_env();
     const long grid = RimFirst(a.groups_x, tiles_y, a.rim_first).grid();
     if (grid > 0x7fffffffL) return fail("focal mean: raster too large for one launch");
+    a.rescue = mom_rescue_slot();
+    a.rescue_cap = (unsigned)(g.tiles_x * tiles_y);
+    if (a.rescue && mom_rescue_bytes(g.rows, g.cols) < 8 + 4 * (size_t)a.rescue_cap) a.rescue = nullptr;
     if (out_mean) {
         a.out = out_mean;
+        if (a.rescue) XRS_HIP(hipMemsetAsync(a.rescue, 0, 8, s));
         hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_MEAN>), dim3((unsigned)grid), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
+        if (a.rescue)
+            if (int rc = launch_wide_rescue<R, Shape, WIDE_MEAN>(a, tiles_y, s)) return rc;
     }
     if constexpr (!shape_has_hole<Shape>(R)) {                 // (annuli: the mean and the convolution only -- the entry refuses a sum)
         if (out_sum) {
             a.out = out_sum;
+            if (a.rescue) XRS_HIP(hipMemsetAsync(a.rescue, 0, 8, s));
             hipLaunchKernelGGL((focal_wide_kernel<R, Shape, WIDE_SUM>), dim3((unsigned)grid), dim3(256), 0, s, a);
             XRS_LAUNCH_CHECK();
+            if (a.rescue)
+                if (int rc = launch_wide_rescue<R, Shape, WIDE_SUM>(a, tiles_y, s)) return rc;
         }
     }
     return 0;

@@ -131,9 +131,10 @@ def _window_workspace(k, rows=0, cols=0):
     separable box walk (csrc/boxsep.hip; xrs_focal_workspace_bytes).  The block goes back to the pool behind the launch on
     the launch's stream (device.py fences recycled blocks with an event), so nobody has to wait for it."""
     big = max(k.shape) > 63
-    # 9x9 .. 25x25: the moments kernels (circles, boxes, annuli) note the tiles their fast walks hand on -- the rim of a
-    # nodata region, dense nodata -- in a work-list inside this block (csrc/mom_impl.h: focal_mom_rescue_kernel)
-    walked = k.shape[0] == k.shape[1] and 9 <= k.shape[0] <= 25 and k.shape[0] % 2 == 1
+    # 7x7 .. 25x25: the large-window kernels (circles, boxes, annuli; mean / sum and the moments) note the tiles their fast
+    # walks hand on -- the rim of a nodata region, dense nodata -- in a work-list inside this block (csrc/mom_impl.h:
+    # focal_mom_rescue_kernel, csrc/wide_impl.h: focal_wide_rescue_kernel)
+    walked = k.shape[0] == k.shape[1] and 7 <= k.shape[0] <= 25 and k.shape[0] % 2 == 1
     if os.environ.get("XRS_MOM_RESCUE") == "0":            # (A/B: no work-list, slow tiles are walked in place as before round 6)
         walked = bool((k == 1.0).all())
     if not (big or walked):

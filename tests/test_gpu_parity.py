@@ -20,11 +20,12 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
 # Large-window moments (9x9 .. 25x25) on tiles with nodata / at the raster edge: float32 sums about a shift that trails the walk,
-# a guard per window (amplification <= 2.5 in the rescue walker), windows that fail it recomputed in float64.  Until round 6 ONE
+# a guard per window (amplification <= 5, the interior tiles' own), windows that fail it recomputed in float64.  Until round 6 ONE
 # failing window sent its whole tile through the float64 walker, and on the small rasters of these tests (every tile an edge tile,
-# every raster with a NaN block) that made the results float64-exact by accident; a window now stands on its own guard.  Measured
-# <= 2.4e-6 on these rasters; DESIGN.md documents 5e-6 for this path, north_star asks for 1e-5.
-RIM_MOMENT_RTOL = 3e-6
+# every raster with a NaN block) that made the results float64-exact by accident; a window now stands on its own guard, like
+# every window of an interior tile always has.  Measured <= 4.3e-6 on these rasters; DESIGN.md documents 5e-6 for the float32
+# moments, north_star asks for 1e-5.
+RIM_MOMENT_RTOL = 5e-6
 
 
 
@@ -1508,7 +1509,9 @@ def test_raster_pass_fallbacks_and_shards():
         r2 = _separate(z, k)
         got = _raster_pass(z, ('hillshade', 'focal_mean'), k)
         np.testing.assert_array_equal(got['hillshade'], r2['hillshade'])
-        np.testing.assert_array_equal(got['focal_mean'], r2['focal_mean'])
+        # (the stand-alone call brings a workspace and its slow tiles go through the rescue launch band by band, the pass's
+        # fallback walks them in place: the float32 sums of a tile with nodata may end in another last bit)
+        np.testing.assert_allclose(got['focal_mean'], r2['focal_mean'], rtol=3e-7, atol=0, equal_nan=True)
     # width not a multiple of 4
     zu = synth.smooth_dem((33, 301), nan_frac=0.01)
     r3 = _separate(zu, k5)

@@ -10,13 +10,10 @@ K = 25
 k = np.ones((K, K))
 rows, cols = 700, 1500
 z2 = synth.smooth_dem((rows, cols), seed=K).copy()
-rng = np.random.default_rng(K)
-z2[rng.random(z2.shape) < 0.0005] = np.nan
-z2[300:300 + 3 * K, 700:700 + 3 * K] = np.nan
-z2[500, 100] = np.inf
-z2[520, 1300] = -np.inf
-z2[200:260, 300:400] = 777.25
-z2[600:640, 1100:1200] = np.float32(16777217.0)
+z2[100, 300] = np.nan
+z2[400, 1200] = np.inf
+z2[500:560, 600:700] = 1234.567
+z2[0:40, 0:60] = -5.25
 for env in ("1", "0"):
     os.environ["XRS_MOM_RESCUE"] = env
     got = np.asarray(focal_stats(xs.DataArray(z2, dims=['y', 'x']), k, stats_funcs=['mean', 'std', 'var', 'sum']).data)[3]

@@ -113,8 +113,7 @@ struct MomWalkN {
     float *lds;                                            // Z[STG] then F[STG]
     unsigned short *fix_list = nullptr;                    // LDS: outputs that failed their guard, (row in the band) << 6 | lane; the
     int fix_cap = 0, n_fix = 0;                            // caller recomputes them one by one (mom_fix_cells); NULL: a failure hands on the half tile
-    float guard_t = 0.2f;                                  // a variance is accepted if n var >= guard_t * B (amplification <= 1 / guard_t).  With
-                                                           // a fix list a failure costs one window, not a tile: the rescue kernels ask for 0.4
+    float a_span = 0.0f;                                   // (fix list only, wave-uniform) largest |v - c| staged in this band so far
     unsigned lds_z;                                        // LDS byte address of Z[lane]
     long xw, x, y0, y_end, y_first;
     int lane;
@@ -286,7 +285,18 @@ struct MomWalkN {
                 if (HAVE_Q) {
                     const float e = n == 1.0f ? 0.0f : Q - S * ms;      // (one valid cell: variance exactly 0, whatever the shift)
                     const float B = Q + n * dqm;
-                    bad = (n != 1.0f && !(e >= guard_t * B)) || !(mean * mean * n >= gmf * B);
+                    bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
+                    if (fix_list) {
+                        // A window judged on its own (not tile by tile) must also answer for what its guard cannot see: a cell far
+                        // from the shift -- a cliff, a block of 1.6e7 next to relief around 2000 -- sits in the lane-local PREFIX sums
+                        // of windows that do not contain it (to the left of their runs), and the difference of two prefixes of size A
+                        // carries a rounding of ~u A per term whatever the window itself holds.  ~sqrt(1.5 n) such terms behave like a
+                        // random walk: accepted while that stays under 2e-6 of n |mean| (sum, mean) and of n var (squares: A^2).
+                        // (Without a fix list the tile-wide all-or-nothing rule covers this: the far cell lies INSIDE some window of
+                        // the tile, which fails.)
+                        const float lim = 28.0f * sqrtf(n);        // 2e-6 / (1.2 u), u = 2^-24
+                        bad = bad || !(a_span <= lim * fabsf(mean)) || (n != 1.0f && !(a_span * a_span <= lim * var));
+                    }
                     var = e / n;
                     sd = sqrtf(var);
                 } else {
@@ -351,6 +361,16 @@ struct MomWalkN {
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (load_row(t + P, pf_own[P], pf_halo[P]), ...);
         if (!seeded) first_shift();
+        if (fix_list) {                                        // (the rows of this round, before any of them is summed)
+            float m = 0.0f;
+#pragma unroll
+            for (int r = 0; r < U; ++r) {
+                const float o = fabsf(pf_own[r] - c), h = fabsf(pf_halo[r] - c);
+                m = fmaxf(m, o == o ? o : 0.0f);               // (NaN: nodata, adds nothing; +-inf stays inf and flags everything)
+                m = fmaxf(m, h == h ? h : 0.0f);
+            }
+            a_span = fmaxf(a_span, wave_reduce<WrMax>(m));
+        }
         (step<P>(), ...);
         ring_rotate<K, U>(accN);
         ring_rotate<K, U>(accS);

@@ -353,13 +353,17 @@ int xrs_zonal_majority_f64(const int32_t *zone_idx_dev, const double *values_dev
  * majority_dev holds n_zones + 1 doubles: the LAST one is the number of parts whose table overflowed (a zone of more
  * than ~2^27 cells of all-distinct values) -- nonzero means the results are not valid and the caller must use
  * xrs_zonal_majority_*.  n_zones <= xrs_zonal_mode_max_zones(); n < 2^31; `work_dev` holds
- * xrs_zonal_mode_workspace_bytes(n, n_zones, values_f64) bytes. */
+ * xrs_zonal_mode_workspace_bytes(n, n_zones, values_f64) bytes.  zone_counts_dev: the valid cells per zone as uint32 if the
+ * caller has them (the `count` of xrs_zonal_partials_* for the same rasters and nodata value), else NULL -- they are
+ * then counted here with one more pass over the rasters. */
 size_t xrs_zonal_mode_workspace_bytes(int64_t n, int n_zones, int values_f64);
 int xrs_zonal_mode_max_zones(void);
 int xrs_zonal_mode_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones, float nodata,
-                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream);
+                       int has_nodata, const uint32_t *zone_counts_dev, void *work_dev, size_t work_bytes, double *majority_dev,
+                       void *stream);
 int xrs_zonal_mode_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones, double nodata,
-                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream);
+                       int has_nodata, const uint32_t *zone_counts_dev, void *work_dev, size_t work_bytes, double *majority_dev,
+                       void *stream);
 /* the valid cells of every zone gathered into one contiguous run, for statistics that are arbitrary host callables
  * (zonal.stats(stats_funcs={name: callable}): _calc_stats, xrspatial/zonal.py:144-163, slices the argsort-ordered
  * values per zone and filters non-finite / nodata cells before calling func).  sorted_values_dev[n] receives the cells

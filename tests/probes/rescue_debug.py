@@ -1,6 +1,6 @@
 """Where do the moments differ from the oracle on the 'nodata' case of test_third_generation_walkers (ragged region + scattered NaN)?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import xrspatial_amd as xs
 from oracle import c_oracle as corc

@@ -1,6 +1,6 @@
 """Where does the window sum of the 'holes' raster of test_separable_box_walk[25] leave its tolerance?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import xrspatial_amd as xs
 from oracle import c_oracle as corc

@@ -70,7 +70,26 @@ def check_window_sum(got, z, k, err_msg=""):
         # reference's own rounding bound is 2.6e-5 of the sum and would let a 2e-5 regression through; only windows that
         # cancel keep that bound
         tol = np.where(ref >= 0.1 * sum_abs[fin], 1e-5 * ref, np.maximum(1e-5 * ref, 1.01 * bound[fin] + 1e-30))
-        worst = (d - tol).max() if d.size else -1.0
+        over = np.zeros(got.shape)
+        over[fin] = d - tol
+        worst = over.max() if d.size else -1.0
+        if 0 < worst and np.count_nonzero(over > 0) <= 500:
+            # A few windows beyond 1e-5 of the reference: whose rounding is it?  Adding 625 times 1234.567 to a partial sum near
+            # 1e6 rounds the same way every time, and the reference's sequential float32 sum drifts by 1e-5 of the total (measured:
+            # 14 in 1 338 078, tests/probes/sum_debug.py) -- inside ITS bound, outside the 1e-5 asked of this kernel.  Such a window
+            # passes if the kernel's value is the exactly rounded window sum (float64 tap by tap here) and the reference lies
+            # within its own rounding bound of that.
+            kk = np.asarray(k) == 1
+            ry, rx = kk.shape[0] // 2, kk.shape[1] // 2
+            zp = np.pad(z.astype(np.float64), ((ry, ry), (rx, rx)), constant_values=np.nan)
+            worst = -1.0
+            for y, x in zip(*np.nonzero(over > 0)):
+                win = zp[y:y + kk.shape[0], x:x + kk.shape[1]][kk]
+                exact = win[~np.isnan(win)].sum()
+                ours_ok = abs(float(got[y, x]) - exact) <= 0.51 * np.spacing(np.float32(abs(exact)))
+                ref_ok = abs(float(want[y, x]) - exact) <= 1.01 * bound[y, x]
+                if not (ours_ok and ref_ok):
+                    worst = max(worst, over[y, x])
     assert worst <= 0, f"{err_msg}: window sum off by {worst} beyond tolerance"
 
 
@@ -742,8 +761,10 @@ def test_separable_box_walk(K):
             for i, arr in got.items():
                 want = corc.focal_apply(zz, k, names[i], nthreads=8)[lo:hi]
                 if names[i] == 'sum':
-                    check_window_sum(arr, zz, k, f"{what} sum") if lo == 0 and hi == zz.shape[0] else None
-                    np.testing.assert_allclose(arr, want, rtol=1e-5, equal_nan=True, err_msg=f"{what} sum")
+                    if lo == 0 and hi == zz.shape[0]:
+                        check_window_sum(arr, zz, k, f"{what} sum")          # (1e-5, or exactly rounded where the reference is not)
+                    else:
+                        np.testing.assert_allclose(arr, want, rtol=1e-5, equal_nan=True, err_msg=f"{what} sum")
                 else:
                     np.testing.assert_allclose(arr, want, rtol=tol, atol=0, equal_nan=True, err_msg=f"{what} {names[i]}")
 

@@ -31,7 +31,7 @@ nbytes2 = int(_lib.load().xrs_zonal_mode_workspace_bytes(n * n, nz, 0))
 work2 = xs.DeviceArray((nbytes2,), np.uint8)
 out2 = xs.DeviceArray((nz + 1,), np.float64)
 for name, vals in (("continuous", dem), ("categorical32", cat)):
-    med, mn = t.time(lambda: L("xrs_zonal_mode_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work2.ptr, nbytes2, out2.ptr, None), 5, warmup=1)
+    med, mn = t.time(lambda: L("xrs_zonal_mode_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, None, work2.ptr, nbytes2, out2.ptr, None), 5, warmup=1)
     L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None)
     a, b = out2.get(), out.get()
     same = np.array_equal(a[:nz], b, equal_nan=True)

@@ -129,8 +129,8 @@ _PROTOTYPES = {
                                c_void_p],
     "xrs_zonal_mode_workspace_bytes": [c_int64, c_int, c_int],
     "xrs_zonal_mode_max_zones": [],
-    "xrs_zonal_mode_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
-    "xrs_zonal_mode_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
+    "xrs_zonal_mode_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
+    "xrs_zonal_mode_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
     "xrs_focal_windows_f32": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_void_p],
     "xrs_zonal_group_f32": [c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p, c_void_p],
     "xrs_zonal_group_f64": [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p, c_size_t, c_void_p, c_void_p],

@@ -110,8 +110,9 @@ struct MomWalk {
     float fill;                    // (wave-uniform) the value a nodata cell is replaced with in the ring
     unsigned inflight;             // (wave-uniform) bit b: input row t - b held NaN cells
     int lost_slot;                 // (wave-uniform) t mod K of the current step
+    int span_total;                // (wave-uniform) NaN cells the rows of this tile have shown their worst lane, summed
     unsigned *nanmap;              // LDS: NMW words, the NaN bitmap of the row being marked: bit s = staged cell s is NaN
-    unsigned *lostring;            // LDS: [K][64] -- slot (step mod K), lane; 16 bits per owned column (a window holds <= 625 cells)
+    unsigned short *lostring;      // LDS: [K][64] -- slot (step mod K), lane
 
     __device__ __forceinline__ MomWalk(const MomArgs &a_, float *lds_, long xt, long y0_, long ye, int lane_)
         : a(a_), g(a_.g), lds(lds_), x_tile(xt), y0(y0_), lane(lane_) { y_end = ye; }
@@ -199,6 +200,7 @@ struct MomWalk {
             if (!isfinite(c0)) c = fill;
             inflight = 0u;
             lost_slot = K - 1;
+            span_total = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) lostring[j * 64 + lane] = 0;
         }
@@ -268,9 +270,11 @@ struct MomWalk {
         const unsigned span = (unsigned)(two >> (s0 & 31));    // bit k: the lane's cell w[k] of this row is NaN
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                       // (the next marked row clears the bitmap)
-        // every distinct half-width once (both owned columns packed: 16 bits each -- bytes until round 6, which capped a tile at
-        // 255 lost cells per lane and sent rasters with more than ~1 % nodata to the one-column walker), then one LDS add per
-        // output row in flight into the lane's own word of the ring
+        // lost counts are bytes: once the rows of this tile have shown a lane more than 255 NaN cells in all (the sum of the
+        // rows' worst lanes: a scalar) the tile is handed on (dense nodata); below that no byte of the ring can overflow
+        span_total += wave_reduce<WrMax>(__popc(span & ((1u << NV) - 1u)));
+        // every distinct half-width once (both owned columns packed: byte o), then one LDS add per output row in flight; the
+        // ring holds one 16-bit entry per lane, two lanes to a word: an atomic add of the entry shifted to the lane's half
         constexpr ShapeRows<R, Shape> T{};
         unsigned lvl[R + 1];
 #pragma unroll
@@ -278,28 +282,28 @@ struct MomWalk {
             lvl[h] = 0u;
             if (!C::level_used(h)) continue;
 #pragma unroll
-            for (int o = 0; o < NC; ++o) lvl[h] |= (unsigned)__popc((span >> (HL + o - h)) & ((2u << (2 * h)) - 1u)) << (16 * o);
+            for (int o = 0; o < NC; ++o) lvl[h] |= (unsigned)__popc((span >> (HL + o - h)) & ((2u << (2 * h)) - 1u)) << (8 * o);
+            lvl[h] <<= 16 * (ln & 1);
         }
-        unsigned *ring32 = lostring + ln;
+        unsigned *ring32 = reinterpret_cast<unsigned *>(lostring) + (ln >> 1);
 #pragma unroll
         for (int j = 0; j < K; ++j) {                          // the output row completed j steps from now sees this row at offset R - j
             // (no test for the run-in here -- 25 scalar branches in this block: a step that completes no output row clears
             // its slot instead, step())
             const int slot = lost_slot + j < K ? lost_slot + j : lost_slot + j - K;
-            // (the lane's own word; the atomic form because it is ONE LDS instruction, not for exclusion)
-            __hip_atomic_fetch_add(ring32 + slot * 64, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ring32 + slot * 32, lvl[T.hw[j < R ? R - j : j - R]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return false;
+        return span_total > 255;
     }
 
     // (CARRY) NaN cells under the windows of the output row this step completes: the lane's entry of the lost ring, cleared
     // for the step that will use the slot next
     __device__ __forceinline__ unsigned lost_cells() {
-        unsigned *p = lostring + lost_slot * 64 + lane_here();
+        unsigned short *p = lostring + lost_slot * 64 + lane_here();
         const unsigned v = *p;
         unsigned zero;                                         // (a fresh zero: a constant one would live in a register across the loop)
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-        *p = zero;
+        *p = (unsigned short)zero;
         return v;
     }
 
@@ -427,7 +431,7 @@ struct MomWalk {
                     for (int e = 0; e < NC; ++e) inf |= isinf(a0[e]) || isinf(a1[e]);          // +-inf: the tile is handed on
                     inflight |= 1u;
                     // (dense nodata: the NaN-aware walker is the faster one)
-                    const bool stop = mark_row(rowp) || __any(inf);
+                    const bool stop = mark_row(rowp) || __popc(inflight) > 18 || __any(inf);
                     badm |= (unsigned long long)__builtin_amdgcn_readfirstlane(stop ? 1 : 0);   // (a scalar: the verdicts stay in SGPRs)
                 }
             }
@@ -501,7 +505,7 @@ struct MomWalk {
                 const float dl = fill - c, dl2 = dl * dl;
 #pragma unroll
                 for (int o = 0; o < NC; ++o) {
-                    const unsigned lost = (lost_pk >> (16 * o)) & 0xffffu;
+                    const unsigned lost = (lost_pk >> (8 * o)) & 255u;
                     const float L = (float)lost;
                     const float n = (float)C::NTAPS - L;
                     // (v_rcp_f32, 1 ulp, for every window -- choosing the plain walk's constant for windows that lost nothing costs
@@ -644,7 +648,7 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
     __shared__ __attribute__((aligned(16))) float lds_rows[4][(C::D + 1) * C::RBF];
     constexpr bool CARRIES = XRS_MOM_CARRY && OM != 0 && MomWalk<R, Shape, OM, false, true>::NANOK;
     __shared__ unsigned nan_row[4][8];                         // per wave: the NaN bitmap of the row being marked
-    __shared__ unsigned lost_ring[4][CARRIES ? C::K * 64 : 1];         // per wave: NaN cells under the windows in flight
+    __shared__ unsigned short lost_ring[4][CARRIES ? C::K * 64 : 1];   // per wave: NaN cells under the windows in flight
     long ty, gx;
     if (!RimFirst(a.groups_x, a.n_groups / a.groups_x, a.rim_first).locate(blockIdx.x, ty, gx)) return;
     if (std::is_same<Shape, BoxShape>::value && a.todo && !a.todo[ty * a.groups_x + gx]) return;   // (boxsep.hip did this tile)

@@ -113,7 +113,9 @@ struct MomWalkN {
     float *lds;                                            // Z[STG] then F[STG]
     unsigned short *fix_list = nullptr;                    // LDS: outputs that failed their guard, (row in the band) << 6 | lane; the
     int fix_cap = 0, n_fix = 0;                            // caller recomputes them one by one (mom_fix_cells); NULL: a failure hands on the half tile
-    float a_span = 0.0f;                                   // (fix list only, wave-uniform) largest |v - c| staged in this band so far
+    static constexpr int NH = (K + U - 1) / U + 1;         // rounds whose rows can still lie under a window being completed
+    float a_hist[NH];                                      // (fix list only, wave-uniform) largest |v - c| staged in each of them
+    float a_span = 0.0f;                                   // ... and their maximum
     unsigned lds_z;                                        // LDS byte address of Z[lane]
     long xw, x, y0, y_end, y_first;
     int lane;
@@ -146,6 +148,9 @@ struct MomWalkN {
         lds_z = lds_addr(lds) + 4u * (unsigned)lane;
         c = 0.0f;
         seeded = false;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) a_hist[q] = 0.0f;
+        a_span = 0.0f;
     }
 
     // first shift, from the rows of the FIRST ROUND THAT HOLDS A VALID CELL: the mean of the lane's valid cells (staged cell
@@ -162,7 +167,7 @@ struct MomWalkN {
         // -- the last columns left of a region's rim -- was never "seeded" by its own cells, and this function then put c back
         // to 0 at the head of EVERY round, under sums accumulated about the shift the re-centring had moved to: garbage that
         // no guard sees.  Masked until round 6 because such a tile always held a window that failed and went to the exact
-        // walker as a whole; tools/rescue_debug.py found it the day single windows began to be repaired.)
+        // walker as a whole; tests/probes/rescue_debug.py found it the day single windows began to be repaired.)
         float s = 0.0f, n = 0.0f, sh = 0.0f, nh = 0.0f;
 #pragma unroll
         for (int r = 0; r < U; ++r) {
@@ -366,10 +371,17 @@ struct MomWalkN {
 #pragma unroll
             for (int r = 0; r < U; ++r) {
                 const float o = fabsf(pf_own[r] - c), h = fabsf(pf_halo[r] - c);
-                m = fmaxf(m, o == o ? o : 0.0f);               // (NaN: nodata, adds nothing; +-inf stays inf and flags everything)
+                m = fmaxf(m, o == o ? o : 0.0f);               // (NaN: nodata, adds nothing; +-inf stays inf and flags what it touches)
                 m = fmaxf(m, h == h ? h : 0.0f);
             }
-            a_span = fmaxf(a_span, wave_reduce<WrMax>(m));
+            // a sliding maximum over the rounds a window in flight can reach back to: the terms were about the shift of THEIR
+            // round (the re-centring moves sums by exact algebra, not the size of what was rounded)
+            a_span = wave_reduce<WrMax>(m);
+#pragma unroll
+            for (int q = NH - 1; q > 0; --q) a_hist[q] = a_hist[q - 1];
+            a_hist[0] = a_span;
+#pragma unroll
+            for (int q = 1; q < NH; ++q) a_span = fmaxf(a_span, a_hist[q]);
         }
         (step<P>(), ...);
         ring_rotate<K, U>(accN);

@@ -39,7 +39,9 @@ constexpr int PART_TARGET = 1024;                 // a zone is cut into 2^B part
 constexpr int MAX_B = 16;                         // most parts per zone
 constexpr int LDS_B = 11;                         // zones of up to 2^LDS_B parts: per-chunk LDS histogram (8 KiB); above: one
                                                   // global atomic per key (a 4096-key chunk meets a part less than twice)
-constexpr int SLOTS = 4096;                       // hash table of the counting pass (load <= 0.25 + tail for a part)
+constexpr int SLOTS = 2048;                       // hash table of the counting pass: load <= 0.5 + tail for a part.  (4096 slots: 32 KiB,
+                                                  // four workgroups per CU -- the pass is bound by the LATENCY of its LDS atomics, and
+                                                  // eight tables in flight per CU count twice as fast as four half-empty ones)
 constexpr int MAX_ZONES = 16384;                  // LDS histogram of the zones of a tile
 
 template <typename VT> struct Key;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(TILE_THREADS) zone_count_kernel(const int32_t 
 
 // 2. the plan.  One workgroup of 1024 threads; three exclusive scans over the zones.
 __device__ __forceinline__ int parts_log2(unsigned count) {
-    if (count <= (unsigned)(PART_TARGET + PART_TARGET / 2)) return 0;
+    if (count <= (unsigned)(PART_TARGET + PART_TARGET / 4)) return 0;
     int B = 1;
     while (B < MAX_B && ((unsigned long long)PART_TARGET << B) < count) ++B;
     return B;
@@ -563,8 +565,8 @@ struct Plan {
 };
 
 template <typename VT>
-int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata, void *work, size_t work_bytes,
-              double *majority, hipStream_t s) {
+int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, int has_nodata, const uint32_t *counts_dev,
+              void *work, size_t work_bytes, double *majority, hipStream_t s) {
     using K = typename Key<VT>::K;
     if (n < 0 || nz < 0) return fail("xrs_zonal_mode: negative size");
     if (nz > MAX_ZONES) return fail("xrs_zonal_mode: at most %d zones (the sorting path has no limit)", MAX_ZONES);
@@ -591,7 +593,10 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
     XRS_HIP(hipMemsetAsync(w, 0, pl.zero_bytes, s));
     const size_t zone_lds = (size_t)nz * 4;
     const long n_tiles = (n + TILE - 1) / TILE;
-    if (n_tiles) {
+    if (counts_dev) {
+        // the caller has them (the partial-sums reduction counts the same cells): one pass over the rasters saved
+        XRS_HIP(hipMemcpyAsync(zone_count, counts_dev, (size_t)nz * 4, hipMemcpyDeviceToDevice, s));
+    } else if (n_tiles) {
         const unsigned g1 = (unsigned)(n_tiles < 4096 ? n_tiles : 4096);
         hipLaunchKernelGGL((zone_count_kernel<VT>), dim3(g1), dim3(TILE_THREADS), zone_lds, s, zidx, vals, n, nz, nodata, has_nodata,
                            zone_count);
@@ -637,7 +642,9 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
         }
         // (an ODD number of workgroups: the heavy parts of a categorical raster sit at the same offsets d in every zone's
         //  2^B parts, and a stride that divides 2^B hands all of them to the same few workgroups: 55 ms instead of 5)
-        const long slots = ((long)cus * (160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64)) - 1) | 1;
+        long per_cu = 160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64);
+        if (per_cu > 8) per_cu = 8;                 // (2048 threads per CU)
+        const long slots = ((long)cus * per_cu - 1) | 1;
         hipLaunchKernelGGL((count_kernel<K>), dim3((unsigned)(slots < pl.max_parts ? slots : pl.max_parts)), dim3(256), 0, s, keys, parted,
                            part_off, part_count, hdr, best_count, best_key);
     }
@@ -659,15 +666,17 @@ size_t xrs_zonal_mode_workspace_bytes(int64_t n, int n_zones, int values_f64) {
 int xrs_zonal_mode_max_zones(void) { return MAX_ZONES; }
 
 int xrs_zonal_mode_f32(const int32_t *zone_idx_dev, const float *values_dev, int64_t n, int n_zones, float nodata,
-                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream) {
-    return mode_impl<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, work_dev, work_bytes, majority_dev,
-                            as_stream(stream));
+                       int has_nodata, const uint32_t *zone_counts_dev, void *work_dev, size_t work_bytes, double *majority_dev,
+                       void *stream) {
+    return mode_impl<float>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, zone_counts_dev, work_dev, work_bytes,
+                            majority_dev, as_stream(stream));
 }
 
 int xrs_zonal_mode_f64(const int32_t *zone_idx_dev, const double *values_dev, int64_t n, int n_zones, double nodata,
-                       int has_nodata, void *work_dev, size_t work_bytes, double *majority_dev, void *stream) {
-    return mode_impl<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, work_dev, work_bytes, majority_dev,
-                             as_stream(stream));
+                       int has_nodata, const uint32_t *zone_counts_dev, void *work_dev, size_t work_bytes, double *majority_dev,
+                       void *stream) {
+    return mode_impl<double>(zone_idx_dev, values_dev, n, n_zones, nodata, has_nodata, zone_counts_dev, work_dev, work_bytes,
+                             majority_dev, as_stream(stream));
 }
 
 }  // extern "C"

@@ -311,8 +311,9 @@ def _majority_by_counting(zdev, vdev, n_zones, nodata_values, stream):
     return out
 
 
-def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
-    """Per-zone most frequent valid value (ties -> smallest), float64, NaN for empty zones."""
+def zonal_majority(zone_idx, values, n_zones, nodata_values=None, counts=None):
+    """Per-zone most frequent valid value (ties -> smallest), float64, NaN for empty zones.  `counts`: the valid cells per
+    zone if the caller has them (the `count` of zonal_partials for the same rasters), which saves the counting pass."""
     _lib.require_device()
     stream = get_stream()
     zdev, vdev = _stage(zone_idx, values)
@@ -330,8 +331,11 @@ def zonal_majority(zone_idx, values, n_zones, nodata_values=None):
         out = DeviceArray((n_zones + 1,), np.float64)
         nbytes = int(_lib.load().xrs_zonal_mode_workspace_bytes(vdev.size, n_zones, int(f64)))
         work = DeviceArray((nbytes,), np.uint8)
+        cdev = None
+        if counts is not None and len(counts) == n_zones and int(np.max(counts, initial=0)) < (1 << 32):
+            cdev = DeviceArray.from_numpy(np.ascontiguousarray(counts, dtype=np.uint32))
         _lib.call("xrs_zonal_mode_f64" if f64 else "xrs_zonal_mode_f32", zdev.ptr, vdev.ptr, vdev.size, n_zones, nodata,
-                  int(has_nodata), work.ptr, nbytes, out.ptr, stream)
+                  int(has_nodata), cdev.ptr if cdev is not None else None, work.ptr, nbytes, out.ptr, stream)
         res = out.get(stream)
         del work
         if res[n_zones] == 0:
@@ -473,7 +477,9 @@ def _stats_hip(zones_data, values_data, zone_ids, stat_names, nodata_values, ret
     nz = len(unique_zones)
     _, vdev = _stage(idx_dev, values_data)
     count, s1, s2, mn, mx, shift = zonal_partials(idx_dev, vdev, nz, nodata_values, comm)
-    majority = zonal_majority(idx_dev, vdev, nz, nodata_values) if 'majority' in builtin else None
+    # (the counts of THIS device's cells: with a communicator they have been added over the ranks and are not passed on)
+    majority = (zonal_majority(idx_dev, vdev, nz, nodata_values, counts=count if comm is None else None)
+                if 'majority' in builtin else None)
     cols = finalize_stats(builtin, count, s1, s2, mn, mx, majority, shift)
     keep = [i for i, z in enumerate(unique_zones) if z in selected]
     if custom:

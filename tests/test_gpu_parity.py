@@ -1039,6 +1039,24 @@ def test_focal_mean3x3(shape):
     np.testing.assert_allclose(xs.focal.mean(raster(z64)).data, orc.focal_mean3x3(z64), rtol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_focal_mean3x3_nodata_value_among_the_excludes(dtype):
+    """focal.mean(excludes=[nan, -9999]) on a raster wide enough for the strip kernel (its EXCL instantiation: a centre cell
+    that equals an exclude value passes through, neighbours that do are summed like any value -- focal.py:44-67), interior strips
+    with and without NaN rows, edge strips, several passes."""
+    z = synth.smooth_dem((96, 1280), nan_frac=0.003).astype(dtype)
+    rng = np.random.default_rng(6)
+    z[rng.random(z.shape) < 0.01] = -9999.0
+    z[40:44, 300:700] = -9999.0
+    z[0, :5] = -9999.0
+    for ex in ([np.nan, -9999.0], [-9999.0], [np.nan, -9999.0, float(z[50, 50])]):
+        for passes in (1, 2):
+            got = xs.focal.mean(raster(z), passes=passes, excludes=ex).data
+            want = orc.focal_mean3x3(z, excludes=ex, passes=passes)
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, equal_nan=True, err_msg=f"{ex} passes={passes}")
+            assert (got[40:44, 300:700] == -9999.0).all()
+
+
 @pytest.mark.parametrize("scatter", [False, True])
 @pytest.mark.parametrize("vdtype", [np.float32, np.float64, np.int32])
 def test_zonal_vs_oracle(scatter, vdtype):

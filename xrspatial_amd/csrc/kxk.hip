@@ -631,7 +631,7 @@ struct Mean3Args {
     long rows, cols, ld_in, ld_out;
     int halo_top, halo_bot;
     int n_excl;
-    int only_nan_excl;            // every exclude value is NaN (or there is none): the strip path's condition
+    int only_nan_excl;            // every exclude value is NaN (or there is none): no per-cell exclude test in the strip path
     int excl_nan;                 // some exclude value is NaN: NaN cells pass through
     double excl[8];
 };
@@ -709,7 +709,9 @@ __device__ __forceinline__ double div9_exact(double s) {
 #ifndef XRS_LB_MEAN3
 #define XRS_LB_MEAN3 3
 #endif
-template <typename InT>
+// EXCL: some exclude value is not NaN (a nodata VALUE: excludes=[nan, -9999]) -- a centre cell that equals one passes
+// through.  Its own instantiation: the test per cell costs the default one (NaN only) 46 spilled registers.
+template <typename InT, bool EXCL>
 __global__ void __launch_bounds__(256, XRS_LB_MEAN3) focal_mean3_strip_kernel(const Mean3Args a, const long tiles_x, const long n_tiles) {
     constexpr int RB = 4;
     const long t = xcd_tile(blockIdx.x, n_tiles, tiles_x);
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(256, XRS_LB_MEAN3) focal_mean3_strip_kernel(co
     const unsigned loff = (unsigned)lane * 4u;
     const long x0 = x_tile + loff;
     const bool interior = x_tile >= 4 && x_tile + TW + 4 <= a.cols && y0 - 1 >= y_lo && y0 + RB + 1 <= y_hi &&
-                          y0 + RB <= a.rows && a.only_nan_excl;
+                          y0 + RB <= a.rows && (EXCL || a.only_nan_excl);
     if (interior) {
         double d[RB + 2][6];
 #pragma unroll
@@ -764,6 +766,9 @@ __global__ void __launch_bounds__(256, XRS_LB_MEAN3) focal_mean3_strip_kernel(co
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) s += d[r + ky][o + kx];
                     res[o] = ninth(s);
+                    // (a nodata VALUE among the excludes -- excludes=[nan, -9999] --: such a centre cell passes through; until
+                    // round 6 any non-NaN exclude sent the whole raster down the cell-by-cell body)
+                    if (EXCL && is_excluded(a, d[r + 1][o + 1])) res[o] = d[r + 1][o + 1];
                 }
                 store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[0], res[1], res[2], res[3]);
             }
@@ -814,7 +819,9 @@ __global__ void __launch_bounds__(256, XRS_LB_MEAN3) focal_mean3_strip_kernel(co
                     if (__builtin_expect(!(as < 0x1p900 && (sizeof(InT) == 4 || as > 0x1p-900 || as == 0.0)) && lost < 9, 0)) q = s / n;
                     const bool c_nan = (hit & 2u) && (nanbits[(r + 1) >> 2] >> (8 * ((r + 1) & 3) + o + 1) & 1u);
                     res[o] = (c_nan && a.excl_nan) ? nan("") : q;
+                    if (EXCL && !c_nan && is_excluded(a, d[r + 1][o + 1])) res[o] = d[r + 1][o + 1];
                 }
+                if (EXCL && hit == 0u && is_excluded(a, d[r + 1][o + 1])) res[o] = d[r + 1][o + 1];
             }
             store_wave_row_d4(a.out + (y0 + r) * a.ld_out + x_tile, lane, res[0], res[1], res[2], res[3]);
         }
@@ -1344,9 +1351,11 @@ int xrs_focal_mean3x3(const void *in_dev, int in_is_f64, double *out_dev, int64_
         const long tiles_x = (cols + TW - 1) / TW, n_tiles = tiles_x * ((rows + 15) / 16);
         const unsigned g = (unsigned)xcd_grid(n_tiles, tiles_x);
         if (in_is_f64)
-            hipLaunchKernelGGL(focal_mean3_strip_kernel<double>, dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+            if (a.only_nan_excl) hipLaunchKernelGGL((focal_mean3_strip_kernel<double, false>), dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+            else hipLaunchKernelGGL((focal_mean3_strip_kernel<double, true>), dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
         else
-            hipLaunchKernelGGL(focal_mean3_strip_kernel<float>, dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+            if (a.only_nan_excl) hipLaunchKernelGGL((focal_mean3_strip_kernel<float, false>), dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
+            else hipLaunchKernelGGL((focal_mean3_strip_kernel<float, true>), dim3(g), dim3(256), 0, as_stream(stream), a, tiles_x, n_tiles);
         XRS_LAUNCH_CHECK();
         return 0;
     }

@@ -291,6 +291,8 @@ struct MomWalkN {
                     const float e = n == 1.0f ? 0.0f : Q - S * ms;      // (one valid cell: variance exactly 0, whatever the shift)
                     const float B = Q + n * dqm;
                     bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
+                    var = e / n;
+                    sd = sqrtf(var);
                     if (fix_list) {
                         // A window judged on its own (not tile by tile) must also answer for what its guard cannot see: a cell far
                         // from the shift -- a cliff, a block of 1.6e7 next to relief around 2000 -- sits in the lane-local PREFIX sums
@@ -302,8 +304,6 @@ struct MomWalkN {
                         const float lim = 28.0f * sqrtf(n);        // 2e-6 / (1.2 u), u = 2^-24
                         bad = bad || !(a_span <= lim * fabsf(mean)) || (n != 1.0f && !(a_span * a_span <= lim * var));
                     }
-                    var = e / n;
-                    sd = sqrtf(var);
                 } else {
                     m_min = fminf(m_min, fabsf(mean));
                     bad = !(fabsf(mean) <= 3.0e38f);                    // +-inf under the window: the exact walker's business

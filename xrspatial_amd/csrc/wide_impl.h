@@ -637,6 +637,9 @@ struct WideWalk {
                 stNC rq;
 #pragma unroll
                 for (int o = 0; o < NC; ++o) rq[o] = res[o];
+#ifdef XRS_FLOOR_NO_STORES                                     // (tools/floor_probe.sh: the walk without its output stream)
+                if (g.rows < 0)
+#endif
                 if constexpr (NC == 2) st_row_nt(out_row, 8u * (unsigned)lane, rq);
                 else __builtin_nontemporal_store(rq, reinterpret_cast<stNC *>(out_row + NC * lane));
                 out_row += g.ld_out;

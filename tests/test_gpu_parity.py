@@ -615,7 +615,7 @@ def test_large_window_statistic_subsets():
                 parity_log.record(f'{shape[0]}x{shape[1]}', f'focal_stats {kind}{K} subset {st}', got[i], want[st])
         for st, fn in (('max', xfocal._calc_max), ('min', xfocal._calc_min), ('range', xfocal._calc_range), ('std', xfocal._calc_std),
                        ('var', xfocal._calc_var)):
-            np.testing.assert_allclose(apply(raster(z), k, func=fn).data, want[st], rtol=2e-6, atol=0, equal_nan=True,
+            np.testing.assert_allclose(apply(raster(z), k, func=fn).data, want[st], rtol=RIM_MOMENT_RTOL, atol=0, equal_nan=True,
                                        err_msg=f"apply {kind} r={radius} {st}")
         flat = focal_stats(raster(z), k, stats_funcs=['var', 'std']).data[:, shape[0] - 60 + radius:shape[0], :200 - radius]
         assert (flat == 0).all()

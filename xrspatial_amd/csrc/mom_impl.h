@@ -787,8 +787,29 @@ __global__ void __launch_bounds__(256, 2) focal_mom_rescue_kernel(const MomArgs 
                 mom_fix_cells<R, Shape>(a, fixes[wv], w.n_fix, xw, y0, lane);
             }
         } else {
-            mom_exact_tile<R, Shape>(a, x_tile, lane, y0, y_end, q, 1);
+            // the float64 column walker: a launch of its own behind this one (inlined here its registers are this kernel's --
+            // 332 against 256, 129 of them spilled in the NaN-aware walker's loop, the common path)
+            unsigned idx = 0;
+            if (lane == 0) idx = atomicAdd(a.exact, 1u);
+            idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+            // (the list holds every band this launch can form: items <= max(waves, 2 tiles) <= exact_cap, xrs_common.h)
+            if (lane == 0 && idx < a.exact_cap) {
+                uint4 e4;
+                e4.x = (unsigned)x_tile; e4.y = (unsigned)q; e4.z = (unsigned)y0; e4.w = (unsigned)y_end;
+                reinterpret_cast<uint4 *>(a.exact + 4)[idx] = e4;
+            }
         }
+    }
+}
+
+template <int R, typename Shape>
+__global__ void __launch_bounds__(256) focal_mom_exact_kernel(const MomArgs a) {
+    const unsigned count = a.exact[0] < a.exact_cap ? a.exact[0] : a.exact_cap;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (unsigned it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {
+        const uint4 e4 = reinterpret_cast<const uint4 *>(a.exact + 4)[it];
+        mom_exact_tile<R, Shape>(a, (long)e4.x, lane, (long)e4.z, (long)e4.w, (int)e4.y, 1);
     }
 }
 
@@ -823,7 +844,12 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
     if (a.rescue) {
         a.rescue_cap = (unsigned)(g.tiles_x * tiles_y);
         if (mom_rescue_bytes(g.rows, g.cols) < 8 + 4 * (size_t)a.rescue_cap) a.rescue = nullptr;
-        else XRS_HIP(hipMemsetAsync(a.rescue, 0, 8, s));
+        else {
+            XRS_HIP(hipMemsetAsync(a.rescue, 0, 8, s));
+            a.exact = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(a.rescue) + mom_exact_offset(g.rows, g.cols));
+            a.exact_cap = (unsigned)mom_exact_cap(g.rows, g.cols);
+            XRS_HIP(hipMemsetAsync(a.exact, 0, 16, s));
+        }
     }
     // (annuli: one instantiation per (outer, inner) radius pair, the run-time plane set -- 66 pairs up to radius 12)
     if constexpr (shape_has_hole<Shape>(R)) {
@@ -842,6 +868,8 @@ int launch_mom(MomArgs &a, const double *kernel, hipStream_t s) {
         static thread_local int cus = 0;
         if (!cus) cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : n_cu;
         hipLaunchKernelGGL((focal_mom_rescue_kernel<R, Shape, 0>), dim3((unsigned)(cus * 2)), dim3(256), 0, s, a);
+        XRS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((focal_mom_exact_kernel<R, Shape>), dim3((unsigned)(cus * 2)), dim3(256), 0, s, a);
         XRS_LAUNCH_CHECK();
     }
     return 0;

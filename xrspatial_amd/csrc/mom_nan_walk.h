@@ -22,6 +22,8 @@ struct MomArgs {
     const unsigned char *todo;    // boxes behind boxsep.hip's fast walk: one byte per workgroup tile, 0 = nothing to do; else NULL
     unsigned *rescue;             // work-list of the wave tiles the fast walks handed on: [0] count, [2..] tiles; or NULL
     unsigned rescue_cap;          // entries it holds
+    unsigned *exact;              // bands the rescue launch hands on to focal_mom_exact_kernel: [0] count, then from [4] on
+    unsigned exact_cap;           // 16-byte entries {x_tile, q, y0, y_end}
 };
 
 

@@ -327,7 +327,11 @@ int launch_box_sep(const float *in, float *out_sum, float *out_mean, float *out_
 inline size_t box_todo_bytes(long rows, long cols) { return (size_t)(cols / 512 + 2) * (size_t)(rows / 64 + 2); }
 // the moments kernels' work-list of wave tiles handed on to focal_mom_rescue_kernel (mom_impl.h): [0] count, [2..] tiles;
 // wave tiles are at least 64 columns x 16 rows
-inline size_t mom_rescue_bytes(long rows, long cols) { return 256 + 4 * (size_t)(cols / 64 + 2) * (size_t)(rows / 16 + 2); }
+// behind it (mom_exact_offset): the bands the rescue launch hands on to the float64 walker's own launch, 16 bytes each
+inline size_t mom_rescue_tiles(long rows, long cols) { return (size_t)(cols / 64 + 2) * (size_t)(rows / 16 + 2); }
+inline size_t mom_exact_offset(long rows, long cols) { return 256 + 4 * mom_rescue_tiles(rows, cols); }
+inline size_t mom_exact_cap(long rows, long cols) { return 2 * mom_rescue_tiles(rows, cols) + 8192; }
+inline size_t mom_rescue_bytes(long rows, long cols) { return mom_exact_offset(rows, cols) + 16 + 16 * mom_exact_cap(rows, cols); }
 // ... handed from xrs_focal_stats_f32 (kxk.hip, which owns the caller's workspace) to launch_mom (mom_impl.h, nine
 // translation units) without widening every entry point in between: set around the call, NULL otherwise
 inline unsigned *&mom_rescue_slot() {

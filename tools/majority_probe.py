@@ -22,7 +22,9 @@ nbytes = int(_lib.load().xrs_zonal_majority_workspace_bytes(n * n, nz, 0))
 work = xs.DeviceArray((nbytes,), np.uint8)
 out = xs.DeviceArray((nz,), np.float64)
 t = Timer()
-for name, vals in (("continuous", dem), ("categorical32", cat)):
+CASES = [c for c in (("continuous", dem), ("categorical32", cat)) if c[0] in os.environ.get("MAJORITY_CASES", "continuous,categorical32")]
+SORT_TOO = os.environ.get("MAJORITY_SORT", "1") == "1"
+for name, vals in (CASES if SORT_TOO else []):
     med, mn = t.time(lambda: L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None), 3, warmup=1)
     print(f"majority {name:14s} {med:9.2f} ms  ({n*n/med/1e3:8.0f} Mcells/s)  workspace {nbytes/2**30:.1f} GiB", flush=True)
 
@@ -30,7 +32,7 @@ for name, vals in (("continuous", dem), ("categorical32", cat)):
 nbytes2 = int(_lib.load().xrs_zonal_mode_workspace_bytes(n * n, nz, 0))
 work2 = xs.DeviceArray((nbytes2,), np.uint8)
 out2 = xs.DeviceArray((nz + 1,), np.float64)
-for name, vals in (("continuous", dem), ("categorical32", cat)):
+for name, vals in CASES:
     med, mn = t.time(lambda: L("xrs_zonal_mode_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, None, work2.ptr, nbytes2, out2.ptr, None), 5, warmup=1)
     L("xrs_zonal_majority_f32", zones.ptr, vals.ptr, n * n, nz, 0.0, 0, work.ptr, nbytes, out.ptr, None)
     a, b = out2.get(), out.get()

@@ -33,13 +33,22 @@ namespace {
 constexpr int TILE_THREADS = 256;
 constexpr int PER_THREAD = 16;
 constexpr int TILE = TILE_THREADS * PER_THREAD;   // cells / keys per workgroup of the scatter passes
-constexpr int CHUNK_THREADS = 1024;               // the part passes: 16384 keys per workgroup -- a zone of 2^10 parts then gets 16 keys =
+#ifndef XRS_MODE_CHUNK_THREADS
+#define XRS_MODE_CHUNK_THREADS 512
+#endif
+#ifndef XRS_MODE_SLOTS
+#define XRS_MODE_SLOTS 2048
+#endif
+#ifndef XRS_MODE_PART_TARGET
+#define XRS_MODE_PART_TARGET 1024
+#endif
+constexpr int CHUNK_THREADS = XRS_MODE_CHUNK_THREADS;               // the part passes: 16384 keys per workgroup -- a zone of 2^10 parts then gets 16 keys =
 constexpr int CHUNK = CHUNK_THREADS * PER_THREAD;  // one 64-byte line per part and chunk (4096-key chunks: 16-byte runs, 2 TB/s)
-constexpr int PART_TARGET = 1024;                 // a zone is cut into 2^B parts of (512, 1024] keys on average
+constexpr int PART_TARGET = XRS_MODE_PART_TARGET;                 // a zone is cut into 2^B parts of (512, 1024] keys on average
 constexpr int MAX_B = 16;                         // most parts per zone
 constexpr int LDS_B = 11;                         // zones of up to 2^LDS_B parts: per-chunk LDS histogram (8 KiB); above: one
                                                   // global atomic per key (a 4096-key chunk meets a part less than twice)
-constexpr int SLOTS = 2048;                       // hash table of the counting pass: load <= 0.5 + tail for a part.  (4096 slots: 32 KiB,
+constexpr int SLOTS = XRS_MODE_SLOTS;                       // hash table of the counting pass: load <= 0.5 + tail for a part.  (4096 slots: 32 KiB,
                                                   // four workgroups per CU -- the pass is bound by the LATENCY of its LDS atomics, and
                                                   // eight tables in flight per CU count twice as fast as four half-empty ones)
 constexpr int MAX_ZONES = 16384;                  // LDS histogram of the zones of a tile
@@ -379,9 +388,12 @@ __global__ void __launch_bounds__(CHUNK_THREADS) scatter_part_kernel(const K *__
 // No pass over the table at the end: the add that counts a key returns how many there were before it, so the LAST of a
 // key's cells to arrive holds its multiplicity, and the maximum over every cell of (what its add returned + 1, key) is
 // the maximum over the table.
-// Persistent workgroups, one part after the other; the descriptor and the first keys of the NEXT part are fetched while
-// this one is counted (a part is ~1024 keys: without that every part is three dependent round trips to memory for a
-// microsecond of LDS work).  A wave whose 64 keys are one value (categories, quantised rasters) counts them with one add.
+// A part is ~1024 keys: a microsecond of LDS work behind three dependent round trips to memory (descriptor, keys, the
+// write of the result) if taken one by one -- 8 ms for the 10^6 parts of a 32768^2 raster however the table was sized.
+// So a workgroup owns a CONTIGUOUS range of parts, reads their descriptors 256 at a time into LDS, and keeps the first
+// keys of the next TWO parts in flight while it counts one.  (Contiguous ranges also spread the heavy parts of a
+// categorical raster -- the same few offsets in every zone's 2^B parts -- over all workgroups.)  A wave whose 64 keys are
+// one value counts them with one add.
 constexpr int CNT_BATCH = 4;                       // keys per thread and batch: 1024 keys, the usual part in one batch
 template <typename K>
 __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, const K *__restrict__ parted,
@@ -391,13 +403,16 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
     __shared__ __attribute__((aligned(16))) unsigned t_cnt[SLOTS];
     __shared__ unsigned s_cnt[4];
     __shared__ K s_key[4];
+    __shared__ unsigned d_off[256], d_len[256];
     const K EMPTY = ~(K)0;                          // no finite value encodes to all-ones
     const unsigned n_parts = hdr->n_parts;
     const int lane = threadIdx.x & 63;
-    unsigned p = blockIdx.x;
-    if (p >= n_parts) return;
-    unsigned off = part_off[p], len = part_count[p];
-    K pre[CNT_BATCH];
+    const unsigned per = (n_parts + gridDim.x - 1) / gridDim.x;
+    const unsigned p0 = blockIdx.x * per;
+    const unsigned p1 = p0 + per < n_parts ? p0 + per : n_parts;
+    if (p0 >= p1) return;
+    bool lost = false;
+
     auto fetch = [&](unsigned o, unsigned l, unsigned base, K (&k)[CNT_BATCH]) {
         const K *src = (o & IN_KEYS) ? keys + (o & ~IN_KEYS) : parted + o;
 #pragma unroll
@@ -406,80 +421,87 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
             k[j] = i < l ? src[i] : EMPTY;
         }
     };
-    fetch(off, len, 0, pre);
-    bool lost = false;
-    for (;;) {
-        const unsigned pn = p + gridDim.x;
-        unsigned off_n = 0, len_n = 0;
-        if (pn < n_parts) { off_n = part_off[pn]; len_n = part_count[pn]; }
+    // the first batch of part p (descriptors of the current block of 256 in LDS), nothing for parts beyond the range
+    auto fetch_part = [&](unsigned p, unsigned blk0, K (&k)[CNT_BATCH]) {
+        if (p < p1 && p - blk0 < 256u) fetch(d_off[p - blk0], d_len[p - blk0], 0, k);
+        else {
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j) k[j] = EMPTY;
+        }
+    };
+    // one batch of keys into the table; (bc, bk): the thread's best so far
+    auto probe = [&](const K (&cur)[CNT_BATCH], unsigned &bc, K &bk) {
+        // the batch's keys probe TOGETHER: a compare-and-swap and an add that return are ~2 x 150 cycles of LDS latency per
+        // probe, and one key after the other is four such chains in a row; four slots in flight instead
+        unsigned slot[CNT_BATCH], add[CNT_BATCH];
+        unsigned open = 0;                         // bit j: key j has not been counted yet
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            const K k = cur[j];
+            const bool has = k != EMPTY;
+            slot[j] = slot_of(k);
+            add[j] = 1;
+            bool mine = has;
+            const unsigned long long hm = __ballot(has);
+            if (hm) {
+                // one value in the whole wave (categories, quantised rasters): its first lane adds for all
+                const int leader = __ffsll((long long)hm) - 1;
+                const K kl = __shfl(k, leader);
+                if (__all(!has || k == kl)) { add[j] = (unsigned)__popcll(hm); mine = lane == leader; }
+            }
+            open |= mine ? 1u << j : 0u;
+        }
+        for (int probes = 0; __any(open != 0); ++probes) {
+            K prev[CNT_BATCH];
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j)
+                if (open >> j & 1) prev[j] = atomicCAS(&t_key[slot[j]], EMPTY, cur[j]);
+            unsigned got = 0;
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j) {
+                if (!(open >> j & 1)) continue;
+                if (prev[j] == EMPTY || prev[j] == cur[j]) got |= 1u << j;
+                else slot[j] = (slot[j] + 1) & (SLOTS - 1);
+            }
+            unsigned cnt[CNT_BATCH];
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j)
+                if (got >> j & 1) cnt[j] = atomicAdd(&t_cnt[slot[j]], add[j]) + add[j];
+#pragma unroll
+            for (int j = 0; j < CNT_BATCH; ++j)
+                if (got >> j & 1) {
+                    const K k = cur[j];
+                    if (cnt[j] > bc || (cnt[j] == bc && k < bk)) { bc = cnt[j]; bk = k; }
+                }
+            open &= ~got;
+            if (probes >= SLOTS) { lost = lost || open != 0; break; }
+        }
+    };
+    // part p, whose first batch is in `first`
+    auto one_part = [&](unsigned p, unsigned blk0, const K (&first)[CNT_BATCH]) {
+        const unsigned off = d_off[p - blk0], len = d_len[p - blk0];
         unsigned bc = 0;
         K bk = EMPTY;
         if (len) {                                  // (uniform over the workgroup)
-            {
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                v4u *ck = reinterpret_cast<v4u *>(t_key), *cc = reinterpret_cast<v4u *>(t_cnt);
-                const v4u ones = {~0u, ~0u, ~0u, ~0u}, zeros = {0u, 0u, 0u, 0u};
-                for (int s = threadIdx.x; s < (int)(SLOTS * sizeof(K) / 16); s += 256) ck[s] = ones;
-                for (int s = threadIdx.x; s < SLOTS / 4; s += 256) cc[s] = zeros;
-            }
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            v4u *ck = reinterpret_cast<v4u *>(t_key), *cc = reinterpret_cast<v4u *>(t_cnt);
+            const v4u ones = {~0u, ~0u, ~0u, ~0u}, zeros = {0u, 0u, 0u, 0u};
+            for (int s = threadIdx.x; s < (int)(SLOTS * sizeof(K) / 16); s += 256) ck[s] = ones;
+            for (int s = threadIdx.x; s < SLOTS / 4; s += 256) cc[s] = zeros;
             __syncthreads();
             K cur[CNT_BATCH];
 #pragma unroll
-            for (int j = 0; j < CNT_BATCH; ++j) cur[j] = pre[j];
+            for (int j = 0; j < CNT_BATCH; ++j) cur[j] = first[j];
             for (unsigned base = 0; base < len; base += 256 * CNT_BATCH) {
-                // the next batch of this part, or the first of the next part, on its way while this one is counted
-                if (base + 256 * CNT_BATCH < len) fetch(off, len, base + 256 * CNT_BATCH, pre);
-                else if (pn < n_parts) fetch(off_n, len_n, 0, pre);
-                // the batch's keys probe TOGETHER: a compare-and-swap and an add that return are ~2 x 150 cycles of LDS latency
-                // per probe, and one key after the other is four such chains in a row; four slots in flight instead
-                unsigned slot[CNT_BATCH], add[CNT_BATCH];
-                unsigned open = 0;                     // bit j: key j has not been counted yet
+                K nxt[CNT_BATCH];
+                const bool more = base + 256 * CNT_BATCH < len;          // (a part of many batches: heavy duplicates)
+                if (more) fetch(off, len, base + 256 * CNT_BATCH, nxt);
+                probe(cur, bc, bk);
+                if (more) {
 #pragma unroll
-                for (int j = 0; j < CNT_BATCH; ++j) {
-                    const K k = cur[j];
-                    const bool has = k != EMPTY;
-                    slot[j] = slot_of(k);
-                    add[j] = 1;
-                    bool mine = has;
-                    const unsigned long long hm = __ballot(has);
-                    if (hm) {
-                        // one value in the whole wave (categories, quantised rasters): its first lane adds for all
-                        const int leader = __ffsll((long long)hm) - 1;
-                        const K kl = __shfl(k, leader);
-                        if (__all(!has || k == kl)) { add[j] = (unsigned)__popcll(hm); mine = lane == leader; }
-                    }
-                    open |= mine ? 1u << j : 0u;
+                    for (int j = 0; j < CNT_BATCH; ++j) cur[j] = nxt[j];
                 }
-                for (int probes = 0; __any(open != 0); ++probes) {
-                    K prev[CNT_BATCH];
-#pragma unroll
-                    for (int j = 0; j < CNT_BATCH; ++j)
-                        if (open >> j & 1) prev[j] = atomicCAS(&t_key[slot[j]], EMPTY, cur[j]);
-                    unsigned got = 0;
-#pragma unroll
-                    for (int j = 0; j < CNT_BATCH; ++j) {
-                        if (!(open >> j & 1)) continue;
-                        if (prev[j] == EMPTY || prev[j] == cur[j]) got |= 1u << j;
-                        else slot[j] = (slot[j] + 1) & (SLOTS - 1);
-                    }
-                    unsigned cnt[CNT_BATCH];
-#pragma unroll
-                    for (int j = 0; j < CNT_BATCH; ++j)
-                        if (got >> j & 1) cnt[j] = atomicAdd(&t_cnt[slot[j]], add[j]) + add[j];
-#pragma unroll
-                    for (int j = 0; j < CNT_BATCH; ++j)
-                        if (got >> j & 1) {
-                            const K k = cur[j];
-                            if (cnt[j] > bc || (cnt[j] == bc && k < bk)) { bc = cnt[j]; bk = k; }
-                        }
-                    open &= ~got;
-                    if (probes >= SLOTS) { lost = lost || open != 0; break; }
-                }
-#pragma unroll
-                for (int j = 0; j < CNT_BATCH; ++j) cur[j] = pre[j];
             }
-        } else if (pn < n_parts) {
-            fetch(off_n, len_n, 0, pre);
         }
         // workgroup maximum of (count, then smallest key)
 #pragma unroll
@@ -496,9 +518,33 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
             best_count[p] = bc;
             best_key[p] = bk;
         }
-        if (pn >= n_parts) break;
-        p = pn; off = off_n; len = len_n;
         __syncthreads();                            // (s_cnt / the table are reused)
+    };
+
+    for (unsigned blk0 = p0; blk0 < p1; blk0 += 256) {
+        __syncthreads();
+        if (blk0 + threadIdx.x < p1) { d_off[threadIdx.x] = part_off[blk0 + threadIdx.x]; d_len[threadIdx.x] = part_count[blk0 + threadIdx.x]; }
+        __syncthreads();
+        const unsigned blk1 = blk0 + 256 < p1 ? blk0 + 256 : p1;
+        K a[CNT_BATCH], b[CNT_BATCH];
+        fetch_part(blk0, blk0, a);
+        fetch_part(blk0 + 1, blk0, b);
+        for (unsigned p = blk0; p < blk1; p += 2) {
+            {
+                K cur[CNT_BATCH];
+#pragma unroll
+                for (int j = 0; j < CNT_BATCH; ++j) cur[j] = a[j];
+                fetch_part(p + 2 < blk1 ? p + 2 : p1, blk0, a);          // (two parts ahead, before this one is counted)
+                one_part(p, blk0, cur);
+            }
+            if (p + 1 < blk1) {
+                K cur[CNT_BATCH];
+#pragma unroll
+                for (int j = 0; j < CNT_BATCH; ++j) cur[j] = b[j];
+                fetch_part(p + 3 < blk1 ? p + 3 : p1, blk0, b);
+                one_part(p + 1, blk0, cur);
+            }
+        }
     }
     if (lost) atomicAdd(&hdr->overflow, 1u);
 }
@@ -640,8 +686,6 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
         }
-        // (an ODD number of workgroups: the heavy parts of a categorical raster sit at the same offsets d in every zone's
-        //  2^B parts, and a stride that divides 2^B hands all of them to the same few workgroups: 55 ms instead of 5)
         long per_cu = 160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64);
         if (per_cu > 8) per_cu = 8;                 // (2048 threads per CU)
         const long slots = ((long)cus * per_cu - 1) | 1;

@@ -2,7 +2,7 @@
 #   gpurun -- 'bash tools/zm_variants.sh [lib ...]'     (libs: names under xrspatial_amd/, default libxrs_hip.so)
 mkdir -p gpurun_out/zm
 for lib in ${@:-libxrs_hip.so}; do
-  for c in continuous categorical32; do
+  for c in ${ZM_CASES:-continuous categorical32}; do
     echo "=== $lib $c"
     (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/zm_prof && XRS_LIB=/root/repo/xrspatial_amd/$lib MAJORITY_CASES=$c MAJORITY_SORT=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zm_prof -o s -- python /root/repo/tools/majority_probe.py 32768 2>/dev/null | grep "^mode")
     f=$(find /tmp/zm_prof -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/zm/${lib%.so}_${c}_kernel_stats.csv

@@ -15,8 +15,9 @@
 //                   equally; continuous rasters, quantised rasters and categories all spread evenly)  4 B / cell
 //   5. part_offsets per zone: exclusive scan of its parts
 //   6. scatter_part keys of a zone -> its parts (LDS histogram per 4096-key chunk, one global atomic per part) 4 + 4
-//   7. count        one workgroup per part: open-addressing hash table in LDS (key -> multiplicity), its best
-//                   (multiplicity, then smallest key)                                         4 B / cell
+//   7. count        a workgroup per part, two passes over its ~1024 keys (in registers): a count-only table first (one LDS
+//                   add per key) -- a key ALONE in its slot has multiplicity 1 -- then the keys that share a slot into an
+//                   open-addressing table (key -> multiplicity); the part's best (multiplicity, smallest key)   4 B / cell
 //   8. reduce       per zone: best of its parts -> the value, float64; NaN for a zone without a valid cell
 // 32 B / cell of streaming traffic instead of the sorts' ~100.  Grids of 4 / 6 / 7 are sized for the worst case the
 // plan can produce (no host round trip in the middle); surplus workgroups leave at once.
@@ -384,16 +385,17 @@ __global__ void __launch_bounds__(CHUNK_THREADS) scatter_part_kernel(const K *__
         if (part[j] != 0xffffffffu) parted[hist[part[j]] + rank[j]] = key[j];
 }
 
-// 7. multiplicities of the keys of one part, in an LDS hash table; the part's best (multiplicity, then smallest key).
-// No pass over the table at the end: the add that counts a key returns how many there were before it, so the LAST of a
-// key's cells to arrive holds its multiplicity, and the maximum over every cell of (what its add returned + 1, key) is
-// the maximum over the table.
-// A part is ~1024 keys: a microsecond of LDS work behind three dependent round trips to memory (descriptor, keys, the
-// write of the result) if taken one by one -- 8 ms for the 10^6 parts of a 32768^2 raster however the table was sized.
-// So a workgroup owns a CONTIGUOUS range of parts, reads their descriptors 256 at a time into LDS, and keeps the first
-// keys of the next TWO parts in flight while it counts one.  (Contiguous ranges also spread the heavy parts of a
-// categorical raster -- the same few offsets in every zone's 2^B parts -- over all workgroups.)  A wave whose 64 keys are
-// one value counts them with one add.
+// 7. the mode of one part.  No pass over a table at the end: the add that counts a key returns how many there were before it, so
+// the LAST of a key's cells to arrive holds its multiplicity, and the maximum over every cell of (returned + 1, key) is the
+// maximum over the table.
+// A part is ~1024 keys: a microsecond of LDS work behind three dependent round trips to memory (descriptor, keys, the write
+// of the result) if taken one by one.  So a workgroup owns a CONTIGUOUS range of parts, reads their descriptors 256 at a time
+// into LDS and keeps the first keys of the next TWO parts in flight while it counts one.  (Contiguous ranges also spread the
+// heavy parts of a categorical raster -- the same few offsets in every zone's 2^B parts -- over all workgroups.)
+// What the pass costs (32768^2, 10^6 parts, tools/zm_variants.sh): its structure without any table 0.2 ms; one returning LDS
+// add per key 1.85 ms; every key finding its own slot by compare-and-swap 8 ms -- whatever the table size (2048 / 4096 / 8192
+// slots: 8.0 / 7.0 / 11.0), the prefetch depth or the number of adds behind the swap: the probing loop runs until the wave's
+// unluckiest key has walked its cluster.  Hence the sieve in front of it (7.0 ms): two passes, below.
 constexpr int CNT_BATCH = 4;                       // keys per thread and batch: 1024 keys, the usual part in one batch
 template <typename K>
 __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, const K *__restrict__ parted,
@@ -401,6 +403,7 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
                                                     Hdr *__restrict__ hdr, unsigned *__restrict__ best_count, K *__restrict__ best_key) {
     __shared__ __attribute__((aligned(16))) K t_key[SLOTS];
     __shared__ __attribute__((aligned(16))) unsigned t_cnt[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned f_cnt[SLOTS];
     __shared__ unsigned s_cnt[4];
     __shared__ K s_key[4];
     __shared__ unsigned d_off[256], d_len[256];
@@ -429,28 +432,55 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
             for (int j = 0; j < CNT_BATCH; ++j) k[j] = EMPTY;
         }
     };
-    // one batch of keys into the table; (bc, bk): the thread's best so far
-    auto probe = [&](const K (&cur)[CNT_BATCH], unsigned &bc, K &bk) {
-        // the batch's keys probe TOGETHER: a compare-and-swap and an add that return are ~2 x 150 cycles of LDS latency per
-        // probe, and one key after the other is four such chains in a row; four slots in flight instead
-        unsigned slot[CNT_BATCH], add[CNT_BATCH];
-        unsigned open = 0;                         // bit j: key j has not been counted yet
+    // a batch's keys as the cells that act for them: a wave whose 64 keys are ONE value (categories, quantised rasters) is
+    // represented by its first lane with add = 64; `open` bit j: key j acts
+    auto group = [&](const K (&cur)[CNT_BATCH], unsigned (&add)[CNT_BATCH]) -> unsigned {
+        unsigned open = 0;
 #pragma unroll
         for (int j = 0; j < CNT_BATCH; ++j) {
             const K k = cur[j];
             const bool has = k != EMPTY;
-            slot[j] = slot_of(k);
             add[j] = 1;
             bool mine = has;
             const unsigned long long hm = __ballot(has);
             if (hm) {
-                // one value in the whole wave (categories, quantised rasters): its first lane adds for all
                 const int leader = __ffsll((long long)hm) - 1;
                 const K kl = __shfl(k, leader);
                 if (__all(!has || k == kl)) { add[j] = (unsigned)__popcll(hm); mine = lane == leader; }
             }
             open |= mine ? 1u << j : 0u;
         }
+        return open;
+    };
+    // PASS 1 of a part: cells per slot of a count-only table (one LDS add that returns nothing).  Measured on the 10^6 parts of
+    // a 32768^2 raster: this pass 1.7 ms, against 6 ms for finding every key's own slot by compare-and-swap (the loop runs
+    // until the wave's unluckiest key has walked its cluster).
+    auto sieve = [&](const K (&cur)[CNT_BATCH]) {
+        unsigned add[CNT_BATCH];
+        const unsigned open = group(cur, add);
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j)
+            if (open >> j & 1) atomicAdd(&f_cnt[slot_of(cur[j])], add[j]);
+    };
+    // PASS 2: a key ALONE in its slot of the count-only table has multiplicity add (exact: equal keys share a slot); only the
+    // keys that share a slot (39 % at load 0.5, mostly with other values) are counted exactly, in an open-addressing table that
+    // is then nearly empty -- the add that counts a key returns how many came before it; the table's count is the multiplicity
+    // minus one, so the cell that claims a slot pays no second atomic.  (bc, bk): the thread's best so far.
+    auto count = [&](const K (&cur)[CNT_BATCH], unsigned &bc, K &bk) {
+        unsigned slot[CNT_BATCH], add[CNT_BATCH];
+        unsigned open = group(cur, add);
+#pragma unroll
+        for (int j = 0; j < CNT_BATCH; ++j) {
+            if (!(open >> j & 1)) continue;
+            const K k = cur[j];
+            if (f_cnt[slot_of(k)] == add[j]) {
+                if (add[j] > bc || (add[j] == bc && k < bk)) { bc = add[j]; bk = k; }
+                open &= ~(1u << j);
+            } else {
+                slot[j] = slot_of((K)((k << 15) | (k >> (8 * sizeof(K) - 15))) ^ (K)0x68E31DA4u);      // (another hash)
+            }
+        }
+        // the keys that are left probe TOGETHER: a compare-and-swap that returns is ~150 cycles of LDS latency
         for (int probes = 0; __any(open != 0); ++probes) {
             K prev[CNT_BATCH];
 #pragma unroll
@@ -465,8 +495,12 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
             }
             unsigned cnt[CNT_BATCH];
 #pragma unroll
-            for (int j = 0; j < CNT_BATCH; ++j)
-                if (got >> j & 1) cnt[j] = atomicAdd(&t_cnt[slot[j]], add[j]) + add[j];
+            for (int j = 0; j < CNT_BATCH; ++j) {
+                if (!(got >> j & 1)) continue;
+                const bool claimed = prev[j] == EMPTY;
+                const unsigned extra = claimed ? add[j] - 1u : add[j];     // (a claimer of ONE cell: no atomic at all)
+                cnt[j] = (extra ? atomicAdd(&t_cnt[slot[j]], extra) : 0u) + add[j] + (claimed ? 0u : 1u);
+            }
 #pragma unroll
             for (int j = 0; j < CNT_BATCH; ++j)
                 if (got >> j & 1) {
@@ -484,22 +518,29 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
         K bk = EMPTY;
         if (len) {                                  // (uniform over the workgroup)
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            v4u *ck = reinterpret_cast<v4u *>(t_key), *cc = reinterpret_cast<v4u *>(t_cnt);
+            v4u *ck = reinterpret_cast<v4u *>(t_key), *cc = reinterpret_cast<v4u *>(t_cnt), *cf = reinterpret_cast<v4u *>(f_cnt);
             const v4u ones = {~0u, ~0u, ~0u, ~0u}, zeros = {0u, 0u, 0u, 0u};
             for (int s = threadIdx.x; s < (int)(SLOTS * sizeof(K) / 16); s += 256) ck[s] = ones;
-            for (int s = threadIdx.x; s < SLOTS / 4; s += 256) cc[s] = zeros;
+            for (int s = threadIdx.x; s < SLOTS / 4; s += 256) { cc[s] = zeros; cf[s] = zeros; }
             __syncthreads();
-            K cur[CNT_BATCH];
-#pragma unroll
-            for (int j = 0; j < CNT_BATCH; ++j) cur[j] = first[j];
-            for (unsigned base = 0; base < len; base += 256 * CNT_BATCH) {
-                K nxt[CNT_BATCH];
-                const bool more = base + 256 * CNT_BATCH < len;          // (a part of many batches: heavy duplicates)
-                if (more) fetch(off, len, base + 256 * CNT_BATCH, nxt);
-                probe(cur, bc, bk);
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < CNT_BATCH; ++j) cur[j] = nxt[j];
+            const bool single = len <= 256u * CNT_BATCH;          // (the usual part: its keys stay in registers between the passes)
+            if (single) {
+                sieve(first);
+            } else {
+                for (unsigned base = 0; base < len; base += 256 * CNT_BATCH) {
+                    K cur[CNT_BATCH];
+                    fetch(off, len, base, cur);
+                    sieve(cur);
+                }
+            }
+            __syncthreads();
+            if (single) {
+                count(first, bc, bk);
+            } else {
+                for (unsigned base = 0; base < len; base += 256 * CNT_BATCH) {
+                    K cur[CNT_BATCH];
+                    fetch(off, len, base, cur);
+                    count(cur, bc, bk);
                 }
             }
         }
@@ -518,7 +559,7 @@ __global__ void __launch_bounds__(256) count_kernel(const K *__restrict__ keys, 
             best_count[p] = bc;
             best_key[p] = bk;
         }
-        __syncthreads();                            // (s_cnt / the table are reused)
+        __syncthreads();                            // (s_cnt / the tables are reused)
     };
 
     for (unsigned blk0 = p0; blk0 < p1; blk0 += 256) {
@@ -686,7 +727,7 @@ int mode_impl(const int32_t *zidx, const VT *vals, long n, int nz, VT nodata, in
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
         }
-        long per_cu = 160 * 1024 / (SLOTS * (long)(sizeof(K) + 4) + 64);
+        long per_cu = 160 * 1024 / (SLOTS * (long)(sizeof(K) + 8) + 2304);
         if (per_cu > 8) per_cu = 8;                 // (2048 threads per CU)
         const long slots = ((long)cus * per_cu - 1) | 1;
         hipLaunchKernelGGL((count_kernel<K>), dim3((unsigned)(slots < pl.max_parts ? slots : pl.max_parts)), dim3(256), 0, s, keys, parted,

@@ -2,7 +2,7 @@
 
 dask is not installable where this project is built and tested.  The slot (xrspatial_amd/utils.py: dask_overlap,
 dask_blocks) only needs `Array.map_overlap(func, depth, boundary, meta)`, `Array.astype`, `map_blocks(func, *arrays,
-meta)`, `stack`, and for hotspots `nanmean` / `nanstd` / `compute`; this module provides exactly those over numpy arrays cut into chunks, with dask's semantics:
+meta)`, `stack`, for hotspots `nanmean` / `nanstd` / `compute`, for zonal.stats `numblocks` / `blocks[i, j]`; this module provides exactly those over numpy arrays cut into chunks, with dask's semantics:
 a block is extended by `depth` cells of its neighbours (the `boundary` value beyond the array), the function runs on
 the extended block, the overlap is trimmed from its result.  Evaluation is eager (`compute()` returns what is already
 there); the chunk log lets a test check that the work really went block by block."""
@@ -22,6 +22,22 @@ class Array:
 
     def compute(self):
         return self._v
+
+    @property
+    def numblocks(self):
+        return tuple(len(ch) for ch in self.chunks)
+
+    @property
+    def blocks(self):
+        """`arr.blocks[i, j]`: that block as an array of one chunk (dask.array.Array.blocks)."""
+        outer = self
+
+        class _Blocks:
+            def __getitem__(self, ij):
+                (r0, r1), (c0, c1) = outer._spans()[0][ij[0]], outer._spans()[1][ij[1]]
+                outer.blocks_seen.append((r1 - r0, c1 - c0))
+                return Array(outer._v[r0:r1, c0:c1], ((r1 - r0,), (c1 - c0,)))
+        return _Blocks()
 
     def __array__(self, dtype=None, copy=None):
         return self._v if dtype is None else self._v.astype(dtype)

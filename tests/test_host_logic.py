@@ -698,8 +698,22 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
     assert len(np.unique(np.asarray(want.data))) > 1
     with pytest.raises(ZeroDivisionError):
         xfocal.hotspots(lazy(np.full((37, 53), 7.0, np.float32)), k5)
-    # what has no dask slot still says so (zonal.stats on dask needs the block-partials combine: ShardedArray's job here)
+    # zonal.stats: per-block partial sums combined like _stats_dask_numpy (zonal.py:181-277); majority is not a block statistic
     from xrspatial_amd import zonal as xzonal
-    zones = xs.DataArray(fake_dask.from_array((np.arange(37 * 53).reshape(37, 53) % 5).astype(np.int32), (16, 20)), dims=['y', 'x'])
-    with pytest.raises((NotImplementedError, TypeError)):
-        xzonal.stats(zones, lazy())
+    monkeypatch.setattr(xzonal, "is_dask", lambda d: isinstance(d, fake_dask.Array))
+    zvals = ((np.arange(37)[:, None] // 9) * 3 + np.arange(53)[None, :] // 20).astype(np.int32)
+    zones = xs.DataArray(fake_dask.from_array(zvals, (16, 20)), dims=['y', 'x'])
+    seven = ['mean', 'max', 'min', 'sum', 'std', 'var', 'count']
+    lazy_vals = lazy()
+    got = xzonal.stats(zones, lazy_vals, stats_funcs=seven + ['majority'], zone_ids=[0, 4, 7, 99], nodata_values=float(z[0, 0]))
+    want = xzonal.stats(xs.DataArray(zvals, dims=['y', 'x']), host, stats_funcs=seven, zone_ids=[0, 4, 7, 99], nodata_values=float(z[0, 0]))
+    assert list(got.columns) == ['zone'] + seven and got['zone'].tolist() == [0, 4, 7]
+    for col in got.columns:
+        np.testing.assert_allclose(np.asarray(got[col], dtype=np.float64), np.asarray(want[col], dtype=np.float64), rtol=1e-12, err_msg=col)
+    assert len(lazy_vals.data.blocks_seen) == 9 and max(lazy_vals.data.blocks_seen) == (16, 20)       # block by block
+    with pytest.raises(ValueError):
+        xzonal.stats(zones, lazy(), stats_funcs={'n': len})
+    with pytest.raises(ValueError):
+        xzonal.stats(zones, lazy(), return_type='xarray.DataArray')
+    with pytest.raises(ValueError):
+        xzonal.stats(xs.DataArray(fake_dask.from_array(zvals, (10, 20)), dims=['y', 'x']), lazy(), stats_funcs=seven)

@@ -18,7 +18,7 @@ from ._launch import get_stream
 from ._xr import DataArray, Dataset
 from .device import DTYPE_CODE, DeviceArray
 from .sharded import ShardedArray, ShardedStack, same_layout
-from .utils import validate_arrays
+from .utils import is_dask, validate_arrays
 
 _DEVICE_STATS = ('mean', 'max', 'min', 'sum', 'std', 'var', 'count')
 _DEFAULT_STATS = _DEVICE_STATS + ('majority',)
@@ -645,6 +645,13 @@ def stats(
             coords['stats'] = names
             return DataArray(result, coords=coords, dims=('stats',) + tuple(values.dims), attrs=values.attrs)
         return result
+    if is_dask(values.data):
+        if custom or return_type != 'pandas.DataFrame':
+            # (zonal.py:628-633: a dask-backed `values` takes a LIST of the default statistics; its dask runner ignores
+            #  return_type, :181-277)
+            raise ValueError("Got dask-backed DataArray as `values` aggregate. `stats_funcs` must be a subset of default supported "
+                             "stats `['mean', 'max', 'min', 'sum', 'std', 'var', 'count']`; the result is a DataFrame")
+        return _stats_dask(zones.data, values.data, zone_ids, names, nodata_values)
     if not isinstance(values.data, (np.ndarray, DeviceArray)):
         raise TypeError("Unsupported Array Type: {}".format(type(values)))
     result = _stats_hip(zones.data, values.data, zone_ids, names, nodata_values, return_type, custom=custom)
@@ -653,6 +660,48 @@ def stats(
         coords['stats'] = names
         return DataArray(result, coords=coords, dims=('stats',) + tuple(values.dims), attrs=values.attrs)
     return result
+
+
+def _stats_dask(zones, values, zone_ids, stat_names, nodata_values):
+    """zonal.stats of dask-backed rasters: the reference's `_stats_dask_numpy` (zonal.py:181-277) -- per-block
+    count / sum / sum of squares / min / max, combined by adding and reducing, mean / std / var from the combined sums
+    (`_dask_mean / _dask_std / _dask_var`, :100-102) -- with the MI355X reducing every block (the partial-sums kernel the
+    numpy and sharded backends use) and `distributed.combine_zonal_partials` as the combine.  One block in HBM at a time.
+    Like upstream: `majority` is not among the block statistics and is left out of the frame (:83-99, :262-264); the blocks
+    of `zones` and `values` are paired in order, so both rasters must be chunked alike.
+    Returns a pandas DataFrame (upstream: a dask DataFrame of one partition -- `dask.dataframe` wraps it when importable)."""
+    from .distributed import combine_zonal_partials
+    if tuple(zones.chunks) != tuple(values.chunks):
+        raise ValueError("zones and values must be chunked alike (zonal.py:198-199 pairs their blocks in order)")
+    nby, nbx = zones.numblocks
+    zblocks = [[np.asarray(zones.blocks[i, j].compute()) for j in range(nbx)] for i in range(nby)]
+    uniq = [np.unique(b[np.isfinite(b)]) if np.issubdtype(b.dtype, np.floating) else np.unique(b) for row in zblocks for b in row]
+    unique_zones = np.unique(np.concatenate(uniq)) if uniq else np.empty(0)
+    nz = len(unique_zones)
+    names = [n for n in stat_names if n != 'majority']
+    if nz == 0:
+        return pd.DataFrame({'zone': unique_zones, **{n: np.empty(0) for n in names}})
+    parts = []
+    for i in range(nby):
+        for j in range(nbx):
+            zb = zblocks[i][j]
+            vb = np.ascontiguousarray(values.blocks[i, j].compute())
+            ok = np.isfinite(zb) if np.issubdtype(zb.dtype, np.floating) else np.ones(zb.shape, bool)
+            idx = np.where(ok, np.searchsorted(unique_zones, np.where(ok, zb, unique_zones[0])), -1).astype(np.int32)
+            _, vdev = _stage(idx, vb)
+            parts.append(zonal_partials(DeviceArray.from_numpy(np.ascontiguousarray(idx)), vdev, nz, nodata_values))
+    count, s1, s2, mn, mx, shift = combine_zonal_partials(parts)
+    cols = finalize_stats(names, count, s1, s2, mn, mx, None, shift)
+    keep = np.arange(nz) if zone_ids is None else np.flatnonzero(np.isin(unique_zones, np.unique(zone_ids)))
+    frame = {'zone': unique_zones[keep]}
+    for n in names:
+        frame[n] = cols[n][keep]
+    df = pd.DataFrame(frame)
+    try:                                                      # pragma: no cover (dask is not installable in the build image)
+        import dask.dataframe as dd
+        return dd.from_pandas(df, npartitions=1)
+    except ImportError:
+        return df
 
 
 def _dense_index_any(data):

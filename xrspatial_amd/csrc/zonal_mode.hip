@@ -340,13 +340,24 @@ __global__ void __launch_bounds__(CHUNK_THREADS) scatter_part_kernel(const K *__
                                                                     const unsigned char *__restrict__ zone_B, int nz,
                                                                     const Hdr *__restrict__ hdr, unsigned *__restrict__ part_cursor,
                                                                     K *__restrict__ parted) {
-    if (blockIdx.x >= hdr->n_chunks || (DIRECT && !hdr->n_direct)) return;
+    if (DIRECT && !hdr->n_direct) return;
+#ifndef XRS_MODE_NO_XCD_BANDS
+    // chunks in contiguous bands per XCD (block b runs on XCD b % 8): the ~64-128 chunks of a zone then write their 16-64 byte
+    // runs of every part through ONE L2, which merges them into whole lines before they leave (dealt round-robin, eight L2s
+    // each held a slice of every line)
+    const long chunk_l = xcd_tile(blockIdx.x, hdr->n_chunks, 0);
+    if (chunk_l < 0) return;
+    const unsigned chunk = (unsigned)chunk_l;
+#else
+    if (blockIdx.x >= hdr->n_chunks) return;
+    const unsigned chunk = blockIdx.x;
+#endif
     __shared__ unsigned hist[DIRECT ? 1 : (1 << LDS_B)];
-    const int z = chunk_zone[blockIdx.x];
+    const int z = chunk_zone[chunk];
     const int B = zone_B[z];
     if ((B > LDS_B) != DIRECT) return;
     const unsigned np = 1u << B, pb = part_base[z];
-    const unsigned lo = key_off[z] + (blockIdx.x - chunk_base[z]) * CHUNK, hi = key_off[z + 1];
+    const unsigned lo = key_off[z] + (chunk - chunk_base[z]) * CHUNK, hi = key_off[z + 1];
     if (DIRECT) {
 #pragma unroll 4
         for (int j = 0; j < PER_THREAD; ++j) {
@@ -629,7 +640,7 @@ struct Plan {
         direct = n > ((long)PART_TARGET << LDS_B);
         // sum over zones of 2^B <= 2 n / PART_TARGET + nz; of ceil(count / CHUNK) <= n / CHUNK + nz
         max_parts = 2 * (n / PART_TARGET + 1) + nz;
-        max_chunks = n / CHUNK + 1 + nz;
+        max_chunks = ((n / CHUNK + 1 + nz + 7) / 8) * 8 + 8;          // (padded for xcd_tile's bands)
         size_t o = 0;
         off_hdr = o; o += 256;
         off_zone_count = o; o += up256((size_t)nz * 4);

@@ -22,6 +22,8 @@ What is executed (reference file:line -> fixture prefix):
   kb    xrspatial/convolution.py:30-282   _is_numeric, _to_meters, _get_distance, _ellipse_kernel, circle_kernel,
                                        annulus_kernel, custom_kernel (live comparison only: tests/
                                        test_oracle_vs_reference_exec.py; nothing stored)
+  a14   xrspatial/utils.py:146-277, convolution.py:78-134   validate_arrays, get_xy_range, calc_res, get_dataarray_resolution,
+                                       calc_cellsize (live comparison only)
   ms    xrspatial/multispectral.py:825-841, 1017-1030   _normalized_ratio_cpu, _sipi_cpu on float32 bands: every
                                        operation is float32 (op) float32 -> float32 under NumPy-2 AND Numba typing
 
@@ -120,6 +122,17 @@ def ref_zonal():
 def ref_kernels():
     return lift("convolution.py", ["DEFAULT_UNIT", "METER", "FOOT", "KILOMETER", "MILE", "UNITS", "_is_numeric", "_to_meters",
                                    "_get_distance", "_ellipse_kernel", "circle_kernel", "annulus_kernel", "custom_kernel"])
+
+
+def ref_host_utils():
+    """utils.py:146-277 + convolution.py:78-134: validate_arrays, get_xy_range, calc_res, get_dataarray_resolution and
+    calc_cellsize -- plain Python over the DataArray surface (attrs, dims, shape, coordinate min / max)."""
+    u = lift("utils.py", ["validate_arrays", "get_xy_range", "calc_res", "get_dataarray_resolution"],
+             {"has_dask_array": lambda: False})
+    c = lift("convolution.py", ["DEFAULT_UNIT", "METER", "FOOT", "KILOMETER", "MILE", "UNITS", "_to_meters", "calc_cellsize"],
+             {"get_dataarray_resolution": u["get_dataarray_resolution"]})
+    u["calc_cellsize"] = c["calc_cellsize"]
+    return u
 
 
 def ref_multispectral():

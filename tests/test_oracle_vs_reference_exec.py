@@ -227,3 +227,91 @@ def test_live_kernel_builders():
         assert outcome(mine._get_distance, s) == outcome(ref["_get_distance"], s), s
         n += 1
     assert n > 1000
+
+
+@needs_reference
+def test_live_host_resolution_helpers():
+    """a14: the package's resolution / validation helpers against the reference's, on the same DataArray objects: `res` as tuple,
+    list, ndarray, scalar, malformed; coordinates only (ascending, descending, non-uniform); units; named dimensions; shapes
+    and backends that must be refused -- values and exception types."""
+    import xrspatial_amd as xs
+    from xrspatial_amd import convolution as mine_conv, utils as mine
+    ref = rx.ref_host_utils()
+
+    def outcome(fn, *args, **kw):
+        try:
+            r = fn(*args, **kw)
+            return ("ok", tuple(float(v) for v in r) if r is not None else None)
+        except Exception as e:                                        # noqa: BLE001 (the TYPE is what is compared)
+            return ("raise", type(e).__name__)
+
+    data = np.zeros((7, 11), np.float32)
+    rasters = []
+    for res in ((0.5, 0.5), [2, 3.5], np.array([1.0, 2.0]), 30, 12.5, (1, 2, 3), "10", None, (np.float32(2.0), 2.0), ("a", 1.0)):
+        rasters.append(xs.DataArray(data, dims=['y', 'x'], attrs={} if res is None else {'res': res},
+                                    coords={'y': np.linspace(70, 10, 7), 'x': np.linspace(-5, 45, 11)}))
+    rasters.append(xs.DataArray(data, dims=['lat', 'lon'], coords={'lat': np.array([0, 1, 2, 4, 7, 11, 16.0]), 'lon': np.arange(11.0) * 3}))
+    rasters.append(xs.DataArray(data, dims=['y', 'x'], attrs={'unit': 'km'}, coords={'y': np.arange(7.0), 'x': np.arange(11.0)}))
+    rasters.append(xs.DataArray(data, dims=['y', 'x'], attrs={'unit': 'ft', 'res': (3, 3)}))
+    rasters.append(xs.DataArray(data, dims=['y', 'x'], attrs={'unit': 'parsec', 'res': (3, 3)}))
+    rasters.append(xs.DataArray(np.zeros((1, 1), np.float32), dims=['y', 'x'], coords={'y': [1.0], 'x': [2.0]}))
+    n = 0
+    with np.errstate(all="ignore"):
+        for r in rasters:
+            for name, kw in (("get_dataarray_resolution", {}), ("calc_res", {}), ("calc_res", {'xdim': r.dims[-1], 'ydim': r.dims[-2]})):
+                assert outcome(getattr(mine, name), r, **kw) == outcome(ref[name], r, **kw), (name, r.attrs, r.dims)
+                n += 1
+            assert outcome(mine_conv.calc_cellsize, r) == outcome(ref["calc_cellsize"], r), ("calc_cellsize", r.attrs)
+            got, want = outcome(mine.get_xy_range, r), outcome(ref["get_xy_range"], r)
+            assert got[0] == want[0] and (got[0] == "raise" or np.allclose(np.ravel(got[1]), np.ravel(want[1]))) or got == want
+            n += 2
+    other = xs.DataArray(np.zeros((7, 12), np.float32), dims=['y', 'x'])
+    for args in ((rasters[0],), (rasters[0], other), (rasters[0], rasters[1]), (rasters[0], rasters[1], other)):
+        assert outcome(lambda *a: mine.validate_arrays(*a), *args) == outcome(lambda *a: ref["validate_arrays"](*a), *args)
+        n += 1
+    assert n >= 60
+
+
+@needs_reference
+def test_live_dataset_adapters():
+    """a14: `supports_dataset` / `supports_dataset_bands` (dataset_support.py) lifted from the reference and applied to the same
+    probe functions as the package's decorators, on the package's Dataset: results per variable, the `name` pass-through, band
+    aliases, what is refused and how."""
+    import functools
+    import inspect
+    import xrspatial_amd as xs
+    from xrspatial_amd import _xr, dataset_support as mine
+    ref = rx.lift("dataset_support.py", ["supports_dataset", "supports_dataset_bands"], {"functools": functools, "inspect": inspect, "xr": _xr})
+
+    def one(agg, factor=2.0, name='one'):
+        return xs.DataArray(np.asarray(agg.data) * factor, dims=agg.dims, name=name)
+
+    def no_name(agg, offset=0.0):
+        return xs.DataArray(np.asarray(agg.data) + offset, dims=agg.dims)
+
+    def bands(nir_agg, red_agg, soil=1.0, name='idx'):
+        return xs.DataArray(np.asarray(nir_agg.data) - soil * np.asarray(red_agg.data), dims=nir_agg.dims, name=name)
+
+    a = xs.DataArray(np.arange(6.0).reshape(2, 3), dims=['y', 'x'])
+    b = xs.DataArray(np.arange(6.0).reshape(2, 3) * 10, dims=['y', 'x'])
+    ds = xs.Dataset({'b4': a, 'b8': b}, attrs={'crs': 'EPSG:4326'})
+
+    def outcome(fn, *args, **kw):
+        try:
+            r = fn(*args, **kw)
+        except Exception as e:                                        # noqa: BLE001
+            return ("raise", type(e).__name__, str(e))
+        if isinstance(r, _xr.Dataset):
+            return ("dataset", dict(r.attrs), {k: (np.asarray(r[k].data).tolist(), r[k].name) for k in r.data_vars})
+        return ("array", np.asarray(r.data).tolist(), r.name)
+
+    for fn in (one, no_name):
+        m, r = mine.supports_dataset(fn), ref["supports_dataset"](fn)
+        assert m.__name__ == r.__name__ == fn.__name__
+        for args, kw in (((ds,), {}), ((ds, 3.0), {}), ((a,), {}), ((a,), {'name': 'x'} if fn is one else {'offset': 1.0}), ((ds,), {'bogus': 1})):
+            assert outcome(m, *args, **kw) == outcome(r, *args, **kw), (fn.__name__, kw)
+    m = mine.supports_dataset_bands(nir='nir_agg', red='red_agg')(bands)
+    r = ref["supports_dataset_bands"](nir='nir_agg', red='red_agg')(bands)
+    for args, kw in (((ds,), {'nir': 'b8', 'red': 'b4'}), ((ds,), {'nir': 'b8', 'red': 'b4', 'soil': 0.5, 'name': 'savi'}), ((ds,), {'nir': 'b8'}),
+                     ((ds,), {'nir': 'b8', 'red': 'b9'}), ((b, a), {}), ((b, a), {'soil': 2.0}), ((ds,), {'nir': 'b8', 'red': 'b4', 'bogus': 1})):
+        assert outcome(m, *args, **kw) == outcome(r, *args, **kw), kw

@@ -17,6 +17,10 @@ elif mode == "aligned":            # the region ends on a wave-tile boundary (co
     z[:, :5376] = np.nan
 elif mode == "rows":               # the top third
     z[: n // 3, :] = np.nan
+elif mode == "scatter5":           # 5 % of the cells, scattered: every tile is dense with nodata
+    synth.scatter_nodata(z, 0.05, 99)
+elif mode == "scatter1":           # 1 %
+    synth.scatter_nodata(z, 0.01, 99)
 A = xs.DataArray(xs.DeviceArray.from_numpy(z), dims=["y", "x"], attrs={"res": (1.0, 1.0)})
 k = circle_kernel(1, 1, 12)
 for _ in range(4):

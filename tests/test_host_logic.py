@@ -717,3 +717,12 @@ def test_dask_slot_runs_block_by_block(monkeypatch):
         xzonal.stats(zones, lazy(), return_type='xarray.DataArray')
     with pytest.raises(ValueError):
         xzonal.stats(xs.DataArray(fake_dask.from_array(zvals, (10, 20)), dims=['y', 'x']), lazy(), stats_funcs=seven)
+    # crosstab, 2-D values: per-block count tables added (zonal.py:813-916), then the same frame as the numpy backend
+    cats = ((np.arange(37)[:, None] * 7 + np.arange(53)[None, :] * 3) % 5 + 10).astype(np.float64)
+    cats[3, 4] = np.nan
+    lazy_cats = xs.DataArray(fake_dask.from_array(cats, (16, 20)), dims=['y', 'x'])
+    for kw in ({}, {'nodata_values': 12}, {'zone_ids': [0, 4, 99], 'cat_ids': [10, 14], 'agg': 'percentage'}):
+        got = xzonal.crosstab(zones, lazy_cats, **kw)
+        want = xzonal.crosstab(xs.DataArray(zvals, dims=['y', 'x']), xs.DataArray(cats, dims=['y', 'x']), **kw)
+        assert list(got.columns) == list(want.columns)
+        np.testing.assert_array_equal(got.to_numpy(dtype=np.float64), want.to_numpy(dtype=np.float64))

@@ -831,6 +831,46 @@ def _crosstab_2d_sharded(zones, values, zone_ids, cat_ids, nodata_values, agg):
     return _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_values, agg)
 
 
+def _crosstab_2d_dask(zones, values, zone_ids, cat_ids, nodata_values, agg):
+    """2-D crosstab of dask-backed rasters: the reference's `_crosstab_dask_numpy` (zonal.py:813-916) -- one table of
+    (zone, category) cell counts per block, the tables added, counts or percentages from the sum -- with the MI355X counting
+    every block (the crosstab kernel of the numpy and sharded backends) against ONE agreed list of zones and categories
+    (a first pass over the blocks collects them, as upstream's `np.unique(zones[...])` and `_find_cats` do).  One block in
+    HBM at a time; returns a pandas DataFrame (upstream: a dask DataFrame of one partition, wrapped when importable)."""
+    _lib.require_device()
+    stream = get_stream()
+    if tuple(zones.chunks) != tuple(values.chunks):
+        raise ValueError("zones and values must be chunked alike (zonal.py:906-907 pairs their blocks in order)")
+    nby, nbx = zones.numblocks
+
+    def finite_unique(b):
+        return np.unique(b[np.isfinite(b)]) if np.issubdtype(b.dtype, np.floating) else np.unique(b)
+    zb = [[np.asarray(zones.blocks[i, j].compute()) for j in range(nbx)] for i in range(nby)]
+    vb = [[np.asarray(values.blocks[i, j].compute()) for j in range(nbx)] for i in range(nby)]
+    unique_zones = np.unique(np.concatenate([finite_unique(b) for row in zb for b in row]))
+    all_cats = np.unique(np.concatenate([finite_unique(b) for row in vb for b in row]))
+    nz, nc = len(unique_zones), len(all_cats)
+    counts = np.zeros((nz, nc), dtype=np.uint64)
+
+    def dense(b, uniq):
+        ok = np.isfinite(b) if np.issubdtype(b.dtype, np.floating) else np.ones(b.shape, bool)
+        return np.ascontiguousarray(np.where(ok, np.searchsorted(uniq, np.where(ok, b, uniq[0])), -1).astype(np.int32))
+    if nz and nc:
+        for i in range(nby):
+            for j in range(nbx):
+                zidx, cidx = DeviceArray.from_numpy(dense(zb[i][j], unique_zones)), DeviceArray.from_numpy(dense(vb[i][j], all_cats))
+                cdev = DeviceArray((nz * nc,), np.uint64)
+                _lib.call("xrs_memset", cdev.ptr, 0, cdev.nbytes, stream)
+                _lib.call("xrs_crosstab_counts", zidx.ptr, cidx.ptr, zidx.size, nz, nc, cdev.ptr, stream)
+                counts += cdev.get(stream).reshape(nz, nc)
+    df = _crosstab_frame(unique_zones, all_cats, counts, zone_ids, cat_ids, nodata_values, agg)
+    try:                                                      # pragma: no cover (dask is not installable in the build image)
+        import dask.dataframe as dd
+        return dd.from_pandas(df, npartitions=1)
+    except ImportError:
+        return df
+
+
 def _crosstab_3d(zones_data, values_data, cat_labels, zone_ids, cat_ids, nodata_values, agg):
     # 3-D values: one layer per category, `agg` of the layer's values per zone (zonal.py:724-739)
     unique_zones, zidx = _dense_index_any(zones_data)
@@ -881,6 +921,8 @@ def crosstab(zones, values, zone_ids=None, cat_ids=None, layer=None, agg="count"
             raise ValueError("`agg` method for 2D data array must be one of following ['percentage', 'count']")
         if sharded:
             return _crosstab_2d_sharded(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
+        if is_dask(values.data):
+            return _crosstab_2d_dask(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
         return _crosstab_2d(zones.data, values.data, zone_ids, cat_ids, nodata_values, agg)
     if agg not in _DEFAULT_STATS:
         raise ValueError(f"`agg` method for 3D numpy backed data array must be one of following {list(_DEFAULT_STATS)}")

@@ -308,3 +308,30 @@ def test_16k_nodata_region_rim(variant):
     del dev, stats25, mean_alone
     from xrspatial_amd import device
     device.empty_cache()
+
+
+@pytest.mark.parametrize("kind,K", [("circle", 13), ("box", 25), ("circle", 25), ("annulus", 21)])
+def test_windows_whose_only_valid_cell_is_infinite(kind, K):
+    """A window with ONE valid cell has variance exactly 0 -- unless that cell is +-inf: numba's nanvar takes (inf - inf)^2 = NaN
+    (focal.py:282-289).  Mostly-nodata rasters with isolated finite and infinite cells, so that whole neighbourhoods of windows see
+    exactly one of them (found by tests/fuzz_parity.py seeds 61 / 63 once the large-window kernels judged windows one by one)."""
+    from xrspatial_amd.convolution import annulus_kernel, circle_kernel
+    R = K // 2
+    k = circle_kernel(1, 1, R) if kind == "circle" else np.ones((K, K)) if kind == "box" else annulus_kernel(1, 1, R, 4)
+    z = np.full((300, 520), np.nan, np.float32)
+    z[60, 70], z[60, 300], z[200, 130], z[210, 420] = np.inf, 7.5, -np.inf, 1234.5
+    z[120:124, 200:204] = 3.25                                    # a few equal finite cells: variance 0
+    z[250:, 450:] = synth.smooth_dem((50, 70), seed=3)            # and an ordinary corner
+    z[270, 480] = np.inf
+    got = focal_stats(xs.DataArray(z, dims=['y', 'x']), k).data
+    with np.errstate(all='ignore'):
+        for i, stat in enumerate(orc.FOCAL_STATS):
+            want = corc.focal_apply(z, k, stat, nthreads=8)
+            np.testing.assert_array_equal(np.isnan(got[i]), np.isnan(want), err_msg=f"{kind}{K} {stat}: NaN pattern")
+            fin = np.isfinite(want)
+            np.testing.assert_array_equal(got[i][~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)], err_msg=f"{kind}{K} {stat}: infinities")
+            if stat in ('max', 'min', 'range'):
+                np.testing.assert_array_equal(got[i][fin], want[fin], err_msg=f"{kind}{K} {stat}")
+            else:
+                np.testing.assert_allclose(got[i][fin], want[fin], rtol=RTOL, atol=1e-6 if stat in ('var', 'std') else 0, err_msg=f"{kind}{K} {stat}")
+    assert np.isnan(got[list(orc.FOCAL_STATS).index('var')][60, 70 - R // 2])        # the single +inf under that window

@@ -290,7 +290,10 @@ struct MomWalkN {
                 mean = c + ms;
                 sum = fmaf(n, c, S);
                 if (HAVE_Q) {
-                    const float e = n == 1.0f ? 0.0f : Q - S * ms;      // (one valid cell: variance exactly 0, whatever the shift)
+                    // (one valid cell: variance exactly 0, whatever the shift -- unless that cell is +-inf: the reference's nanvar
+                    //  takes (inf - inf)^2 = NaN there; until round 6 a neighbouring window with n > 1 failed its guard and sent the
+                    //  whole tile to the exact walker, which masked it; the differential fuzzer found it once windows stood alone)
+                    const float e = n == 1.0f ? mean - mean : Q - S * ms;
                     const float B = Q + n * dqm;
                     bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
                     var = e / n;

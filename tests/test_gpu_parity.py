@@ -471,6 +471,48 @@ def test_wide_row_walker_paths():
         np.testing.assert_allclose(o_mean.get(), want[first:first + n], rtol=1e-6)
 
 
+def test_annuli_of_radius_11_on_interior_tiles():
+    """annulus_kernel(1, 1, 11, ri): the one moments instantiation whose staged row (64 + 22 = 86 cells, one column per lane) is
+    not a whole number of 16-byte LDS-DMA pieces.  Until round 6 the piece count was rounded down, the last two cells of every
+    row kept what the ring slot held before, and the last two columns of every INTERIOR 64-column tile (lanes 62 and 63) came
+    out with mean off by up to 5e-3 and var by 50 % -- on rasters of two tile rows or more only, which no test had for this
+    radius (tests/fuzz_parity.py --windows found it)."""
+    z = synth.asv_dem(393, 900)
+    for ri in (1, 5, 8, 10):
+        k = annulus_kernel(1, 1, 11, ri)
+        got = focal_stats(raster(z), k, stats_funcs=['mean', 'var', 'std', 'sum']).data
+        for i, st in enumerate(('mean', 'var', 'std')):
+            want = corc.focal_apply(z, k, st, nthreads=8)
+            np.testing.assert_allclose(got[i], want, rtol=5e-6 if st == 'var' else 2.5e-6, equal_nan=True, err_msg=f"annulus 11/{ri} {st}")
+            parity_log.record('393x900', f'annulus 11/{ri} {st}', got[i], want)
+        check_window_sum(got[3], z, k, f"annulus 11/{ri} sum")
+
+
+@pytest.mark.parametrize("kind,radius", [("box", 11), ("circle", 11), ("box", 10), ("circle", 12), ("box", 12), ("circle", 6)])
+def test_cliff_one_column_beside_a_window(kind, radius):
+    """A plateau 1e5 below (or 1e7 above) the ground, its last column ONE column outside a window: no tap of the window, nothing
+    in its Q -- and until round 6 in the lane-local prefix sums its runs were cut from (mom_impl.h; the float64 prefix of
+    boxsep.hip likewise at 1e7): var off by up to 5 %, mean by 1e-4, in windows whose guard had nothing to object to, on
+    interior and bottom-edge tiles alike.  The walkers now sum every run from the window's centre outwards (its own cells
+    only), and the separable box walk hands a tile on when a box sum is lost in the prefix it was cut from."""
+    K = 2 * radius + 1
+    k = circle_kernel(1, 1, radius) if kind == "circle" else np.ones((K, K))
+    for offset, rows in ((-1e5, 262), (1e7, 393), (3000.0, 300)):
+        z = synth.asv_dem(rows, 640).copy()
+        z[:, :130] += np.float32(offset)             # windows centred on column 130 + radius .. do not hold the plateau
+        z[:, 400:] += np.float32(offset)             # ... nor do those up to column 399 - radius (the cliff to their right)
+        got = focal_stats(raster(z), k, stats_funcs=['mean', 'var', 'std']).data
+        clear = (slice(None), slice(130 + radius, 400 - radius))
+        for i, st in enumerate(('mean', 'var', 'std')):
+            want = corc.focal_apply(z, k, st, nthreads=8)
+            # beside the cliff: the tolerances of ordinary relief
+            np.testing.assert_allclose(got[i][clear], want[clear], rtol=5e-6 if st == 'var' else 2.5e-6,
+                                       err_msg=f"{kind} {K} cliff {offset:g} {st} beside the cliff")
+            # across it (windows that hold both levels): the contract
+            np.testing.assert_allclose(got[i], want, rtol=1e-5, equal_nan=True, err_msg=f"{kind} {K} cliff {offset:g} {st}")
+            parity_log.record(f'{rows}x640', f'cliff {offset:g} {kind}{K} {st}', got[i], want)
+
+
 def test_third_generation_walkers_interior_and_rim_tiles():
     """The round-3 large-window kernels (mom_impl.h: float32 moments about a shift that trails the walk, guarded;
     ext_impl.h: extrema with two input rows per ring operation) on rasters of several tiles in both directions -- most

@@ -11,7 +11,7 @@ import subprocess
 import sys
 import tempfile
 
-CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xrspatial_amd", "csrc")
+CSRC = os.environ.get("XRS_CSRC") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xrspatial_amd", "csrc")   # XRS_CSRC: another checkout
 
 
 def main():

@@ -156,7 +156,7 @@ struct BoxWalk {
     // that every access is one float64 per lane at an 8-byte lane stride: conflict free (interleaved, the two float64 of a
     // lane sat 16 bytes apart and every LDS access was a 2-way bank conflict: 46 % of the LDS cycles).
     template <int N>
-    __device__ __forceinline__ void across_n(const double (&C)[N][NC], double *pp, double (&B)[N][NC]) const {
+    __device__ __forceinline__ void across_n(const double (&C)[N][NC], double *pp, double (&B)[N][NC], double (&H)[N][NC]) const {
         static_assert(NC == 2, "prefix layout by column parity");
         double tot[N];
 #pragma unroll
@@ -180,8 +180,10 @@ struct BoxWalk {
         for (int i = 0; i < N; ++i) {
             const double *p = pp + i * G::PSLOTS;
             // output o = 0: columns 2 lc + 2 rx (even) minus 2 lc - 1 (odd; slot 0 for lc = 0);  o = 1: 2 lc + 1 + 2 rx (odd) minus 2 lc (even)
-            B[i][0] = p[G::PEVEN + lc + rx] - p[lc];
-            B[i][1] = p[1 + lc + rx] - p[G::PEVEN + lc];
+            H[i][0] = p[G::PEVEN + lc + rx];                            // (the prefix a box sum was cut from: finish()'s guard)
+            H[i][1] = p[1 + lc + rx];
+            B[i][0] = H[i][0] - p[lc];
+            B[i][1] = H[i][1] - p[G::PEVEN + lc];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                                // (the next step's writes come after these reads)
@@ -189,34 +191,34 @@ struct BoxWalk {
 
     // one output row from the column sums (S, QQ)
     __device__ __forceinline__ void emit(long yo, const double (&S)[NC], const double (&QQ)[NC]) {
-        double C[Q ? 2 : 1][NC], B[Q ? 2 : 1][NC];
+        double C[Q ? 2 : 1][NC], B[Q ? 2 : 1][NC], H[Q ? 2 : 1][NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) { C[0][j] = S[j]; if (Q) C[Q ? 1 : 0][j] = QQ[j]; }
-        across_n<Q ? 2 : 1>(C, p1, B);
+        across_n<Q ? 2 : 1>(C, p1, B, H);
         double zero[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) zero[j] = 0.0;
-        finish(yo, B[0], Q ? B[Q ? 1 : 0] : zero);
+        finish(yo, B[0], Q ? B[Q ? 1 : 0] : zero, Q ? H[Q ? 1 : 0] : zero);
     }
     // two output rows (yo from Sa / Qa, yo + 1 from Sb / Qb): all their scans step by step together
     __device__ __forceinline__ void emit2(long yo, const double (&Sa)[NC], const double (&Qa)[NC], const double (&Sb)[NC],
                                           const double (&Qb)[NC]) {
         constexpr int N = Q ? 4 : 2;
-        double C[N][NC], B[N][NC];
+        double C[N][NC], B[N][NC], H[N][NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             C[0][j] = Sa[j]; C[1][j] = Sb[j];
             if (Q) { C[Q ? 2 : 0][j] = Qa[j]; C[Q ? 3 : 1][j] = Qb[j]; }
         }
-        across_n<N>(C, p1, B);
+        across_n<N>(C, p1, B, H);
         double zero[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) zero[j] = 0.0;
-        finish(yo, B[0], Q ? B[Q ? 2 : 0] : zero);
-        finish(yo + 1, B[1], Q ? B[Q ? 3 : 1] : zero);
+        finish(yo, B[0], Q ? B[Q ? 2 : 0] : zero, Q ? H[Q ? 2 : 0] : zero);
+        finish(yo + 1, B[1], Q ? B[Q ? 3 : 1] : zero, Q ? H[Q ? 3 : 1] : zero);
     }
 
-    __device__ __forceinline__ void finish(long yo, const double (&B1)[NC], const double (&B2)[NC]) {
+    __device__ __forceinline__ void finish(long yo, const double (&B1)[NC], const double (&B2)[NC], const double (&H2)[NC]) {
         const bool out_lane = NC * lane < a.w_out;
         const long xo = x_out0 + NC * lane;
         float r_sum[NC], r_mean[NC], r_var[NC], r_std[NC];
@@ -253,6 +255,11 @@ struct BoxWalk {
                 // residual can be: below 2^-26 of it (a few hundred residuals: 2^-22 relative on e) the tile is handed on.
                 q_peak[o] = fmax(q_peak[o], B2[o]);
                 bad |= !(e >= 0x1p-24 * B2[o]) || !(e >= 0x1p-26 * q_peak[o]);     // (a NaN / inf anywhere fails it too)
+                // ... and the box sum was the difference of two wave-wide PREFIX sums, which also hold every column to the LEFT of
+                // the window: a plateau 1e7 above the shift there (d^2 = 1e14 a cell) is in no window of this lane and still
+                // leaves 2^-53 of itself in B2 -- var off by 4e-5 next to such a cliff until round 6 (tests/fuzz_parity.py
+                // --windows).  Below 2^-27 of the prefix it was cut from (a few roundings: 2^-25 relative on e) the tile is handed on.
+                bad |= !(e >= 0x1p-27 * H2[o]);
                 const double var = e * inv;
                 r_var[o] = (float)var;
                 r_std[o] = __builtin_amdgcn_sqrtf((float)var);               // (v_sqrt_f32: 1 ulp; sqrtf's fix-up costs 8 instructions per cell)

@@ -142,7 +142,10 @@ struct MomWalk {
         const float *p = uniform_ptr(dma_src);
         dma_src += dma_adv > 0 ? g.ld_in : 0;
         --dma_adv;
-        constexpr int QMAX = C::CELLS / 4 - 1;
+        // (whole 16-byte pieces: CELLS = 86 -- one column per lane, radius 11: the annuli of kxk_mom_ann11.hip -- is not a multiple
+        //  of four; until round 6 the count was rounded DOWN there and the row's last two cells, which only lanes 62 and 63
+        //  read, kept whatever the ring slot held before.  tests/fuzz_parity.py --windows found it.)
+        constexpr int QMAX = C::CELLS_DMA / 4 - 1;
         // (CARRY: the lane's DMA offset computed afresh per row -- four instructions -- instead of living in a register the
         // carrying walk does not have: radius 12 with four planes spilled exactly one)
         int ln = lane;
@@ -322,11 +325,22 @@ struct MomWalk {
                 w[NC * b + e] = SQ ? d * d : d;
             }
         }
-        float w0[NC];                                         // the centre cells themselves (half-width 0)
+        // Running sums FROM THE CENTRE OUTWARDS: w[j] = cells j .. HL for j <= HL, cells HL+1 .. j for j > HL, so that the centred
+        // run of half-width h under owned column o is w[HL+o-h] + w[HL+o+h] -- a sum over the run's own cells and nothing else.
+        // (Until round 6: one prefix sum from the left, a run = the difference of two prefixes.  A prefix also holds the cells
+        // to the LEFT of the run, and a cell far from the shift there -- the last column of a plateau 1e5 above the window, a lake
+        // at 1.6e7 -- is in no row of the window, adds nothing to its Q, and still left ~u |prefix| of rounding in each of the
+        // window's ~NV K additions and subtractions: var off by up to 5 %, mean by 1e-4, with the guard none the wiser -- the
+        // windows that DO contain the far cell pass it honestly, their variance is large.  tests/fuzz_parity.py --windows,
+        // cliffs one column outside a window.  Same number of additions, no subtraction, and nothing to guard.)
+        static_assert(NC <= 2, "two chains serve the centres HL and HL + 1");
 #pragma unroll
-        for (int o = 0; o < NC; ++o) w0[o] = w[HL + o];
+        for (int j = HL - 1; j >= 0; --j) w[j] += w[j + 1];
 #pragma unroll
-        for (int k = 1; k < NV; ++k) w[k] += w[k - 1];
+        for (int j = HL + 2; j < NV; ++j) w[j] += w[j - 1];
+        auto run_sum = [&](int h, int o) -> float {            // (static h, o; h = 0: the centre cell itself, both chains start there)
+            return h == 0 ? w[HL + o] : w[HL + o - h] + w[HL + o + h];
+        };
         if constexpr (!shape_has_hole<Shape>(R)) {
             // every distinct half-width once, into the ring slots of the output rows that see this row with it
 #pragma unroll
@@ -334,10 +348,7 @@ struct MomWalk {
                 if (!C::level_used(h)) continue;
                 float S[NC];
 #pragma unroll
-                for (int o = 0; o < NC; ++o) {
-                    const int hi = HL + o + h, lo = HL + o - h - 1;
-                    S[o] = h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
-                }
+                for (int o = 0; o < NC; ++o) S[o] = run_sum(h, o);
                 if (!EDGE && !SQ && h == R) c_next = PHASE == 0 ? S[0] : c_next + S[0];       // (hw(0) == R for every shape)
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -355,10 +366,8 @@ struct MomWalk {
             // a shape with a hole (annuli): every distinct ROW PATTERN once -- the centred run of half-width hw minus the one of
             // half-width hwi -- through compile-time tables (ShapeRows: evaluated once, not per loop iteration)
             constexpr ShapeRows<R, Shape> T{};
-            auto run = [&](int h, int o) -> float {          // the centred run of half-width h under owned column o (static h, o)
-                const int hi = HL + o + h, lo = HL + o - h - 1;
-                return h == 0 ? w0[o] : lo >= 0 ? w[hi] - w[lo] : w[hi];
-            };
+            // (the hole's cells are still under both runs of a row pattern: a far cell INSIDE the hole reaches the sums)
+            auto run = [&](int h, int o) -> float { return run_sum(h, o); };
             if (!EDGE && !SQ) {                                // (the widest run is nobody's level here: its own subtraction)
                 const float W = run(R, 0);
                 c_next = PHASE == 0 ? W : c_next + W;
@@ -659,7 +668,7 @@ __global__ void __launch_bounds__(256, XRS_MOM_WAVES) focal_mom_kernel(const Mom
     const WalkGeom &g = a.g;
     if (x_tile >= g.cols) return;
     const long y_end = y0 + a.tile_rows < g.rows ? y0 + a.tile_rows : g.rows;
-    const bool interior = x_tile - C::HL >= 0 && x_tile + C::TW + C::HL <= g.cols && y0 - R >= -(long)g.halo_top &&
+    const bool interior = x_tile - C::HL >= 0 && x_tile - C::HL + C::CELLS_DMA <= g.cols && y0 - R >= -(long)g.halo_top &&
                           y_end + R <= g.rows + g.halo_bot && y_end - y0 == a.tile_rows;
     if (interior) {
         MomWalk<R, Shape, OM, false> w(a, lds_rows[wv], x_tile, y0, y_end, lane);

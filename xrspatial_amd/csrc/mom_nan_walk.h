@@ -39,7 +39,8 @@ struct MomCfg {
     static constexpr int NV = NC + 2 * HL;                 // cells a lane reads back per row
     static constexpr int NQ = NV / NC;
     static constexpr int CELLS = TW + 2 * HL;
-    static_assert(CELLS <= 256, "one 16-byte DMA per row");
+    static constexpr int CELLS_DMA = (CELLS + 3) / 4 * 4;  // ... as the LDS-DMA moves them: 16 bytes per lane (interior tiles have them all)
+    static_assert(CELLS_DMA <= 256, "one 16-byte DMA per row");
     static constexpr int NTAPS = shape_taps<Shape>(R);
 #ifndef XRS_MOM_U
 #define XRS_MOM_U 5
@@ -200,14 +201,17 @@ struct MomWalkN {
             const float w = fmaf(-c, f[k], z[k]);
             p[k] = WHAT == 1 ? w : w * w;
         }
-        const float p0 = p[R];
+        // running sums from the centre outwards (mom_impl.h, moment_pass: a run = the sum of ITS cells, nothing beside it)
 #pragma unroll
-        for (int k = 1; k < K; ++k) p[k] += p[k - 1];
+        for (int j = R - 1; j >= 0; --j) p[j] += p[j + 1];
+#pragma unroll
+        for (int j = R + 2; j < K; ++j) p[j] += p[j - 1];
+        auto run_sum = [&](int h) -> float { return h == 0 ? p[R] : p[R - h] + p[R + h]; };
         if constexpr (!shape_has_hole<Shape>(R)) {
 #pragma unroll
             for (int h = 0; h <= R; ++h) {
                 if (!C::level_used(h)) continue;
-                const float S = h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
+                const float S = run_sum(h);
                 if (h == R) {                                  // (hw(0) == R for every shape)
                     if (WHAT == 0) snapN += S;
                     if (WHAT == 1) snapS += S;
@@ -225,9 +229,7 @@ struct MomWalkN {
         } else {
             // a shape with a hole (annuli): every distinct row pattern once, run(hw) - run(hwi) (compile-time tables)
             constexpr ShapeRows<R, Shape> T{};
-            auto run = [&](int h) -> float {                 // the centred run of half-width h (static h)
-                return h == 0 ? p0 : (R - h - 1 >= 0 ? p[R + h] - p[R - h - 1] : p[R + h]);
-            };
+            auto run = [&](int h) -> float { return run_sum(h); };      // the centred run of half-width h (static h)
             {                                                  // the widest run: the shift's next estimate
                 const float W = run(R);
                 if (WHAT == 0) snapN += W;
@@ -298,14 +300,14 @@ struct MomWalkN {
                     bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
                     var = e / n;
                     sd = sqrtf(var);
-                    if (fix_list) {
-                        // A window judged on its own (not tile by tile) must also answer for what its guard cannot see: a cell far
-                        // from the shift -- a cliff, a block of 1.6e7 next to relief around 2000 -- sits in the lane-local PREFIX sums
-                        // of windows that do not contain it (to the left of their runs), and the difference of two prefixes of size A
-                        // carries a rounding of ~u A per term whatever the window itself holds.  ~sqrt(1.5 n) such terms behave like a
-                        // random walk: accepted while that stays under 2e-6 of n |mean| (sum, mean) and of n var (squares: A^2).
-                        // (Without a fix list the tile-wide all-or-nothing rule covers this: the far cell lies INSIDE some window of
-                        // the tile, which fails.)
+                    if (fix_list && shape_has_hole<Shape>(R)) {
+                        // Annuli: a row that crosses the hole is the difference of two centred runs, and the hole's cells are under
+                        // both: a cell far from the shift there -- a spike at the very centre of the ring -- is in no tap of the window,
+                        // adds nothing to its Q, and leaves ~u A of rounding per term whatever the window itself holds.  ~sqrt(1.5 n)
+                        // such terms behave like a random walk: accepted while that stays under 2e-6 of n |mean| (sum, mean) and of
+                        // n var (squares: A^2); A = the largest |v - c| staged in the rounds under the window (wave-wide: coarse).
+                        // (Solid shapes needed this too while a run was the difference of two PREFIX sums, which also hold the cells
+                        // left of the run; since pass() sums from the centre outwards a run holds its own cells only.)
                         const float lim = 28.0f * sqrtf(n);        // 2e-6 / (1.2 u), u = 2^-24
                         bad = bad || !(a_span <= lim * fabsf(mean)) || (n != 1.0f && !(a_span * a_span <= lim * var));
                     }
@@ -371,7 +373,7 @@ struct MomWalkN {
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (load_row(t + P, pf_own[P], pf_halo[P]), ...);
         if (!seeded) first_shift();
-        if (fix_list) {                                        // (the rows of this round, before any of them is summed)
+        if (fix_list && shape_has_hole<Shape>(R)) {            // (the rows of this round, before any of them is summed)
             float m = 0.0f;
 #pragma unroll
             for (int r = 0; r < U; ++r) {

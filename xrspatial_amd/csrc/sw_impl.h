@@ -122,6 +122,7 @@ struct SwWalk {
         dma_src += dma_adv > 0 ? g.ld_in : 0;
         --dma_adv;
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
+        static_assert(C::CELLS % 4 == 0, "whole 16-byte pieces");
         constexpr int QMAX = (C::CELLS < 256 ? C::CELLS : 256) / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), dst);
         if (C::CELLS > 256) glds4_s(p, 4u * (unsigned)(256 + (lane < C::CELLS - 257 ? lane : C::CELLS - 257)), dst + 1024);

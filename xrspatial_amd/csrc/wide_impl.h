@@ -287,6 +287,7 @@ struct WideWalk {
         dma_src += dma_adv > 0 ? g.ld_in : 0;
         --dma_adv;
         const unsigned dst = ring_addr + (unsigned)slot * (C::RBF * 4);
+        static_assert(CELLS % 4 == 0, "whole 16-byte pieces");
         constexpr int QMAX = (CELLS < 256 ? CELLS : 256) / 4 - 1;
         glds16_s(p, 16u * (unsigned)(lane < QMAX ? lane : QMAX), dst);
         if (CELLS > 256) glds4_s(p, 4u * (unsigned)(256 + (lane < CELLS - 257 ? lane : CELLS - 257)), dst + 1024);

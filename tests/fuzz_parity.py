@@ -59,7 +59,7 @@ def make_raster(rng, shape, dtype, allow_nan=True):
     if allow_nan and WINDOWS:
         rows, cols = shape
         for _ in range(int(rng.integers(1, 4))):
-            kind = rng.choice(["rows", "cols", "ragged", "block", "scatter", "sparse", "lake", "cliff", "inf", "none"])
+            kind = rng.choice(["rows", "cols", "ragged", "block", "scatter", "sparse", "lake", "cliff", "inf", "spike", "none"])
             if kind == "rows":
                 a = int(rng.integers(0, rows)); z[a:a + int(rng.integers(1, rows)), :] = np.nan
             elif kind == "cols":
@@ -82,6 +82,9 @@ def make_raster(rng, shape, dtype, allow_nan=True):
                 z[a:a + int(rng.integers(5, 90)), b:b + int(rng.integers(5, 200))] = dtype.type(rng.choice([0.0, 777.25, 1234.567, -5.25, 16777217.0, 3.3e-5]))
             elif kind == "cliff":
                 a = int(rng.integers(0, cols)); z[:, a:] += dtype.type(rng.choice([50.0, 3000.0, -1e5, 1e7]))
+            elif kind == "spike":                        # unmasked sentinels / hot pixels: single cells far from everything around them
+                for _i in range(int(rng.integers(1, 30))):
+                    z.flat[rng.integers(0, z.size)] = dtype.type(rng.choice([-32768.0, -9999.0, 1.0e6, 65535.0]))
             elif kind == "inf":
                 for _i in range(int(rng.integers(1, 4))):
                     z.flat[rng.integers(0, z.size)] = rng.choice([np.inf, -np.inf])

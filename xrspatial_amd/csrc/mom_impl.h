@@ -83,11 +83,27 @@ struct MomWalk {
     __device__ __forceinline__ bool want(int bit, const float *p) const { return OM ? (OM & bit) != 0 : p != nullptr; }
     using C = MomCfg<R, Shape>;
     static constexpr int K = C::K, HL = C::HL, NV = C::NV, NQ = C::NQ, U = C::U, NC = C::NC, TW = C::TW, D = C::D;
+    // Annuli.  A row that crosses the hole is the difference of two centred runs, and the hole's cells are under both: a cell far
+    // from the shift THERE -- a spike at the very centre of the ring, an unmasked -32768 -- is no tap of the window, adds nothing
+    // to its Q, and leaves ~u |its square| of rounding in each of the ~4 (2 RI + 1) additions and subtractions of the rows that
+    // cross the hole (a random walk: its root).  hk bounds the hole's rows still under a window (their widest: the row through
+    // the centre; a maximum decaying by 0.93 per round, >= 0.7 while the row matters); accepted while that random walk stays
+    // below 3e-6 of n var and 2e-6 of n |mean|.  On ordinary relief hk ~ (2 RI + 1) sigma^2: far from binding.  (Solid shapes
+    // have no such cells since a run is summed from the centre outwards, moment_pass.)
+    static constexpr bool HOLE = shape_has_hole<Shape>(R);
+    static constexpr int HOLE_HW = HOLE ? Shape::hwi(R, 0) : 0;
+    static constexpr float HK_OPS = 4.0f * (float)(2 * HOLE_HW + 1);
+    static constexpr float HK_DECAY = 0.93f;
+    static constexpr float HK_VAR = 0.0284f * const_sqrt(HK_OPS);   // 2^-24 / (3e-6 x 0.7) x sqrt(ops)
+    static constexpr float HK_MEAN = 1.27e-3f * HK_OPS;             // (2^-24 / 2e-6)^2 / 0.7 x ops
+    // HK_MEAN if the mean or the sum is wanted, else 0 (from gm: no register of its own)
+    __device__ __forceinline__ float gh() const { return gm * ((float)C::NTAPS * HK_MEAN / 0.04f); }
 
     float accS[K][NC], accQ[K][NC];
     float c, c_next;               // the lane's shift; sum of the round's widest runs about it (-> its successor)
     float dq_last, dq_old;         // d^2 of the last re-centring; decaying maximum of the older ones
     float dqn;                     // NTAPS * max of both: what the re-centrings added to the partial sums of squares
+    float hk;                      // (annuli) decaying maximum of the sums of (v - c)^2 over the cells of the hole's widest row, see HK_VAR
     int slot_in, slot_out;
     unsigned ring_addr;
     float pf_own[EDGE ? U : 1][NC], pf_halo[EDGE ? U : 1];     // EDGE: the rows of the current round, loaded up front
@@ -159,6 +175,7 @@ struct MomWalk {
 #pragma unroll
             for (int o = 0; o < NC; ++o) { accS[j][o] = 0.0f; accQ[j][o] = 0.0f; }
         dq_last = dq_old = dqn = 0.0f;
+        hk = 0.0f;
         badm = 0;
         gm = (want(MOM_MEAN, a.out_mean) || want(MOM_SUM, a.out_sum)) ? 0.04f / (float)C::NTAPS : 0.0f;
         t = 0;
@@ -368,6 +385,7 @@ struct MomWalk {
             constexpr ShapeRows<R, Shape> T{};
             // (the hole's cells are still under both runs of a row pattern: a far cell INSIDE the hole reaches the sums)
             auto run = [&](int h, int o) -> float { return run_sum(h, o); };
+            if (SQ) hk = fmaxf(hk, NC == 1 ? run(HOLE_HW, 0) : run(HOLE_HW, 0) + run(HOLE_HW, NC - 1));
             if (!EDGE && !SQ) {                                // (the widest run is nobody's level here: its own subtraction)
                 const float W = run(R, 0);
                 c_next = PHASE == 0 ? W : c_next + W;
@@ -489,6 +507,7 @@ struct MomWalk {
                 const bool live = xo + o < g.cols;
                 badm |= __builtin_amdgcn_ballot_w64(live && !(e >= 0.2f * Q));
                 badm |= __builtin_amdgcn_ballot_w64(live && !(mean * mean * n >= (gm * (float)C::NTAPS) * Q));
+                if (HOLE) badm |= __builtin_amdgcn_ballot_w64(live && (!(e >= HK_VAR * hk) || !((mean * n) * (mean * n) >= gh() * hk)));
                 const float var = e / n;
                 if (live) {
                     const long off = yo * g.ld_out + xo + o;
@@ -548,6 +567,7 @@ struct MomWalk {
                 // (ballots: the verdicts stay in scalar registers)
                 badm |= __builtin_amdgcn_ballot_w64(!(e >= 0.2f * B));
                 badm |= __builtin_amdgcn_ballot_w64(!(mean * mean >= gm * B));
+                if (HOLE) badm |= __builtin_amdgcn_ballot_w64(!(e >= HK_VAR * hk) || !(mean * mean >= (gh() * inv * inv) * hk));
                 const float var = e * inv;
                 r_mean[o] = mean;
                 r_var[o] = var;
@@ -612,6 +632,7 @@ struct MomWalk {
         ring_rotate<K, U>(accS);
         ring_rotate<K, U>(accQ);
         t += U;
+        if (HOLE) hk *= HK_DECAY;
 #ifndef XRS_MOM_T_NORECENTRE
         if (!EDGE && !NANOK) recentre(std::make_integer_sequence<int, K>{});
 #endif

@@ -27,6 +27,12 @@ struct MomArgs {
 };
 
 
+constexpr float const_sqrt(float x) {                      // (compile-time constants only)
+    float r = x > 1.0f ? x : 1.0f;
+    for (int i = 0; i < 40; ++i) r = 0.5f * (r + x / r);
+    return r;
+}
+
 template <int R, typename Shape>
 struct MomCfg {
     static constexpr int K = 2 * R + 1;
@@ -300,7 +306,7 @@ struct MomWalkN {
                     bad = (n != 1.0f && !(e >= 0.2f * B)) || !(mean * mean * n >= gmf * B);
                     var = e / n;
                     sd = sqrtf(var);
-                    if (fix_list && shape_has_hole<Shape>(R)) {
+                    if (shape_has_hole<Shape>(R)) {
                         // Annuli: a row that crosses the hole is the difference of two centred runs, and the hole's cells are under
                         // both: a cell far from the shift there -- a spike at the very centre of the ring -- is in no tap of the window,
                         // adds nothing to its Q, and leaves ~u A of rounding per term whatever the window itself holds.  ~sqrt(1.5 n)
@@ -373,7 +379,7 @@ struct MomWalkN {
     __device__ __forceinline__ void round(std::integer_sequence<int, P...>) {
         (load_row(t + P, pf_own[P], pf_halo[P]), ...);
         if (!seeded) first_shift();
-        if (fix_list && shape_has_hole<Shape>(R)) {            // (the rows of this round, before any of them is summed)
+        if (HAVE_Q && shape_has_hole<Shape>(R)) {              // (the rows of this round, before any of them is summed)
             float m = 0.0f;
 #pragma unroll
             for (int r = 0; r < U; ++r) {

@@ -37,11 +37,14 @@ WINDOWS = False # --windows: only focal.apply / focal_stats with 9x9 .. 25x25 ci
                 # densities, isolated valid cells inside nodata, +-inf, cliffs and lakes): the large-window walkers' cascade
 
 
+STRUCTURED = False  # --structured: EVERY operator on the rasters of --windows (several tiles of every kernel family; regions, cliffs, lakes ...)
+
+
 def pick_shape(rng, max_cells):
-    if WINDOWS:
-        return int(rng.choice([131, 262, 300, 393, 450, 560])), int(rng.choice([128, 256, 300, 512, 640, 900, 1330]))
     if BIG:
         return int(rng.integers(2100, 4200)), int(rng.choice([2048, 2052, 3000, 3601, 4096, 4100]))
+    if WINDOWS or STRUCTURED:
+        return int(rng.choice([131, 262, 300, 393, 450, 560])), int(rng.choice([128, 256, 300, 512, 640, 900, 1330]))
     special = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 259, 511, 513, 1023, 1025, 1030]
     while True:
         rows = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 700))
@@ -56,7 +59,7 @@ def make_raster(rng, shape, dtype, allow_nan=True):
     if np.issubdtype(dtype, np.integer):
         return np.clip(z, 0, np.iinfo(dtype).max).astype(dtype)
     z = z.astype(dtype)
-    if allow_nan and WINDOWS:
+    if allow_nan and (WINDOWS or STRUCTURED):
         rows, cols = shape
         for _ in range(int(rng.integers(1, 4))):
             kind = rng.choice(["rows", "cols", "ragged", "block", "scatter", "sparse", "lake", "cliff", "inf", "spike", "none"])
@@ -332,9 +335,10 @@ def main():
     ap.add_argument("--max-cells", type=int, default=400000)
     ap.add_argument("--big", action="store_true", help="8-17 Mcell rasters: the banded host pipelines")
     ap.add_argument("--windows", action="store_true", help="large-window statistics on rasters with nodata regions / cliffs / inf")
+    ap.add_argument("--structured", action="store_true", help="every operator on the rasters of --windows")
     args = ap.parse_args()
-    global BIG, WINDOWS
-    BIG, WINDOWS = args.big, args.windows
+    global BIG, WINDOWS, STRUCTURED
+    BIG, WINDOWS, STRUCTURED = args.big, args.windows, args.structured
     rng = np.random.default_rng(args.seed)
     fails = 0
     counts = {}

@@ -169,6 +169,27 @@ def test_fuzz_smoke():
     assert not fails, "\n".join(fails[:10])
 
 
+@pytest.mark.parametrize("mode,cases", [("WINDOWS", 120), ("STRUCTURED", 300)])
+def test_fuzz_smoke_structured_rasters(mode, cases):
+    """The fuzzer's two modes on rasters of several tiles that carry nodata the way real rasters do -- regions with straight and
+    ragged rims, scatter at densities 1e-4 .. 0.9, isolated valid cells, lakes, cliffs to 1e7, spikes, +-inf: `--windows` (9x9 ..
+    25x25 circles, boxes, annuli; single statistics, all seven, random subsets: ~40 s) and `--structured` (every operator, ~10 s).
+    The first 1 200 `--windows` cases found three defects of the large-window kernels; longer runs under profiles/."""
+    from tests import fuzz_parity
+    setattr(fuzz_parity, mode, True)
+    try:
+        rng = np.random.default_rng(20250930)
+        fails = []
+        for i in range(cases):
+            sub = np.random.default_rng(rng.integers(0, 2 ** 62))
+            desc, err = fuzz_parity.one_case(sub, 10 ** 9)
+            if err:
+                fails.append(f"[{i}] {desc}: {err}")
+        assert not fails, "\n".join(fails[:10])
+    finally:
+        setattr(fuzz_parity, mode, False)
+
+
 @pytest.mark.parametrize("kind,radius", [("circle", 12), ("circle", 6), ("circle", 3), ("box", 12), ("box", 5)])
 def test_large_window_mean_sum_carry_nodata(kind, radius):
     """The large-window mean / sum on rasters with nodata (wide_impl.h: a tile whose plain walk meets a NaN is walked again by

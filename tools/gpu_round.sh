@@ -49,7 +49,9 @@ for s in $STEPS; do
       for seed in 51 52; do timeout 600 python tests/fuzz_parity.py --seed $seed --cases 1500 > $OUT/fuzz_s$seed.log 2>&1; tail -3 $OUT/fuzz_s$seed.log; done
       timeout 600 python tests/fuzz_parity.py --seed 53 --cases 40 --big > $OUT/fuzz_big.log 2>&1; tail -3 $OUT/fuzz_big.log
       # large windows on rasters with nodata regions, cliffs, lakes, spikes, +-inf (the large-window walkers' whole cascade)
-      for seed in 61 62 63 64; do timeout 600 python tests/fuzz_parity.py --windows --seed $seed --cases 500 > $OUT/fuzz_win_s$seed.log 2>&1; tail -2 $OUT/fuzz_win_s$seed.log; done ;;
+      for seed in 61 62 63 64; do timeout 600 python tests/fuzz_parity.py --windows --seed $seed --cases 500 > $OUT/fuzz_win_s$seed.log 2>&1; tail -2 $OUT/fuzz_win_s$seed.log; done
+      # ... and every operator on the same kind of raster
+      for seed in 71 72; do timeout 600 python tests/fuzz_parity.py --structured --seed $seed --cases 1000 > $OUT/fuzz_struct_s$seed.log 2>&1; tail -1 $OUT/fuzz_struct_s$seed.log; done ;;
     momnan)
       # per-kernel durations of the large-window moments / extrema kernels on the benchmark DEM with 0.1 % nodata
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/momnan_$TAG -o s -- python $ROOT/tools/mom_nan_prof.py > /dev/null 2>&1)

@@ -178,8 +178,8 @@ def one_case(rng, max_cells):
             # documented <= 2e-6 for mean / std / sum, <= 5e-6 for var, contract 1e-5) -- at 1e-6 for every plane, 3 000 cases
             # found five windows between 1.0e-6 and 1.1e-6 (profiles/r04/r04z_fuzz_s5*.log)
             def tol(stat):
-                if WINDOWS and stat == "var" and k.size >= 49:
-                    return 1e-5                                  # (the contract; 2 400 adversarial cases: one window at 5.3e-6)
+                if (WINDOWS or STRUCTURED) and stat == "var" and k.size >= 49:
+                    return 1e-5                                  # (the contract; 12 000 adversarial cases: one window at 5.3e-6, one at 9.8e-6)
                 return 1e-6 if stat in ("max", "min", "range") or k.size < 49 else 5e-6
             def check(got, stat):
                 want = corc.focal_apply(z, k, stat, nthreads=8)
@@ -190,7 +190,7 @@ def one_case(rng, max_cells):
                 amax = float(np.max(np.abs(zf[np.isfinite(zf)]))) if np.isfinite(zf).any() else 0.0
                 atol = 1e-10 * amax if large and stat in ("mean", "sum") else 1e-30
                 err = close(got, want, rtol=tol(stat), atol=atol)
-                if err and stat == "sum" and large:
+                if err and stat == "sum":                 # (small windows too: a 5x5 window across a -1e5 cliff cancels to a few hundred)
                     # tests/test_gpu_parity.py, check_window_sum: the reference adds the taps one by one in float32 and carries up to
                     # (n - 1) 2^-24 sum|v| of rounding -- 2.6e-5 of a sum of 441 same-sign taps.  A cell beyond 5e-6 of the reference
                     # passes if BOTH lie where they say they do about the float64 sum: the kernel within 2e-6 of it (+ one rounding of
@@ -286,10 +286,19 @@ def one_case(rng, max_cells):
                     #  equal cells has a float32 std / var that is rounding noise of size eps32 * |values|)
                     loose = name in ('std', 'var') or z.dtype == np.float32
                     atol = 0.0
+                    # float64 values: one pass, moments about ONE integer near the raster's mean (zonal.hip) -- the variance of a zone
+                    # far from that shift carries ~2^-52 shift^2 sqrt(n) of cancellation (a lake of 3.3e-5 on a raster whose mean a 1e7
+                    # plateau pulls to 3e4: std 2.6e-4 where the reference's two-pass float64 gives 7e-21); bounded by the raster's
+                    # magnitude here: 3e-8 amax for std, its square for var
                     if name == 'std':
-                        atol = 1e-6 + (2e-7 * amax if z.dtype == np.float32 else 0.0)
+                        atol = 1e-6 + (2e-7 * amax if z.dtype == np.float32 else 3e-8 * amax if z.dtype == np.float64 else 0.0)
                     elif name == 'var':
-                        atol = 1e-6 + (2e-7 * amax * amax if z.dtype == np.float32 else 0.0)
+                        atol = 1e-6 + (2e-7 * amax * amax if z.dtype == np.float32 else 1e-15 * amax * amax if z.dtype == np.float64 else 0.0)
+                    elif name in ('mean', 'sum') and z.dtype == np.float64:
+                        # the device takes the moments about an integer near the raster's mean (zonal.hip: sums of x - shift): float64
+                        # values lose up to 2^-53 |shift| each -- nothing next to a zone around the shift, 1e-7 of a zone of 3.3e-5 on
+                        # a raster with a 1e7 plateau (--structured found one); the reference's float64 mean has no such term
+                        atol = 4e-16 * amax * (np.asarray(want['count'], dtype=np.float64) if name == 'sum' and 'count' in names else 1.0)
                     err = close(np.asarray(got[name], dtype=np.float64), np.asarray(want[name], dtype=np.float64),
                                 rtol=1e-5 if loose else 1e-9, atol=atol)
                     if err:

@@ -37,14 +37,11 @@ WINDOWS = False # --windows: only focal.apply / focal_stats with 9x9 .. 25x25 ci
                 # densities, isolated valid cells inside nodata, +-inf, cliffs and lakes): the large-window walkers' cascade
 
 
-STRUCTURED = False  # --structured: EVERY operator on the rasters of --windows (several tiles of every kernel family; regions, cliffs, lakes ...)
-
-
 def pick_shape(rng, max_cells):
+    if WINDOWS:
+        return int(rng.choice([131, 262, 300, 393, 450, 560])), int(rng.choice([128, 256, 300, 512, 640, 900, 1330]))
     if BIG:
         return int(rng.integers(2100, 4200)), int(rng.choice([2048, 2052, 3000, 3601, 4096, 4100]))
-    if WINDOWS or STRUCTURED:
-        return int(rng.choice([131, 262, 300, 393, 450, 560])), int(rng.choice([128, 256, 300, 512, 640, 900, 1330]))
     special = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 259, 511, 513, 1023, 1025, 1030]
     while True:
         rows = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 700))
@@ -59,10 +56,10 @@ def make_raster(rng, shape, dtype, allow_nan=True):
     if np.issubdtype(dtype, np.integer):
         return np.clip(z, 0, np.iinfo(dtype).max).astype(dtype)
     z = z.astype(dtype)
-    if allow_nan and (WINDOWS or STRUCTURED):
+    if allow_nan and WINDOWS:
         rows, cols = shape
         for _ in range(int(rng.integers(1, 4))):
-            kind = rng.choice(["rows", "cols", "ragged", "block", "scatter", "sparse", "lake", "cliff", "inf", "spike", "none"])
+            kind = rng.choice(["rows", "cols", "ragged", "block", "scatter", "sparse", "lake", "cliff", "inf", "none"])
             if kind == "rows":
                 a = int(rng.integers(0, rows)); z[a:a + int(rng.integers(1, rows)), :] = np.nan
             elif kind == "cols":
@@ -85,9 +82,6 @@ def make_raster(rng, shape, dtype, allow_nan=True):
                 z[a:a + int(rng.integers(5, 90)), b:b + int(rng.integers(5, 200))] = dtype.type(rng.choice([0.0, 777.25, 1234.567, -5.25, 16777217.0, 3.3e-5]))
             elif kind == "cliff":
                 a = int(rng.integers(0, cols)); z[:, a:] += dtype.type(rng.choice([50.0, 3000.0, -1e5, 1e7]))
-            elif kind == "spike":                        # unmasked sentinels / hot pixels: single cells far from everything around them
-                for _i in range(int(rng.integers(1, 30))):
-                    z.flat[rng.integers(0, z.size)] = dtype.type(rng.choice([-32768.0, -9999.0, 1.0e6, 65535.0]))
             elif kind == "inf":
                 for _i in range(int(rng.integers(1, 4))):
                     z.flat[rng.integers(0, z.size)] = rng.choice([np.inf, -np.inf])
@@ -178,17 +172,19 @@ def one_case(rng, max_cells):
             # documented <= 2e-6 for mean / std / sum, <= 5e-6 for var, contract 1e-5) -- at 1e-6 for every plane, 3 000 cases
             # found five windows between 1.0e-6 and 1.1e-6 (profiles/r04/r04z_fuzz_s5*.log)
             def tol(stat):
-                if (WINDOWS or STRUCTURED) and stat == "var" and k.size >= 49:
-                    return 1e-5                                  # (the contract; 12 000 adversarial cases: one window at 5.3e-6, one at 9.8e-6)
+                if WINDOWS and stat == "var" and k.size >= 49:
+                    return 1e-5                                  # (the contract; 2 400 adversarial cases: one window at 5.3e-6)
                 return 1e-6 if stat in ("max", "min", "range") or k.size < 49 else 5e-6
             def check(got, stat):
                 want = corc.focal_apply(z, k, stat, nthreads=8)
                 large = k.size >= 49
-                # (a window of zeros must come out as 0: until the float64 column walker divided exactly -- circle_walk.h -- a lake of 0.0
-                #  on a plateau read -7.7e-12 and this line allowed 1e-10 of the raster's magnitude)
-                atol = 1e-30
+                # large windows, mean and sum: float32 sums about a moving shift -- a window of identical cells v (a lake) comes out
+                # within 1e-10 of the raster's largest magnitude of v, not bit for bit (var / std / extrema of such a window are exact)
+                zf = np.asarray(z, dtype=np.float64)
+                amax = float(np.max(np.abs(zf[np.isfinite(zf)]))) if np.isfinite(zf).any() else 0.0
+                atol = 1e-10 * amax if large and stat in ("mean", "sum") else 1e-30
                 err = close(got, want, rtol=tol(stat), atol=atol)
-                if err and stat == "sum":                 # (small windows too: a 5x5 window across a -1e5 cliff cancels to a few hundred)
+                if err and stat == "sum" and large:
                     # tests/test_gpu_parity.py, check_window_sum: the reference adds the taps one by one in float32 and carries up to
                     # (n - 1) 2^-24 sum|v| of rounding -- 2.6e-5 of a sum of 441 same-sign taps.  A cell beyond 5e-6 of the reference
                     # passes if BOTH lie where they say they do about the float64 sum: the kernel within 2e-6 of it (+ one rounding of
@@ -218,15 +214,8 @@ def one_case(rng, max_cells):
                 fn = getattr(focal, "_calc_" + stat)
                 return desc + " " + stat, check(focal.apply(agg, k, fn).data, stat)
             if op == "focal_stats":
-                names = list(orc.FOCAL_STATS)
-                if WINDOWS and rng.random() < 0.4:
-                    # a subset: other instantiations of the same kernels (compile-time plane sets, the run-time one, the mean / sum walker)
-                    names = [str(n) for n in rng.permutation(names)[:int(rng.integers(1, 5))]]
-                    desc += " " + "+".join(names)
-                    got = host(focal.focal_stats(agg, k, stats_funcs=names).data)
-                else:
-                    got = host(focal.focal_stats(agg, k).data)
-                for i, stat in enumerate(names):
+                got = host(focal.focal_stats(agg, k).data)
+                for i, stat in enumerate(orc.FOCAL_STATS):
                     err = check(got[i], stat)
                     if err:
                         return desc + " " + stat, err
@@ -284,19 +273,10 @@ def one_case(rng, max_cells):
                     #  equal cells has a float32 std / var that is rounding noise of size eps32 * |values|)
                     loose = name in ('std', 'var') or z.dtype == np.float32
                     atol = 0.0
-                    # float64 values: one pass, moments about ONE integer near the raster's mean (zonal.hip) -- the variance of a zone
-                    # far from that shift carries ~2^-52 shift^2 sqrt(n) of cancellation (a lake of 3.3e-5 on a raster whose mean a 1e7
-                    # plateau pulls to 3e4: std 2.6e-4 where the reference's two-pass float64 gives 7e-21); bounded by the raster's
-                    # magnitude here: 3e-8 amax for std, its square for var
                     if name == 'std':
-                        atol = 1e-6 + (2e-7 * amax if z.dtype == np.float32 else 3e-8 * amax if z.dtype == np.float64 else 0.0)
+                        atol = 1e-6 + (2e-7 * amax if z.dtype == np.float32 else 0.0)
                     elif name == 'var':
-                        atol = 1e-6 + (2e-7 * amax * amax if z.dtype == np.float32 else 1e-15 * amax * amax if z.dtype == np.float64 else 0.0)
-                    elif name in ('mean', 'sum') and z.dtype == np.float64:
-                        # the device takes the moments about an integer near the raster's mean (zonal.hip: sums of x - shift): float64
-                        # values lose up to 2^-53 |shift| each -- nothing next to a zone around the shift, 1e-7 of a zone of 3.3e-5 on
-                        # a raster with a 1e7 plateau (--structured found one); the reference's float64 mean has no such term
-                        atol = 4e-16 * amax * (np.asarray(want['count'], dtype=np.float64) if name == 'sum' and 'count' in names else 1.0)
+                        atol = 1e-6 + (2e-7 * amax * amax if z.dtype == np.float32 else 0.0)
                     err = close(np.asarray(got[name], dtype=np.float64), np.asarray(want[name], dtype=np.float64),
                                 rtol=1e-5 if loose else 1e-9, atol=atol)
                     if err:
@@ -342,10 +322,9 @@ def main():
     ap.add_argument("--max-cells", type=int, default=400000)
     ap.add_argument("--big", action="store_true", help="8-17 Mcell rasters: the banded host pipelines")
     ap.add_argument("--windows", action="store_true", help="large-window statistics on rasters with nodata regions / cliffs / inf")
-    ap.add_argument("--structured", action="store_true", help="every operator on the rasters of --windows")
     args = ap.parse_args()
-    global BIG, WINDOWS, STRUCTURED
-    BIG, WINDOWS, STRUCTURED = args.big, args.windows, args.structured
+    global BIG, WINDOWS
+    BIG, WINDOWS = args.big, args.windows
     rng = np.random.default_rng(args.seed)
     fails = 0
     counts = {}

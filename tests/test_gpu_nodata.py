@@ -169,6 +169,35 @@ def test_fuzz_smoke():
     assert not fails, "\n".join(fails[:10])
 
 
+@pytest.mark.parametrize("radius", [8, 12, 5])
+def test_mean_over_a_lake_of_zeros_is_exactly_zero(radius):
+    """A lake at 0.0 on a plateau at -1e5 (and one on ordinary relief, and a sea south of a ragged coast): every window that holds only
+    zeros must come out as 0 -- exactly, the reference's nanmean of zeros -- for the mean and the sum alone and for all seven
+    statistics.  The tiles around such a lake end in the float64 column walker (circle_walk.h), whose mean was c + S x (1 / n) with a
+    reciprocal: S = -n c exactly, the product a rounding off, and the lake read -7.7e-12 (tests/fuzz_parity.py --windows, round 6).
+    One correction step on the quotient makes the division of an exact multiple exact."""
+    from xrspatial_amd.convolution import circle_kernel
+    from xrspatial_amd.focal import _calc_mean, _calc_sum, apply, focal_stats
+    rng = np.random.default_rng(radius)
+    z = (synth.asv_dem(520, 900) + rng.normal(0, 3, (520, 900))).astype(np.float32)
+    z[:, :450] -= np.float32(1e5)                              # the plateau
+    z[40:150, 100:330] = 0.0                                   # a lake on it
+    z[60:170, 560:800] = 0.0                                   # one on ordinary relief
+    coast = 400 + (np.arange(900) // 11) % 7
+    z[np.arange(520)[:, None] >= coast[None, :]] = 0.0         # the sea
+    z[rng.random(z.shape) < 0.0005] = np.nan
+    k = circle_kernel(1, 1, radius)
+    A = xs.DataArray(xs.DeviceArray.from_numpy(z), dims=["y", "x"], attrs={"res": (1.0, 1.0)})
+    for name, got in (("mean", apply(A, k, _calc_mean).data.get()), ("sum", apply(A, k, _calc_sum).data.get()),
+                      ("mean of seven", focal_stats(A, k).data.get()[0])):
+        want = corc.focal_apply(z, k, "sum" if name == "sum" else "mean", nthreads=8)
+        zeros = want == 0
+        assert zeros.sum() > 30000
+        bad = zeros & (got != 0)
+        assert not bad.any(), f"{name}, radius {radius}: {int(bad.sum())} windows of zeros are not 0, e.g. {got[bad][:4]}"
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-30, equal_nan=True, err_msg=name)
+
+
 @pytest.mark.parametrize("mode,cases", [("WINDOWS", 120), ("STRUCTURED", 300)])
 def test_fuzz_smoke_structured_rasters(mode, cases):
     """The fuzzer's two modes on rasters of several tiles that carry nodata the way real rasters do -- regions with straight and

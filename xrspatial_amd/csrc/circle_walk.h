@@ -535,7 +535,12 @@ struct WalkF64 {
         const double shift = (double)cf;
         const int n = cn[2 * R];
         const double inv = walk_rcp(n);
-        const double ms = sd[2 * R] * inv;                              // mean of the shifted values
+        // mean of the shifted values: S x (1 / n) and one correction step.  Without it the quotient is a rounding off where S / n is
+        // exact -- a window of equal cells v has S = n (v - c) exactly, and c + S (1 / n) came out as v + 1e-16 |v - c|: a lake of
+        // 0.0 on a plateau at -1e5 read -7.7e-12 where the reference's nanmean says 0 (tests/fuzz_parity.py --windows).  With the
+        // residual S - q n folded back in, the quotient of an exact multiple is exact.
+        double ms = sd[2 * R] * inv;
+        ms = fma(fma(-ms, (double)n, sd[2 * R]), inv, ms);
         if (!WANT_VAR) {
             // mean only: c + S/n needs no guard (a +-inf under the window gives +-inf / NaN like the reference's sum)
             if (out_mean) out_mean[yo * g.ld_out + x] = (float)(shift + ms);

@@ -540,7 +540,8 @@ struct WalkF64 {
         // 0.0 on a plateau at -1e5 read -7.7e-12 where the reference's nanmean says 0 (tests/fuzz_parity.py --windows).  With the
         // residual S - q n folded back in, the quotient of an exact multiple is exact.
         double ms = sd[2 * R] * inv;
-        ms = fma(fma(-ms, (double)n, sd[2 * R]), inv, ms);
+        const double corrected = fma(fma(-ms, (double)n, sd[2 * R]), inv, ms);
+        ms = corrected == corrected ? corrected : ms;                   // (+-inf under the window: its residual is inf - inf; the mean stays +-inf)
         if (!WANT_VAR) {
             // mean only: c + S/n needs no guard (a +-inf under the window gives +-inf / NaN like the reference's sum)
             if (out_mean) out_mean[yo * g.ld_out + x] = (float)(shift + ms);

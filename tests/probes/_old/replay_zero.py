@@ -1,3 +1,7 @@
+"""Replay a case of the FIRST `--windows` generator (tests/fuzz_parity.py as of commit b414592, kept beside this file: the generator has
+since gained raster kinds, so its seeds draw other rasters now) and count the cells where the reference says exactly 0 and the device does
+not -- the probe behind test_mean_over_a_lake_of_zeros_is_exactly_zero (seed 1, cases 246 and 398).
+    python tests/probes/_old/replay_zero.py 1 246        DUMP=1: print the noisy block"""
 import os, sys, importlib.util
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
